@@ -1,0 +1,504 @@
+/*
+ * sge_amd.h — C ABI of the MI355X (gfx950) character-update path.
+ *
+ * This is the drop-in boundary for ONE hot path of kelian343/swift-game-engine:
+ * MotionProfile pose evaluation + bone palette, 4-weight linear-blend skinning,
+ * and capsule-CCD move-and-slide against static triangle meshes.  The reference
+ * has no FFI layer; each entry point below names the Swift surface it replaces
+ * (paths relative to the reference checkout).  A Swift host binds these through
+ * a module map; tests and bench.py bind them with ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes; no C++/torch types; all structs are POD with the
+ *     exact layouts below (static_asserted in the implementation);
+ *   - matrices are column-major float[16] (simd float4x4 memory order);
+ *     quaternions are float[4] = (ix, iy, iz, r) (simd_quatf memory order);
+ *   - every function returns SGE_OK (0) or an SGE_ERR_* code; create returns NULL
+ *     on failure, mirroring the reference's `init?` convention
+ *     (Game/RTSkinningEncoder.swift:14);
+ *   - host pointers unless a parameter is named d_* (device pointer);
+ *   - work is enqueued on the context's HIP stream and completes asynchronously,
+ *     like the reference's MTLCommandBuffer encode (RTSkinningEncoder.swift:27);
+ *     call sge_synchronize() (or a *_download, which synchronises) to wait;
+ *   - one context per GPU, one caller thread at a time (the reference runs on the
+ *     main actor, Game.xcodeproj/project.pbxproj:420).
+ *
+ * There is NO CPU fallback: without a visible gfx950 device sge_context_create
+ * fails and every other call needs a context.
+ */
+#ifndef SGE_AMD_H
+#define SGE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGE_ABI_VERSION 1
+
+typedef struct sge_context sge_context;
+
+enum {
+    SGE_OK = 0,
+    SGE_ERR_INVALID = 1,   /* bad argument / shape mismatch */
+    SGE_ERR_DEVICE = 2,    /* HIP error (message via sge_last_error) */
+    SGE_ERR_STATE = 3,     /* required upload missing */
+    SGE_ERR_CAPACITY = 4   /* a fixed device-side capacity was exceeded */
+};
+
+#define SGE_MAX_BONES 256
+#define SGE_MAX_PROFILES 16
+#define SGE_MAX_FOURIER_ORDER 8
+#define SGE_MAX_COEFFS (1 + 2 * SGE_MAX_FOURIER_ORDER)
+#define SGE_MAX_OVERLAP_HITS 8
+#define SGE_MANIFOLD_MAX 4 /* ContactManifoldCache.maxCount, Game/Systems.swift:1160 */
+
+/* ------------------------------------------------------------------------- */
+/* Data contracts (Game/Components.swift)                                     */
+/* ------------------------------------------------------------------------- */
+
+/* SurfaceMaterial, Components.swift:704-716 */
+typedef struct sge_surface_material {
+    float muS;
+    float muK;
+    uint32_t flattenGround;
+} sge_surface_material;
+
+/* BodyType, Components.swift:543-547 */
+enum { SGE_BODY_STATIC = 0, SGE_BODY_KINEMATIC = 1, SGE_BODY_DYNAMIC = 2 };
+
+/* PhysicsBodyComponent (Components.swift:549-598) plus the entity's
+ * TransformComponent.rotation as last written by PhysicsWritebackSystem
+ * (Systems.swift:2249-2267), which PoseStackSystem reads one step stale
+ * (ProceduralPoseSystem.swift:345). 96 bytes. */
+typedef struct sge_body_state {
+    double position[3];
+    double linearVelocity[3];
+    float rotation[4];
+    float transformRotation[4];
+    uint32_t bodyType;
+    uint32_t _pad[3];
+} sge_body_state;
+
+enum {
+    SGE_AGENT_PRESENT = 1u << 0,        /* entity has an AgentCollisionComponent */
+    SGE_AGENT_SOLID = 1u << 1,          /* .isSolid */
+    SGE_AGENT_RADIUS_OVERRIDE = 1u << 2 /* .radiusOverride != nil */
+};
+
+/* The constant part of CharacterControllerComponent (Components.swift:353-431)
+ * and AgentCollisionComponent (Components.swift:433-445). 64 bytes. */
+typedef struct sge_controller_params {
+    float radius;
+    float halfHeight;
+    float skinWidth;
+    float groundSnapSkin;
+    float snapDistance;
+    float fallProbeDistance;
+    float groundSnapMaxSpeed;
+    float groundSnapMaxToi;
+    float groundSnapMaxStep;
+    float groundSweepMaxStep;
+    int32_t maxSlideIterations;
+    float minGroundDot;
+    uint32_t collisionMask;
+    uint32_t agentFlags;
+    float agentRadiusOverride;
+    float agentMassWeight;
+} sge_controller_params;
+
+enum {
+    SGE_CTRL_GROUNDED = 1u << 0,
+    SGE_CTRL_GROUNDED_NEAR = 1u << 1,
+    SGE_CTRL_GROUND_SLIDING = 1u << 2
+};
+
+/* The per-step mutable part of CharacterControllerComponent. 128 bytes. */
+typedef struct sge_controller_state {
+    float groundNormal[3];
+    int32_t groundTriangleIndex;
+    float sideContactNormal[3];
+    int32_t sideContactFrames;
+    int32_t manifoldTriangles[SGE_MANIFOLD_MAX];
+    float manifoldNormals[SGE_MANIFOLD_MAX][3];
+    int32_t manifoldCount;
+    int32_t manifoldFrames;
+    int32_t groundTransitionFrames;
+    uint32_t flags; /* SGE_CTRL_* */
+    float groundDistance;
+    uint32_t _pad[3];
+} sge_controller_state;
+
+enum {
+    SGE_INTENT_PRESENT = 1u << 0,     /* entity has a MoveIntentComponent */
+    SGE_INTENT_HAS_FACING_YAW = 1u << 1,
+    SGE_INTENT_DODGE_ACTIVE = 1u << 2 /* DodgeActionComponent.active */
+};
+
+/* MoveIntentComponent + MovementComponent (Components.swift:600-618, 684-702)
+ * as consumed by PhysicsIntentSystem (Systems.swift:205-250). 32 bytes. */
+typedef struct sge_move_intent {
+    float desiredVelocity[3];
+    float desiredFacingYaw;
+    uint32_t flags; /* SGE_INTENT_* */
+    float maxAcceleration;
+    float maxDeceleration;
+    uint32_t _pad;
+} sge_move_intent;
+
+/* LocomotionState, Components.swift:223-228 */
+enum { SGE_LOCO_IDLE = 0, SGE_LOCO_WALK = 1, SGE_LOCO_RUN = 2, SGE_LOCO_FALLING = 3 };
+
+enum {
+    SGE_LOCO_IS_BLENDING = 1u << 0,
+    SGE_LOCO_PRESENT = 1u << 1,       /* entity has a LocomotionProfileComponent */
+    SGE_MOTION_PRESENT = 1u << 2,     /* entity has a MotionProfileComponent */
+    SGE_MOTION_LOOP = 1u << 3,
+    SGE_MOTION_IN_PLACE = 1u << 4
+};
+
+/* LocomotionProfileComponent + MotionProfileComponent
+ * (Components.swift:203-293). Profiles are indices into the table uploaded by
+ * sge_motion_profiles_upload. 96 bytes. */
+typedef struct sge_locomotion_state {
+    int32_t profile[4]; /* idle, walk, run, fall */
+    float time[4];      /* idleTime, walkTime, runTime, fallTime */
+    float idleEnterSpeed;
+    float idleExitSpeed;
+    float runEnterSpeed;
+    float runExitSpeed;
+    float fallMinDropHeight;
+    float blendTime;
+    float blendT;
+    float idleInertiaHalfLife;
+    float idleInertia;
+    int32_t fromState;
+    int32_t state;
+    uint32_t flags; /* SGE_LOCO_* | SGE_MOTION_* */
+    float motionTime;     /* MotionProfileComponent.time */
+    float playbackRate;   /* MotionProfileComponent.playbackRate */
+    int32_t motionProfile; /* MotionProfileComponent.profile */
+    float posePhase;      /* out: PoseComponent.phase */
+} sge_locomotion_state;
+
+enum {
+    SGE_ACTION_PRESENT = 1u << 0,
+    SGE_ACTION_ACTIVE = 1u << 1,
+    SGE_ACTION_LOOP = 1u << 2,
+    SGE_ACTION_IN_PLACE = 1u << 3,
+    SGE_ACTION_EXITING = 1u << 4,
+    SGE_ACTION_HAS_DODGE = 1u << 5 /* entity has a DodgeActionComponent */
+};
+
+/* ActionAnimationComponent (Components.swift:620-653); dodgeEnd is
+ * `dodge.endTime > 0 ? dodge.endTime : dodge.duration` (Systems.swift:488). 32 bytes. */
+typedef struct sge_action_state {
+    int32_t profile;
+    float time;
+    float playbackRate;
+    float weight;
+    float blendInTime;
+    float blendOutHalfLife;
+    float dodgeEnd;
+    uint32_t flags; /* SGE_ACTION_* */
+} sge_action_state;
+
+/* ------------------------------------------------------------------------- */
+/* Context                                                                    */
+/* ------------------------------------------------------------------------- */
+
+/* Creates the per-GPU context (device memory owner, HIP stream, kernels).
+ * Returns NULL when no gfx950 device `device_index` exists. */
+sge_context* sge_context_create(int device_index);
+void sge_context_destroy(sge_context* ctx);
+/* Last error text of this thread ("" if none). */
+const char* sge_last_error(void);
+int sge_abi_version(void);
+/* Use the caller's hipStream_t (e.g. torch's current stream) instead of the
+ * context-owned one. NULL restores the owned stream. */
+int sge_context_set_stream(sge_context* ctx, void* hip_stream);
+/* Blocks until everything enqueued on the context's stream has completed. */
+int sge_synchronize(sge_context* ctx);
+
+enum {
+    SGE_OPT_STORE_POSE_DEBUG = 1, /* also keep PoseComponent.local/.model per character */
+    SGE_OPT_SKIN_LAYOUT = 2,      /* SGE_LAYOUT_* for the skinned output streams */
+    SGE_OPT_PROFILE = 3           /* 1: bracket every kernel with HIP events */
+};
+enum {
+    SGE_LAYOUT_PACKED = 0,  /* positions/normals float[3] (12 B), tangents float[4] */
+    SGE_LAYOUT_PADDED16 = 1 /* Metal `device float3*` stride: 16 B per element */
+};
+int sge_context_set_option(sge_context* ctx, int option, int value);
+
+/* ------------------------------------------------------------------------- */
+/* Skeleton — Game/Skeleton.swift, Game/SkeletonLoader.swift                  */
+/* ------------------------------------------------------------------------- */
+
+/* Host helper: SkeletonLoader.buildSkeleton (SkeletonLoader.swift:28-87) and
+ * Skeleton.init's invBindModel (Skeleton.swift:155-156).  Outputs are
+ * caller-allocated: restTranslation [B][3], bindLocal [B][16],
+ * invBindModel [B][16], rootRotationFix [16]. zero_root = resolved RootRule. */
+int sge_skeleton_build(int32_t bone_count, const int32_t* parent,
+                       const float* raw_translations, const float* pre_rotation_degrees,
+                       const float root_fix_degrees[3], float unit_scale, int zero_root,
+                       float* rest_translation, float* bind_local, float* inv_bind_model,
+                       float* root_rotation_fix);
+
+typedef struct sge_skeleton_desc {
+    int32_t boneCount;
+    const int32_t* parent;           /* [B], parent index < child index, root = -1 */
+    const float* bindLocal;          /* [B][16] */
+    const float* invBindModel;       /* [B][16] */
+    const float* restTranslation;    /* [B][3] */
+    const float* rawRestTranslation; /* [B][3] */
+    const float* preRotationDegrees; /* [B][3] */
+    float rootRotationFix[16];
+    float unitScale;
+    int32_t pelvisIndex; /* skeleton.semantic(.pelvis) or -1 */
+    int32_t leanIndex;   /* chest ?? spine3 ?? spine2 ?? spine1 or -1 (ProceduralPoseSystem.swift:371-374) */
+} sge_skeleton_desc;
+
+/* Replaces constructing `Skeleton` for the GPU path (Skeleton.swift:127-173). */
+int sge_skeleton_upload(sge_context* ctx, const sge_skeleton_desc* desc);
+
+/* ------------------------------------------------------------------------- */
+/* Motion profiles — Game/Animation.swift                                     */
+/* ------------------------------------------------------------------------- */
+
+#define SGE_AXIS_ABSENT 255
+
+/* One MotionProfile (Animation.swift:11-53) flattened per skeleton bone.
+ * Axis order: translation x,y,z then rotation x,y,z. */
+typedef struct sge_motion_profile_desc {
+    int32_t order;       /* MotionProfile.order */
+    float cycleDuration; /* phase?.cycleDuration ?? duration */
+    const uint8_t* bonePresent; /* [B]: 1 when profile.bones[skeleton.names[i]] exists */
+    const uint8_t* coeffCount;  /* [B][6]: array length, SGE_AXIS_ABSENT when the axis is nil */
+    const float* coeffs;        /* [B][6][SGE_MAX_COEFFS] = [a0,a1,b1,...] */
+} sge_motion_profile_desc;
+
+/* Replaces MotionProfileLoader.load + the per-bone dictionary lookups of
+ * ProceduralPoseSystem.swift:153-154 with a dense device table. */
+int sge_motion_profiles_upload(sge_context* ctx, const sge_motion_profile_desc* profiles, int32_t count);
+
+/* ------------------------------------------------------------------------- */
+/* Skinned mesh + skinning — Game/RTSkinningEncoder.swift,                    */
+/* Game/RTGeometryCache.swift:43-52,492-576, Game/RayTracing.metalinc:732-776 */
+/* ------------------------------------------------------------------------- */
+
+/* Host helper: MeshTangents.compute (MeshTangents.swift:10-83). Exactly one of
+ * indices16 / indices32 is non-NULL. tangents out [V][4]. */
+int sge_mesh_tangents_compute(int32_t vertex_count, const float* positions, const float* normals,
+                              const float* uvs, const uint16_t* indices16, const uint32_t* indices32,
+                              int32_t index_count, float* tangents);
+
+typedef struct sge_skinned_mesh_desc {
+    int32_t vertexCount;
+    const float* positions;      /* [V][3] */
+    const float* normals;        /* [V][3] */
+    const float* tangents;       /* [V][4] */
+    const uint16_t* boneIndices; /* [V][4] */
+    const float* boneWeights;    /* [V][4] */
+    const float* invBindModel;   /* optional [invBindCount][16]: SkinnedMeshDescriptor.invBindModel */
+    int32_t invBindCount;
+} sge_skinned_mesh_desc;
+
+/* Uploads the crowd's shared source mesh once (the reference caches source
+ * buffers per unique mesh, RTGeometryCache.swift:499-554). When invBindModel is
+ * given with invBindCount == boneCount, the pose stage emits
+ * model[i] * mesh.invBindModel[i] (Systems.swift:2519-2527) as the palette. */
+int sge_skinned_mesh_upload(sge_context* ctx, const sge_skinned_mesh_desc* desc);
+
+/* RTSkinningJob (RTGeometryCache.swift:43-52) with MTLBuffers as device pointers. */
+typedef struct sge_skinning_job {
+    const void* d_sourcePositions;   /* layout per sourceLayout */
+    const void* d_sourceNormals;
+    const void* d_sourceTangents;    /* float4 */
+    const void* d_sourceBoneIndices; /* ushort4 */
+    const void* d_sourceBoneWeights; /* float4 */
+    const void* d_palette;           /* float4x4[paletteCount] */
+    int32_t paletteCount;
+    int32_t vertexCount;
+    int32_t dstBaseVertex;
+    int32_t sourceLayout; /* SGE_LAYOUT_* of positions/normals */
+} sge_skinning_job;
+
+/* RTSkinningEncoder.encode (RTSkinningEncoder.swift:27-56): one skinningKernel
+ * dispatch per job into the shared output streams. Asynchronous. */
+int sge_skinning_encode(sge_context* ctx, void* d_outPositions, void* d_outNormals,
+                        void* d_outTangents, int32_t out_layout,
+                        const sge_skinning_job* jobs, int32_t job_count);
+
+/* Device-pointer accessors for the context-owned crowd buffers (for building
+ * sge_skinning_job lists or handing the streams to a downstream consumer). */
+int sge_crowd_buffers(sge_context* ctx, void** d_palettes, void** d_outPositions,
+                      void** d_outNormals, void** d_outTangents);
+int sge_skinned_mesh_buffers(sge_context* ctx, void** d_positions, void** d_normals,
+                             void** d_tangents, void** d_boneIndices, void** d_boneWeights);
+
+/* ------------------------------------------------------------------------- */
+/* Collision world — Game/CollisionQuery.swift                                */
+/* ------------------------------------------------------------------------- */
+
+/* One collidable StaticMeshComponent (Components.swift:323-351) with its
+ * TransformComponent.modelMatrix; mesh = collisionMesh ?? mesh
+ * (CollisionQuery.swift:344). */
+typedef struct sge_static_mesh_entity {
+    const float* positions; /* [vertexCount][3], mesh-local */
+    int32_t vertexCount;
+    const uint32_t* indices;
+    int32_t indexCount;
+    float modelMatrix[16];
+    sge_surface_material material;
+    const sge_surface_material* triangleMaterials; /* optional, used when triangleMaterialCount == indexCount/3 */
+    int32_t triangleMaterialCount;
+    uint32_t collisionLayer;
+} sge_static_mesh_entity;
+
+/* CollisionQuery.init / TriangleMeshSet.rebuild + BVH.build
+ * (CollisionQuery.swift:331-417, 577-670) for the static set. */
+int sge_collision_rebuild_static(sge_context* ctx, const sge_static_mesh_entity* entities, int32_t count);
+
+/* Introspection for parity tests: sizes, then copies of the host-side build. */
+typedef struct sge_bvh_node {
+    float boundsMin[3];
+    float boundsMax[3];
+    int32_t left, right, start, count, parent;
+} sge_bvh_node;
+int sge_collision_counts(sge_context* ctx, int32_t* vertex_count, int32_t* triangle_count, int32_t* node_count);
+int sge_collision_copy(sge_context* ctx, float* positions, uint32_t* indices, float* triangle_aabbs,
+                       sge_bvh_node* nodes, int32_t* tri_order, int32_t* tri_leaf);
+
+enum { SGE_CAST = 0, SGE_CAST_BLOCKING = 1, SGE_CAST_GROUND = 2 };
+
+typedef struct sge_capsule_query {
+    float from[3];
+    float delta[3]; /* ignored by overlap queries */
+    float radius;
+    float halfHeight;
+    float minNormalY; /* SGE_CAST_GROUND only */
+    uint32_t mask;
+    uint32_t mode; /* SGE_CAST* */
+} sge_capsule_query;
+
+/* CapsuleCastHit, CollisionQuery.swift:36-43 */
+typedef struct sge_capsule_cast_hit {
+    int32_t hit; /* 0 = nil */
+    float toi;
+    float position[3];
+    float normal[3];
+    float triangleNormal[3];
+    int32_t triangleIndex;
+    sge_surface_material material;
+} sge_capsule_cast_hit;
+
+/* CapsuleOverlapHit, CollisionQuery.swift:45-52 */
+typedef struct sge_capsule_overlap_hit {
+    float depth;
+    float position[3];
+    float normal[3];
+    float triangleNormal[3];
+    int32_t triangleIndex;
+    sge_surface_material material;
+} sge_capsule_overlap_hit;
+
+/* CollisionQuery.capsuleCast / capsuleCastBlocking / capsuleCastGround
+ * (CollisionQuery.swift:96-135), batched: out[i] answers queries[i]. Synchronous. */
+int sge_capsule_cast_batch(sge_context* ctx, const sge_capsule_query* queries, int32_t count,
+                           sge_capsule_cast_hit* out);
+/* CollisionQuery.capsuleOverlapAll (CollisionQuery.swift:148-159), batched:
+ * out[i*max_hits + k], k < out_counts[i]; max_hits in 1..SGE_MAX_OVERLAP_HITS. */
+int sge_capsule_overlap_all_batch(sge_context* ctx, const sge_capsule_query* queries, int32_t count,
+                                  int32_t max_hits, sge_capsule_overlap_hit* out, int32_t* out_counts);
+
+/* ------------------------------------------------------------------------- */
+/* Characters + the batched fixed step                                        */
+/* ------------------------------------------------------------------------- */
+
+/* Sets the crowd size on this GPU; (re)allocates state, palettes and the
+ * skinned output streams (count * vertexCount vertices). */
+int sge_characters_resize(sge_context* ctx, int32_t count);
+/* Any pointer may be NULL (= leave / skip). Arrays are [count]. */
+int sge_characters_upload(sge_context* ctx, int32_t first, int32_t count,
+                          const sge_body_state* bodies, const sge_controller_params* params,
+                          const sge_controller_state* controllers, const sge_move_intent* intents,
+                          const sge_locomotion_state* locomotion, const sge_action_state* actions);
+int sge_characters_download(sge_context* ctx, int32_t first, int32_t count,
+                            sge_body_state* bodies, sge_controller_params* params,
+                            sge_controller_state* controllers, sge_move_intent* intents,
+                            sge_locomotion_state* locomotion, sge_action_state* actions);
+/* PoseComponent.palette / .model / .local (Components.swift:188-201) as
+ * [count][boneCount][16]; model/local need SGE_OPT_STORE_POSE_DEBUG. */
+int sge_palettes_download(sge_context* ctx, int32_t first, int32_t count,
+                          float* palette, float* model, float* local);
+/* Skinned output streams for vertices [first_vertex, first_vertex+count) of the
+ * crowd buffer, always returned packed: positions/normals [n][3], tangents [n][4]. */
+int sge_skinned_download(sge_context* ctx, int64_t first_vertex, int64_t vertex_count,
+                         float* positions, float* normals, float* tangents);
+
+enum {
+    SGE_STAGE_INTENT = 1u << 0,     /* PhysicsIntentSystem, Systems.swift:205-250 */
+    SGE_STAGE_GRAVITY = 1u << 1,    /* GravitySystem, Systems.swift:596-620 */
+    SGE_STAGE_MOVE = 1u << 2,       /* KinematicMoveStopSystem, Systems.swift:1823-1902 */
+    SGE_STAGE_LOCOMOTION = 1u << 3, /* LocomotionProfileSystem, Systems.swift:279-407 */
+    SGE_STAGE_ACTION = 1u << 4,     /* ActionAnimationSystem, Systems.swift:475-517 */
+    SGE_STAGE_POSE = 1u << 5,       /* PoseStackSystem, ProceduralPoseSystem.swift:13-406 */
+    SGE_STAGE_WRITEBACK = 1u << 6,  /* PhysicsWritebackSystem (rotation), Systems.swift:2249-2267 */
+    SGE_STAGE_SKIN = 1u << 7,       /* RTSkinningEncoder.encode over the crowd */
+    SGE_STAGE_AGENTS = 1u << 8,     /* capsule-capsule sweep vs the imported agent set, Systems.swift:1053-1091 */
+    SGE_STAGE_ALL_FIXED = 0x7Fu,
+    SGE_STAGE_ALL = 0xFFu
+};
+
+typedef struct sge_tick_desc {
+    float dt;         /* fixed step, TimeComponent.fixedDelta = 1/60 (Components.swift:526) */
+    float gravity[3]; /* (0,-98,0), Systems.swift:599 */
+    uint32_t stages;  /* SGE_STAGE_* in the reference's order (DemoScene.swift:57-75) */
+    int32_t first;    /* character range; count 0 = all */
+    int32_t count;
+    uint32_t _pad;
+} sge_tick_desc;
+
+/* One fixed step of the hot path for the character range. Asynchronous. */
+int sge_tick(sge_context* ctx, const sge_tick_desc* desc);
+
+/* AgentSweepState (Systems.swift:1023-1029), 32 bytes: the start-of-step
+ * snapshot collectAgentStates builds (Systems.swift:1592-1611). */
+typedef struct sge_agent_state {
+    float position[3];
+    float radius;
+    float velocity[3];
+    float halfHeight;
+} sge_agent_state;
+
+/* Packs this GPU's characters into d_out[count] (device), non-solid or
+ * agent-less characters get radius < 0. Asynchronous. */
+int sge_agents_export(sge_context* ctx, void* d_out);
+/* Declares the all-gathered agent set (device pointer, total entries) and the
+ * index of this GPU's first character inside it; binned on device into an XZ
+ * grid each step when SGE_STAGE_AGENTS is set. */
+int sge_agents_import(sge_context* ctx, const void* d_all, int32_t total, int32_t self_offset);
+
+/* Accumulated HIP-event kernel time since the last reset (SGE_OPT_PROFILE). */
+typedef struct sge_stage_times {
+    double move_ms, pose_ms, skin_ms, agents_ms;
+    int64_t move_launches, pose_launches, skin_launches, agents_launches;
+} sge_stage_times;
+int sge_profile_read(sge_context* ctx, sge_stage_times* out, int reset);
+
+/* Device-side counters of the move stage since the last reset (diagnostics; the
+ * reference's CollisionQueryStats, CollisionQuery.swift:280-290). */
+typedef struct sge_move_stats {
+    uint64_t queries;          /* BVH queries issued */
+    uint64_t candidates;       /* capsuleCandidateCount */
+    uint64_t sweepIterations;  /* capsuleSweepIterations */
+    uint64_t overflow;         /* traversal-stack or candidate overflows (must stay 0) */
+} sge_move_stats;
+int sge_move_stats_read(sge_context* ctx, sge_move_stats* out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGE_AMD_H */

@@ -1,0 +1,10 @@
+"""MI355X (gfx950) character-update path for kelian343/swift-game-engine.
+
+Only what the hot path needs lives here: csrc/ (HIP kernels + the C ABI of
+include/sge_amd.h), the ctypes mirror of that ABI (abi.py), the host driver
+(engine.py), the reference-named system adapters (systems.py) and asset
+preparation (assets.py). The directory name carries a hyphen, so import it with
+importlib.import_module("swift-game-engine_amd").
+"""
+from . import abi, assets, engine  # noqa: F401
+from .engine import CharacterEngine, SgeError, make_queries  # noqa: F401

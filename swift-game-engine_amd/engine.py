@@ -1,0 +1,287 @@
+"""Host driver above the C ABI (include/sge_amd.h): numpy arrays in, numpy arrays out.
+
+`CharacterEngine` is written against a tiny function table so that the parity
+tests can run the very same host code over the CPU oracle (tests/oracle_binding.py
+supplies that table); the product table below binds libsge_amd.so only and there
+is no fallback between the two.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from .abi import ptr
+
+
+class SgeError(RuntimeError):
+    pass
+
+
+class _ProductTable:
+    """sge_* entry points of the HIP library."""
+
+    def __init__(self, device_index=0, lib_path=None):
+        self.lib = abi.load_library(lib_path)
+        if self.lib.sge_abi_version() != 1:
+            raise SgeError("libsge_amd.so ABI version mismatch")
+        self.handle = self.lib.sge_context_create(int(device_index))
+        if not self.handle:
+            raise SgeError("sge_context_create failed: " + self.last_error())
+        self.is_product = True
+
+    def fn(self, name):
+        return getattr(self.lib, "sge_" + name)
+
+    def last_error(self):
+        return (self.lib.sge_last_error() or b"").decode()
+
+    def close(self):
+        if self.handle:
+            self.lib.sge_context_destroy(self.handle)
+            self.handle = None
+
+
+class CharacterEngine:
+    """One GPU's share of the crowd: skeleton, profiles, source mesh, collision world, characters."""
+
+    def __init__(self, device_index=0, table=None):
+        self.t = table if table is not None else _ProductTable(device_index)
+        self.h = self.t.handle
+        self.bone_count = 0
+        self.vertex_count = 0
+        self.count = 0
+        self._keep = []  # arrays referenced by descriptors during a call
+
+    # -- plumbing ---------------------------------------------------------- #
+    def _call(self, name, *args):
+        rc = self.t.fn(name)(self.h, *args)
+        if rc != abi.SGE_OK:
+            raise SgeError(f"{name} failed with code {rc}: {self.t.last_error()}")
+
+    def close(self):
+        self.t.close()
+
+    def synchronize(self):
+        if self.t.is_product:
+            self._call("synchronize")
+
+    def set_option(self, option, value):
+        if self.t.is_product:
+            self._call("context_set_option", int(option), int(value))
+
+    # -- skeleton ---------------------------------------------------------- #
+    def build_skeleton(self, assets):
+        """SkeletonLoader.buildSkeleton + Skeleton.init (host helper of the same library)."""
+        B = assets.bone_count
+        rest = np.zeros((B, 3), np.float32)
+        bind = np.zeros((B, 16), np.float32)
+        inv = np.zeros((B, 16), np.float32)
+        fix = np.zeros(16, np.float32)
+        rc = self.t.fn("skeleton_build")(B, ptr(assets.parent), ptr(assets.translations),
+                                        ptr(assets.pre_rotation_degrees), ptr(assets.root_fix_degrees),
+                                        C.c_float(assets.unit_scale), int(assets.zero_root),
+                                        ptr(rest), ptr(bind), ptr(inv), ptr(fix))
+        if rc != abi.SGE_OK:
+            raise SgeError("skeleton_build failed")
+        return {"restTranslation": rest, "bindLocal": bind, "invBindModel": inv, "rootRotationFix": fix}
+
+    def upload_skeleton(self, assets, built=None):
+        built = built or self.build_skeleton(assets)
+        d = abi.SkeletonDesc()
+        d.boneCount = assets.bone_count
+        arrays = {
+            "parent": np.ascontiguousarray(assets.parent, np.int32),
+            "bindLocal": np.ascontiguousarray(built["bindLocal"], np.float32),
+            "invBindModel": np.ascontiguousarray(built["invBindModel"], np.float32),
+            "restTranslation": np.ascontiguousarray(built["restTranslation"], np.float32),
+            "rawRestTranslation": np.ascontiguousarray(assets.translations, np.float32),
+            "preRotationDegrees": np.ascontiguousarray(assets.pre_rotation_degrees, np.float32),
+        }
+        d.parent = arrays["parent"].ctypes.data_as(C.POINTER(C.c_int32))
+        for k in ("bindLocal", "invBindModel", "restTranslation", "rawRestTranslation", "preRotationDegrees"):
+            setattr(d, k, arrays[k].ctypes.data_as(C.POINTER(C.c_float)))
+        d.rootRotationFix = (C.c_float * 16)(*[float(x) for x in built["rootRotationFix"]])
+        d.unitScale = assets.unit_scale
+        d.pelvisIndex = assets.pelvis_index
+        d.leanIndex = assets.lean_index
+        self._call("skeleton_upload", C.byref(d))
+        self.bone_count = assets.bone_count
+        self.skeleton = dict(built, parent=arrays["parent"])
+        return built
+
+    def upload_profiles(self, profiles):
+        descs = (abi.MotionProfileDesc * len(profiles))()
+        keep = []
+        for k, p in enumerate(profiles):
+            descs[k].order = p["order"]
+            descs[k].cycleDuration = p["cycleDuration"]
+            a = [np.ascontiguousarray(p["bonePresent"], np.uint8), np.ascontiguousarray(p["coeffCount"], np.uint8),
+                 np.ascontiguousarray(p["coeffs"], np.float32)]
+            keep.append(a)
+            descs[k].bonePresent = a[0].ctypes.data_as(C.POINTER(C.c_uint8))
+            descs[k].coeffCount = a[1].ctypes.data_as(C.POINTER(C.c_uint8))
+            descs[k].coeffs = a[2].ctypes.data_as(C.POINTER(C.c_float))
+        self._call("motion_profiles_upload", descs, len(profiles))
+
+    # -- skinned mesh ------------------------------------------------------ #
+    def compute_tangents(self, positions, normals, uvs, indices):
+        """MeshTangents.compute (host helper of the same library)."""
+        V = positions.shape[0]
+        out = np.zeros((V, 4), np.float32)
+        idx = np.ascontiguousarray(indices)
+        i16 = idx if idx.dtype == np.uint16 else None
+        i32 = idx if idx.dtype == np.uint32 else None
+        rc = self.t.fn("mesh_tangents_compute")(V, ptr(positions), ptr(normals), ptr(uvs), ptr(i16), ptr(i32),
+                                               int(idx.size), ptr(out))
+        if rc != abi.SGE_OK:
+            raise SgeError("mesh_tangents_compute failed")
+        return out
+
+    def upload_skinned_mesh(self, mesh, inv_bind_model=None):
+        if "tangents" not in mesh:
+            mesh = dict(mesh, tangents=self.compute_tangents(mesh["positions"], mesh["normals"], mesh["uvs"],
+                                                             mesh["indices"]))
+        d = abi.SkinnedMeshDesc()
+        V = mesh["positions"].shape[0]
+        d.vertexCount = V
+        keep = {k: np.ascontiguousarray(mesh[k], np.float32) for k in ("positions", "normals", "tangents", "boneWeights")}
+        keep["boneIndices"] = np.ascontiguousarray(mesh["boneIndices"], np.uint16)
+        for k in ("positions", "normals", "tangents", "boneWeights"):
+            setattr(d, k, keep[k].ctypes.data_as(C.POINTER(C.c_float)))
+        d.boneIndices = keep["boneIndices"].ctypes.data_as(C.POINTER(C.c_uint16))
+        if inv_bind_model is not None:
+            ib = np.ascontiguousarray(inv_bind_model, np.float32)
+            d.invBindModel = ib.ctypes.data_as(C.POINTER(C.c_float))
+            d.invBindCount = ib.shape[0]
+        self._call("skinned_mesh_upload", C.byref(d))
+        self.vertex_count = V
+        self.mesh = dict(mesh, **keep)
+        return self.mesh
+
+    # -- collision world --------------------------------------------------- #
+    def rebuild_static(self, entities):
+        """entities: list of dict(positions [V][3], indices u32, modelMatrix [16] (default identity),
+        material (muS, muK, flatten) (default SurfaceMaterial.default), layer (default 1))."""
+        descs = (abi.StaticMeshEntity * max(len(entities), 1))()
+        keep = []
+        for k, e in enumerate(entities):
+            pos = np.ascontiguousarray(e["positions"], np.float32)
+            idx = np.ascontiguousarray(e["indices"], np.uint32)
+            keep += [pos, idx]
+            descs[k].positions = pos.ctypes.data_as(C.POINTER(C.c_float))
+            descs[k].vertexCount = pos.shape[0]
+            descs[k].indices = idx.ctypes.data_as(C.POINTER(C.c_uint32))
+            descs[k].indexCount = idx.size
+            m = np.asarray(e.get("modelMatrix", np.eye(4, dtype=np.float32).reshape(16)), np.float32).reshape(16)
+            descs[k].modelMatrix = (C.c_float * 16)(*[float(x) for x in m])
+            mu = e.get("material", (0.8, 0.6, 0))
+            descs[k].material = abi.SurfaceMaterial(mu[0], mu[1], int(mu[2]))
+            tm = e.get("triangleMaterials")
+            if tm is not None:
+                tm = np.ascontiguousarray(tm, abi.material_dtype)
+                keep.append(tm)
+                descs[k].triangleMaterials = tm.ctypes.data_as(C.POINTER(abi.SurfaceMaterial))
+                descs[k].triangleMaterialCount = tm.shape[0]
+            descs[k].collisionLayer = int(e.get("layer", 1))
+        self._call("collision_rebuild_static", descs, len(entities))
+
+    def collision_counts(self):
+        v, t, n = C.c_int32(), C.c_int32(), C.c_int32()
+        self._call("collision_counts", C.byref(v), C.byref(t), C.byref(n))
+        return v.value, t.value, n.value
+
+    def collision_copy(self):
+        v, t, n = self.collision_counts()
+        out = {"positions": np.zeros((v, 3), np.float32), "indices": np.zeros(t * 3, np.uint32),
+               "aabbs": np.zeros((t, 2, 3), np.float32), "nodes": np.zeros(n, abi.bvh_node_dtype),
+               "triOrder": np.zeros(t, np.int32), "triLeaf": np.zeros(t, np.int32)}
+        self._call("collision_copy", ptr(out["positions"]), ptr(out["indices"]), ptr(out["aabbs"]),
+                   ptr(out["nodes"]), ptr(out["triOrder"]), ptr(out["triLeaf"]))
+        return out
+
+    def capsule_cast(self, queries):
+        q = np.ascontiguousarray(queries, abi.query_dtype)
+        out = np.zeros(q.shape[0], abi.cast_hit_dtype)
+        self._call("capsule_cast_batch", ptr(q), q.shape[0], ptr(out))
+        return out
+
+    def capsule_overlap_all(self, queries, max_hits=8):
+        q = np.ascontiguousarray(queries, abi.query_dtype)
+        out = np.zeros((q.shape[0], max_hits), abi.overlap_hit_dtype)
+        counts = np.zeros(q.shape[0], np.int32)
+        self._call("capsule_overlap_all_batch", ptr(q), q.shape[0], int(max_hits), ptr(out), ptr(counts))
+        return out, counts
+
+    # -- characters -------------------------------------------------------- #
+    def resize(self, n):
+        self._call("characters_resize", int(n))
+        self.count = int(n)
+
+    def upload(self, first=0, bodies=None, params=None, controllers=None, intents=None, locomotion=None, actions=None):
+        arrs = []
+        n = None
+        for a, dt in ((bodies, abi.body_dtype), (params, abi.params_dtype), (controllers, abi.controller_dtype),
+                      (intents, abi.intent_dtype), (locomotion, abi.locomotion_dtype), (actions, abi.action_dtype)):
+            if a is None:
+                arrs.append(None)
+                continue
+            a = np.ascontiguousarray(a, dt)
+            n = a.shape[0] if n is None else n
+            assert a.shape[0] == n
+            arrs.append(a)
+        if n is None:
+            return
+        self._call("characters_upload", int(first), int(n), *[ptr(a) for a in arrs])
+
+    def download(self, first=0, count=None, what=("bodies", "params", "controllers", "intents", "locomotion", "actions")):
+        count = self.count - first if count is None else count
+        dts = {"bodies": abi.body_dtype, "params": abi.params_dtype, "controllers": abi.controller_dtype,
+               "intents": abi.intent_dtype, "locomotion": abi.locomotion_dtype, "actions": abi.action_dtype}
+        out = {k: (np.zeros(count, dts[k]) if k in what else None) for k in dts}
+        self._call("characters_download", int(first), int(count), *[ptr(out[k]) for k in dts])
+        return {k: v for k, v in out.items() if v is not None}
+
+    def palettes(self, first=0, count=None, model=False, local=False):
+        count = self.count - first if count is None else count
+        pal = np.zeros((count, self.bone_count, 16), np.float32)
+        mod = np.zeros_like(pal) if model else None
+        loc = np.zeros_like(pal) if local else None
+        self._call("palettes_download", int(first), int(count), ptr(pal), ptr(mod), ptr(loc))
+        return pal, mod, loc
+
+    def skinned(self, first_vertex=0, vertex_count=None, positions=True, normals=True, tangents=True):
+        vertex_count = self.count * self.vertex_count - first_vertex if vertex_count is None else vertex_count
+        p = np.zeros((vertex_count, 3), np.float32) if positions else None
+        n = np.zeros((vertex_count, 3), np.float32) if normals else None
+        t = np.zeros((vertex_count, 4), np.float32) if tangents else None
+        self._call("skinned_download", int(first_vertex), int(vertex_count), ptr(p), ptr(n), ptr(t))
+        return p, n, t
+
+    def tick(self, dt=1.0 / 60.0, stages=abi.STAGE_ALL, gravity=(0.0, -98.0, 0.0), first=0, count=0):
+        d = abi.TickDesc()
+        d.dt = dt
+        d.gravity = (C.c_float * 3)(*gravity)
+        d.stages = stages
+        d.first, d.count = first, count
+        self._call("tick", C.byref(d))
+
+    # -- diagnostics ------------------------------------------------------- #
+    def profile_read(self, reset=True):
+        st = abi.StageTimes()
+        self._call("profile_read", C.byref(st), int(reset))
+        return st
+
+    def move_stats(self, reset=True):
+        st = abi.MoveStats()
+        self._call("move_stats_read", C.byref(st), int(reset))
+        return st
+
+
+def make_queries(origins, deltas=None, radius=1.5, half_height=1.0, mode=abi.CAST, min_normal_y=0.5, mask=0xFFFFFFFF):
+    origins = np.asarray(origins, np.float32).reshape(-1, 3)
+    q = np.zeros(origins.shape[0], abi.query_dtype)
+    q["origin"] = origins
+    if deltas is not None:
+        q["delta"] = np.asarray(deltas, np.float32).reshape(-1, 3)
+    q["radius"], q["halfHeight"], q["minNormalY"], q["mask"], q["mode"] = radius, half_height, min_normal_y, mask, mode
+    return q
