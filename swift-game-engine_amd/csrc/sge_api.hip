@@ -1,0 +1,760 @@
+// C ABI of libsge_amd.so (include/sge_amd.h): context, uploads, the batched
+// fixed step and read-backs. Device memory is context-owned; everything is
+// enqueued on one HIP stream in the reference's system order
+// (Game/DemoScene.swift:57-75): intent -> gravity -> move -> locomotion -> action
+// -> pose -> write-back, then the skinning dispatch of the render frame
+// (Game/RayTracingScene.swift:28-43).
+#include <cstring>
+#include <map>
+#include <vector>
+#include "sge_internal.hpp"
+
+namespace sge {
+
+static thread_local std::string g_error;
+void set_error(const std::string& msg) { g_error = msg; }
+int hip_fail(hipError_t e, const char* what) {
+    g_error = std::string(what) + ": " + hipGetErrorString(e);
+    return SGE_ERR_DEVICE;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t n) {
+        if (n <= bytes && p) return SGE_OK;
+        release();
+        if (n == 0) return SGE_OK;
+        SGE_HIP(hipMalloc(&p, n));
+        bytes = n;
+        return SGE_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Events {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double ms = 0;
+    long long launches = 0;
+};
+
+} // namespace sge
+
+using namespace sge;
+
+struct sge_context {
+    int device = 0;
+    hipStream_t ownStream = nullptr, stream = nullptr;
+    // options
+    bool storePoseDebug = false, profile = false;
+    int skinLayout = SGE_LAYOUT_PACKED;
+    // skeleton
+    int boneCount = 0;
+    DevSkeleton sk{};
+    std::vector<float> hostSkeletonInvBind; // [B][16] skeleton.invBindModel
+    DevBuf dParent, dDepth, dLeanChain, dBindLocal, dInvBind, dRestT, dRawRestT, dPreRot;
+    // profiles
+    DevProfiles prof{};
+    DevBuf dCoeffs, dCoeffCount, dBonePresent;
+    // mesh
+    DevMesh mesh{};
+    DevBuf dMeshPos, dMeshNrm, dMeshTan, dMeshIdx, dMeshWgt;
+    // collision
+    HostCollision hostCol;
+    DevCollision col{};
+    DevBuf dNodes, dTris, dMaterials;
+    // crowd
+    DevCrowd crowd{};
+    DevBuf dBodies, dParams, dCtrl, dIntents, dLoco, dActions, dPalettes, dPoseModel, dPoseLocal;
+    DevBuf dOutPos, dOutNrm, dOutTan;
+    int outLayoutAllocated = -1;
+    // agents
+    DevAgents agents{};
+    DevBuf dCellStart, dCellItems, dCellCursor, dAgentMinMax;
+    // scratch for batched queries
+    DevBuf dQueries, dCastOut, dOverlapOut, dCounts;
+    // stats / profiling
+    DevBuf dStats;
+    Events evMove, evPose, evSkin, evAgents;
+};
+
+namespace {
+
+int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t s) {
+    int rc = b.alloc(bytes);
+    if (rc != SGE_OK) return rc;
+    if (bytes) SGE_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, s));
+    return SGE_OK;
+}
+
+int drainEvents(Events& ev) {
+    for (auto& pr : ev.pending) {
+        SGE_HIP(hipEventSynchronize(pr.second));
+        float ms = 0;
+        SGE_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+        ev.ms += ms;
+        ev.launches += 1;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    ev.pending.clear();
+    return SGE_OK;
+}
+
+struct Bracket {
+    sge_context* c; Events* ev; hipEvent_t a = nullptr, b = nullptr;
+    Bracket(sge_context* ctx, Events* e) : c(ctx), ev(e) {
+        if (c->profile) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, c->stream); }
+    }
+    ~Bracket() {
+        if (c->profile) { (void)hipEventRecord(b, c->stream); ev->pending.emplace_back(a, b); }
+    }
+};
+
+int refreshInvBind(sge_context* c, const float* meshInvBind, int meshInvBindCount) {
+    // Systems.swift:2523: re-bind only when the mesh carries invBindModel of matching count
+    const float* src = (meshInvBind && meshInvBindCount == c->boneCount) ? meshInvBind : c->hostSkeletonInvBind.data();
+    if (c->boneCount == 0) return SGE_OK;
+    int rc = upload(c->dInvBind, src, (size_t)c->boneCount * 64, c->stream);
+    c->sk.invBind = c->dInvBind.as<float>();
+    return rc;
+}
+
+int allocCrowdOutputs(sge_context* c) {
+    size_t verts = (size_t)c->crowd.count * (size_t)c->mesh.vertexCount;
+    size_t stride = c->skinLayout == SGE_LAYOUT_PADDED16 ? 16 : 12;
+    int rc;
+    if ((rc = c->dOutPos.alloc(verts * stride)) != SGE_OK) return rc;
+    if ((rc = c->dOutNrm.alloc(verts * stride)) != SGE_OK) return rc;
+    if ((rc = c->dOutTan.alloc(verts * 16)) != SGE_OK) return rc;
+    c->outLayoutAllocated = c->skinLayout;
+    return SGE_OK;
+}
+
+// ---- agent grid (uniform XZ cells over the gathered snapshot) ---------------
+__global__ void agentBoundsKernel(const sge_agent_state* a, int n, float* mm /*minx,minz,maxx,maxz,maxr,maxv*/) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float minx = 3e38f, minz = 3e38f, maxx = -3e38f, maxz = -3e38f, maxr = 0.f, maxv = 0.f;
+    if (i < n && a[i].radius >= 0) {
+        minx = maxx = a[i].position[0];
+        minz = maxz = a[i].position[2];
+        maxr = a[i].radius;
+        // per-axis bound is enough: the sweep reach uses |v| <= sqrt(3)*max|v_k|; keep the true length
+        float vx = a[i].velocity[0], vy = a[i].velocity[1], vz = a[i].velocity[2];
+        maxv = sqrtf(vx * vx + vy * vy + vz * vz);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        minx = fminf(minx, __shfl_xor(minx, o, 64)); minz = fminf(minz, __shfl_xor(minz, o, 64));
+        maxx = fmaxf(maxx, __shfl_xor(maxx, o, 64)); maxz = fmaxf(maxz, __shfl_xor(maxz, o, 64));
+        maxr = fmaxf(maxr, __shfl_xor(maxr, o, 64)); maxv = fmaxf(maxv, __shfl_xor(maxv, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        // positive floats order as unsigned ints; bias signed values through an order-preserving map
+        auto enc = [](float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+        atomicMin(reinterpret_cast<unsigned*>(mm) + 0, enc(minx));
+        atomicMin(reinterpret_cast<unsigned*>(mm) + 1, enc(minz));
+        atomicMax(reinterpret_cast<unsigned*>(mm) + 2, enc(maxx));
+        atomicMax(reinterpret_cast<unsigned*>(mm) + 3, enc(maxz));
+        atomicMax(reinterpret_cast<unsigned*>(mm) + 4, enc(maxr));
+        atomicMax(reinterpret_cast<unsigned*>(mm) + 5, enc(maxv));
+    }
+}
+
+__device__ __forceinline__ int agentCell(const sge_agent_state& a, float ox, float oz, float inv, int nx, int nz) {
+    int cx = (int)floorf((a.position[0] - ox) * inv), cz = (int)floorf((a.position[2] - oz) * inv);
+    cx = cx < 0 ? 0 : (cx >= nx ? nx - 1 : cx);
+    cz = cz < 0 ? 0 : (cz >= nz ? nz - 1 : cz);
+    return cz * nx + cx;
+}
+__global__ void agentCountKernel(const sge_agent_state* a, int n, float ox, float oz, float inv, int nx, int nz, int* counts) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && a[i].radius >= 0) atomicAdd(&counts[agentCell(a[i], ox, oz, inv, nx, nz)], 1);
+}
+__global__ void agentScanKernel(const int* counts, int cells, int* start, int* cursor) {
+    // single 1024-thread block exclusive scan (cells <= 1<<20)
+    __shared__ int part[1024];
+    int tid = threadIdx.x;
+    int per = (cells + 1023) / 1024;
+    int b = tid * per, e = b + per < cells ? b + per : cells;
+    int s = 0;
+    for (int i = b; i < e; ++i) s += counts[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = tid == 0 ? 0 : part[tid - 1];
+    for (int i = b; i < e; ++i) { start[i] = run; cursor[i] = run; run += counts[i]; }
+    if (tid == 1023) start[cells] = part[1023];
+}
+__global__ void agentScatterKernel(const sge_agent_state* a, int n, float ox, float oz, float inv, int nx, int nz,
+                                   int* cursor, int* items) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && a[i].radius >= 0) items[atomicAdd(&cursor[agentCell(a[i], ox, oz, inv, nx, nz)], 1)] = i;
+}
+
+int buildAgentGrid(sge_context* c) {
+    DevAgents& ag = c->agents;
+    if (!ag.all || ag.total <= 0) return SGE_OK;
+    int rc;
+    if ((rc = c->dAgentMinMax.alloc(32)) != SGE_OK) return rc;
+    const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u};
+    SGE_HIP(hipMemcpyAsync(c->dAgentMinMax.p, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    int blocks = (ag.total + 255) / 256;
+    hipLaunchKernelGGL(agentBoundsKernel, dim3(blocks), dim3(256), 0, c->stream, ag.all, ag.total, c->dAgentMinMax.as<float>());
+    unsigned enc[6];
+    SGE_HIP(hipMemcpyAsync(enc, c->dAgentMinMax.p, sizeof(enc), hipMemcpyDeviceToHost, c->stream));
+    SGE_HIP(hipStreamSynchronize(c->stream));
+    auto dec = [](unsigned u) { unsigned v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; std::memcpy(&f, &v, 4); return f; };
+    if (enc[0] == 0xffffffffu) { ag.nx = ag.nz = 0; ag.cellStart = nullptr; return SGE_OK; } // no solid agents
+    float minx = dec(enc[0]), minz = dec(enc[1]), maxx = dec(enc[2]), maxz = dec(enc[3]);
+    ag.maxRadius = dec(enc[4]);
+    ag.maxSpeed = dec(enc[5]);
+    float cell = 4.0f * (ag.maxRadius > 0.25f ? ag.maxRadius : 0.25f);
+    int nx = (int)((maxx - minx) / cell) + 1, nz = (int)((maxz - minz) / cell) + 1;
+    while ((long long)nx * nz > (1 << 20)) { cell *= 2; nx = (int)((maxx - minx) / cell) + 1; nz = (int)((maxz - minz) / cell) + 1; }
+    ag.originX = minx; ag.originZ = minz; ag.invCell = 1.0f / cell; ag.nx = nx; ag.nz = nz;
+    int cells = nx * nz;
+    // counts live in dCellCursor's tail: [cursor cells][counts cells]
+    if ((rc = c->dCellCursor.alloc((size_t)cells * 8)) != SGE_OK) return rc;
+    if ((rc = c->dCellStart.alloc((size_t)(cells + 1) * 4)) != SGE_OK) return rc;
+    if ((rc = c->dCellItems.alloc((size_t)ag.total * 4)) != SGE_OK) return rc;
+    int* cursor = c->dCellCursor.as<int>();
+    int* cnt = cursor + cells;
+    SGE_HIP(hipMemsetAsync(cnt, 0, (size_t)cells * 4, c->stream));
+    hipLaunchKernelGGL(agentCountKernel, dim3(blocks), dim3(256), 0, c->stream, ag.all, ag.total, ag.originX, ag.originZ, ag.invCell, nx, nz, cnt);
+    hipLaunchKernelGGL(agentScanKernel, dim3(1), dim3(1024), 0, c->stream, cnt, cells, c->dCellStart.as<int>(), cursor);
+    hipLaunchKernelGGL(agentScatterKernel, dim3(blocks), dim3(256), 0, c->stream, ag.all, ag.total, ag.originX, ag.originZ, ag.invCell, nx, nz, cursor, c->dCellItems.as<int>());
+    ag.cellStart = c->dCellStart.as<int>();
+    ag.cellItems = c->dCellItems.as<int>();
+    return SGE_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int sge_abi_version(void) { return SGE_ABI_VERSION; }
+const char* sge_last_error(void) { return g_error.c_str(); }
+
+sge_context* sge_context_create(int device_index) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device visible (there is no CPU fallback)"); return nullptr; }
+    if (device_index < 0 || device_index >= n) { set_error("device index out of range"); return nullptr; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_index) != hipSuccess) { set_error("hipGetDeviceProperties failed"); return nullptr; }
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        set_error(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+        return nullptr;
+    }
+    if (hipSetDevice(device_index) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
+    sge_context* c = new sge_context();
+    c->device = device_index;
+    if (hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
+    c->stream = c->ownStream;
+    if (c->dStats.alloc(64) != SGE_OK || hipMemsetAsync(c->dStats.p, 0, 64, c->stream) != hipSuccess) { delete c; return nullptr; }
+    return c;
+}
+
+void sge_context_destroy(sge_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    drainEvents(c->evMove); drainEvents(c->evPose); drainEvents(c->evSkin); drainEvents(c->evAgents);
+    DevBuf* bufs[] = {&c->dParent, &c->dDepth, &c->dLeanChain, &c->dBindLocal, &c->dInvBind, &c->dRestT, &c->dRawRestT, &c->dPreRot,
+                      &c->dCoeffs, &c->dCoeffCount, &c->dBonePresent, &c->dMeshPos, &c->dMeshNrm, &c->dMeshTan, &c->dMeshIdx, &c->dMeshWgt,
+                      &c->dNodes, &c->dTris, &c->dMaterials, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
+                      &c->dPalettes, &c->dPoseModel, &c->dPoseLocal, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
+                      &c->dCellCursor, &c->dAgentMinMax, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats};
+    for (DevBuf* b : bufs) b->release();
+    if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
+    delete c;
+}
+
+int sge_context_set_stream(sge_context* c, void* hip_stream) {
+    if (!c) return SGE_ERR_INVALID;
+    SGE_HIP(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->ownStream;
+    return SGE_OK;
+}
+
+int sge_synchronize(sge_context* c) {
+    if (!c) return SGE_ERR_INVALID;
+    SGE_HIP(hipStreamSynchronize(c->stream));
+    return SGE_OK;
+}
+
+int sge_context_set_option(sge_context* c, int option, int value) {
+    if (!c) return SGE_ERR_INVALID;
+    switch (option) {
+    case SGE_OPT_STORE_POSE_DEBUG: c->storePoseDebug = value != 0; break;
+    case SGE_OPT_SKIN_LAYOUT:
+        if (value != SGE_LAYOUT_PACKED && value != SGE_LAYOUT_PADDED16) { set_error("bad layout"); return SGE_ERR_INVALID; }
+        c->skinLayout = value;
+        break;
+    case SGE_OPT_PROFILE: c->profile = value != 0; break;
+    default: set_error("unknown option"); return SGE_ERR_INVALID;
+    }
+    return SGE_OK;
+}
+
+// ---- skeleton ----------------------------------------------------------------
+int sge_skeleton_upload(sge_context* c, const sge_skeleton_desc* d) {
+    if (!c || !d || d->boneCount <= 0 || d->boneCount > SGE_MAX_BONES || !d->parent || !d->bindLocal || !d->invBindModel ||
+        !d->restTranslation || !d->rawRestTranslation || !d->preRotationDegrees) {
+        set_error("sge_skeleton_upload: bad argument");
+        return SGE_ERR_INVALID;
+    }
+    const int B = d->boneCount;
+    std::vector<int32_t> depth(B), chain;
+    int maxDepth = 0;
+    for (int i = 0; i < B; ++i) {
+        int p = d->parent[i];
+        if (p >= i) { set_error("sge_skeleton_upload: parent index must precede child (Skeleton.swift:189-203)"); return SGE_ERR_INVALID; }
+        depth[i] = p < 0 ? 0 : depth[p] + 1;
+        maxDepth = depth[i] > maxDepth ? depth[i] : maxDepth;
+    }
+    if (d->pelvisIndex >= B || d->leanIndex >= B) { set_error("semantic bone index out of range"); return SGE_ERR_INVALID; }
+    if (d->leanIndex >= 0) {
+        for (int b = d->leanIndex; b >= 0; b = d->parent[b]) chain.insert(chain.begin(), b);
+    }
+    if (chain.empty()) chain.push_back(0);
+    std::vector<float> bind12((size_t)B * 12), pre12((size_t)B * 12);
+    for (int i = 0; i < B; ++i) {
+        const float* m = d->bindLocal + i * 16;
+        for (int col = 0; col < 4; ++col)
+            for (int r = 0; r < 3; ++r) bind12[(size_t)i * 12 + col * 3 + r] = m[col * 4 + r];
+        Aff pr = rotationXYZDegrees(F3{d->preRotationDegrees[i * 3], d->preRotationDegrees[i * 3 + 1], d->preRotationDegrees[i * 3 + 2]});
+        const F3 cols[4] = {pr.c0, pr.c1, pr.c2, pr.c3};
+        for (int col = 0; col < 4; ++col) {
+            pre12[(size_t)i * 12 + col * 3 + 0] = cols[col].x;
+            pre12[(size_t)i * 12 + col * 3 + 1] = cols[col].y;
+            pre12[(size_t)i * 12 + col * 3 + 2] = cols[col].z;
+        }
+    }
+    (void)hipSetDevice(c->device);
+    int rc;
+    hipStream_t s = c->stream;
+    if ((rc = upload(c->dParent, d->parent, (size_t)B * 4, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dDepth, depth.data(), (size_t)B * 4, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dLeanChain, chain.data(), chain.size() * 4, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dBindLocal, bind12.data(), bind12.size() * 4, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dRestT, d->restTranslation, (size_t)B * 12, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dRawRestT, d->rawRestTranslation, (size_t)B * 12, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dPreRot, pre12.data(), pre12.size() * 4, s)) != SGE_OK) return rc;
+    SGE_HIP(hipStreamSynchronize(s)); // host vectors go out of scope
+    c->boneCount = B;
+    c->hostSkeletonInvBind.assign(d->invBindModel, d->invBindModel + (size_t)B * 16);
+    DevSkeleton& sk = c->sk;
+    sk.boneCount = B;
+    sk.pelvisIndex = d->pelvisIndex;
+    sk.leanIndex = d->leanIndex;
+    sk.leanParent = d->leanIndex >= 0 ? d->parent[d->leanIndex] : -1;
+    sk.maxDepth = maxDepth;
+    sk.leanChainLen = (int)chain.size();
+    sk.unitScale = d->unitScale;
+    sk.parent = c->dParent.as<int32_t>();
+    sk.depth = c->dDepth.as<int32_t>();
+    sk.leanChain = c->dLeanChain.as<int32_t>();
+    sk.bindLocal = c->dBindLocal.as<float>();
+    sk.restT = c->dRestT.as<float>();
+    sk.rawRestT = c->dRawRestT.as<float>();
+    sk.preRot = c->dPreRot.as<float>();
+    for (int col = 0; col < 4; ++col)
+        for (int r = 0; r < 3; ++r) sk.rootFix[col * 3 + r] = d->rootRotationFix[col * 4 + r];
+    rc = refreshInvBind(c, nullptr, 0);
+    if (rc != SGE_OK) return rc;
+    SGE_HIP(hipStreamSynchronize(s));
+    // palettes depend on boneCount
+    if (c->crowd.count > 0) return sge_characters_resize(c, c->crowd.count);
+    return SGE_OK;
+}
+
+// ---- motion profiles -----------------------------------------------------------
+int sge_motion_profiles_upload(sge_context* c, const sge_motion_profile_desc* p, int32_t count) {
+    if (!c || !p || count <= 0 || count > SGE_MAX_PROFILES) { set_error("sge_motion_profiles_upload: bad argument"); return SGE_ERR_INVALID; }
+    if (c->boneCount == 0) { set_error("upload the skeleton first"); return SGE_ERR_STATE; }
+    const int B = c->boneCount;
+    int stride = 1;
+    for (int k = 0; k < count; ++k) {
+        if (p[k].order < 1 || p[k].order > SGE_MAX_FOURIER_ORDER || !p[k].bonePresent || !p[k].coeffCount || !p[k].coeffs) {
+            set_error("sge_motion_profiles_upload: bad profile (order must be 1..8)");
+            return SGE_ERR_INVALID;
+        }
+        for (int i = 0; i < B * 6; ++i) {
+            int cc = p[k].coeffCount[i];
+            if (cc != SGE_AXIS_ABSENT) {
+                if (cc > SGE_MAX_COEFFS) { set_error("coefficient count exceeds SGE_MAX_COEFFS"); return SGE_ERR_INVALID; }
+                stride = cc > stride ? cc : stride;
+            }
+        }
+    }
+    std::vector<float> coeffs((size_t)count * B * 6 * stride, 0.f);
+    std::vector<uint8_t> cc((size_t)count * B * 6), present((size_t)count * B);
+    for (int k = 0; k < count; ++k) {
+        std::memcpy(&cc[(size_t)k * B * 6], p[k].coeffCount, (size_t)B * 6);
+        std::memcpy(&present[(size_t)k * B], p[k].bonePresent, (size_t)B);
+        for (int i = 0; i < B * 6; ++i)
+            std::memcpy(&coeffs[((size_t)k * B * 6 + i) * stride], p[k].coeffs + (size_t)i * SGE_MAX_COEFFS, (size_t)stride * 4);
+    }
+    (void)hipSetDevice(c->device);
+    int rc;
+    if ((rc = upload(c->dCoeffs, coeffs.data(), coeffs.size() * 4, c->stream)) != SGE_OK) return rc;
+    if ((rc = upload(c->dCoeffCount, cc.data(), cc.size(), c->stream)) != SGE_OK) return rc;
+    if ((rc = upload(c->dBonePresent, present.data(), present.size(), c->stream)) != SGE_OK) return rc;
+    SGE_HIP(hipStreamSynchronize(c->stream));
+    DevProfiles& pf = c->prof;
+    pf.count = count;
+    pf.stride = stride;
+    for (int k = 0; k < count; ++k) { pf.order[k] = p[k].order; pf.cycleRaw[k] = p[k].cycleDuration; }
+    pf.coeffs = c->dCoeffs.as<float>();
+    pf.coeffCount = c->dCoeffCount.as<uint8_t>();
+    pf.bonePresent = c->dBonePresent.as<uint8_t>();
+    return SGE_OK;
+}
+
+// ---- skinned mesh ----------------------------------------------------------------
+int sge_skinned_mesh_upload(sge_context* c, const sge_skinned_mesh_desc* d) {
+    if (!c || !d || d->vertexCount <= 0 || !d->positions || !d->normals || !d->tangents || !d->boneIndices || !d->boneWeights) {
+        set_error("sge_skinned_mesh_upload: bad argument");
+        return SGE_ERR_INVALID;
+    }
+    if (c->boneCount == 0) { set_error("upload the skeleton first"); return SGE_ERR_STATE; }
+    const size_t V = (size_t)d->vertexCount;
+    for (size_t i = 0; i < V * 4; ++i)
+        if (d->boneIndices[i] >= c->boneCount) { set_error("bone index out of range"); return SGE_ERR_INVALID; }
+    (void)hipSetDevice(c->device);
+    int rc;
+    hipStream_t s = c->stream;
+    if ((rc = upload(c->dMeshPos, d->positions, V * 12, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dMeshNrm, d->normals, V * 12, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dMeshTan, d->tangents, V * 16, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dMeshIdx, d->boneIndices, V * 8, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dMeshWgt, d->boneWeights, V * 16, s)) != SGE_OK) return rc;
+    if ((rc = refreshInvBind(c, d->invBindModel, d->invBindCount)) != SGE_OK) return rc;
+    SGE_HIP(hipStreamSynchronize(s));
+    c->mesh = DevMesh{d->vertexCount, c->dMeshPos.as<float>(), c->dMeshNrm.as<float>(), c->dMeshTan.as<float>(),
+                      c->dMeshIdx.as<uint16_t>(), c->dMeshWgt.as<float>()};
+    if (c->crowd.count > 0) return allocCrowdOutputs(c);
+    return SGE_OK;
+}
+
+int sge_skinned_mesh_buffers(sge_context* c, void** p, void** n, void** t, void** i, void** w) {
+    if (!c || c->mesh.vertexCount == 0) { set_error("no skinned mesh"); return SGE_ERR_STATE; }
+    if (p) *p = c->dMeshPos.p; if (n) *n = c->dMeshNrm.p; if (t) *t = c->dMeshTan.p; if (i) *i = c->dMeshIdx.p; if (w) *w = c->dMeshWgt.p;
+    return SGE_OK;
+}
+
+int sge_crowd_buffers(sge_context* c, void** pal, void** op, void** on, void** ot) {
+    if (!c || c->crowd.count == 0) { set_error("no characters"); return SGE_ERR_STATE; }
+    if (pal) *pal = c->dPalettes.p; if (op) *op = c->dOutPos.p; if (on) *on = c->dOutNrm.p; if (ot) *ot = c->dOutTan.p;
+    return SGE_OK;
+}
+
+int sge_skinning_encode(sge_context* c, void* d_outPositions, void* d_outNormals, void* d_outTangents, int32_t out_layout,
+                        const sge_skinning_job* jobs, int32_t job_count) {
+    if (!c || !d_outPositions || !d_outNormals || !d_outTangents || (job_count > 0 && !jobs)) { set_error("sge_skinning_encode: bad argument"); return SGE_ERR_INVALID; }
+    (void)hipSetDevice(c->device);
+    for (int j = 0; j < job_count; ++j) { // RTSkinningEncoder.swift:37-54
+        const sge_skinning_job& J = jobs[j];
+        if (J.vertexCount <= 0) continue;
+        if (J.paletteCount <= 0 || J.paletteCount > SGE_MAX_BONES) { set_error("paletteCount out of range"); return SGE_ERR_INVALID; }
+        SkinLaunch L{J.d_sourcePositions, J.d_sourceNormals, J.d_sourceTangents, J.d_sourceBoneIndices, J.d_sourceBoneWeights,
+                     reinterpret_cast<const float*>(J.d_palette), J.paletteCount, J.vertexCount, 1, (long long)J.dstBaseVertex,
+                     J.sourceLayout, out_layout, d_outPositions, d_outNormals, d_outTangents};
+        Bracket br(c, &c->evSkin);
+        launch_skin(L, c->stream);
+    }
+    SGE_HIP(hipGetLastError());
+    return SGE_OK;
+}
+
+// ---- collision world ---------------------------------------------------------------
+int sge_collision_rebuild_static(sge_context* c, const sge_static_mesh_entity* ents, int32_t count) {
+    if (!c || count < 0 || (count > 0 && !ents)) { set_error("sge_collision_rebuild_static: bad argument"); return SGE_ERR_INVALID; }
+    for (int e = 0; e < count; ++e) {
+        if (!ents[e].positions || !ents[e].indices || ents[e].vertexCount < 0 || ents[e].indexCount < 0) { set_error("bad entity"); return SGE_ERR_INVALID; }
+        for (int i = 0; i < ents[e].indexCount; ++i)
+            if (ents[e].indices[i] >= (uint32_t)ents[e].vertexCount) { set_error("index out of range"); return SGE_ERR_INVALID; }
+    }
+    HostCollision& hc = c->hostCol;
+    hc.rebuild(ents, count);
+    const int T = (int)hc.layers.size();
+    if (hc.maxDepth > 120) { set_error("BVH deeper than the traversal stack policy allows"); return SGE_ERR_CAPACITY; }
+    std::vector<DevNode> nodes(hc.nodes.size());
+    for (size_t i = 0; i < hc.nodes.size(); ++i) {
+        const HostBVHNode& n = hc.nodes[i];
+        DevNode d{n.mn[0], n.mn[1], n.mn[2], n.mx[0], n.mx[1], n.mx[2], 0, 0};
+        if (n.left < 0) { d.a = ~n.start; d.b = n.count; } else { d.a = n.left; d.b = n.right; }
+        nodes[i] = d;
+    }
+    std::vector<DevTri> tris(T);
+    std::vector<DevMaterial> mats(T);
+    for (int slot = 0; slot < T; ++slot) {
+        int t = hc.triOrder[slot];
+        const uint32_t* ix = &hc.indices[(size_t)t * 3];
+        const float *p0 = &hc.positions[ix[0] * 3], *p1 = &hc.positions[ix[1] * 3], *p2 = &hc.positions[ix[2] * 3];
+        tris[slot] = DevTri{p0[0], p0[1], p0[2], p1[0], p1[1], p1[2], p2[0], p2[1], p2[2], hc.layers[t], t, hc.rank[t]};
+    }
+    for (int t = 0; t < T; ++t) mats[t] = DevMaterial{hc.materials[t].muS, hc.materials[t].muK, hc.materials[t].flattenGround};
+    (void)hipSetDevice(c->device);
+    int rc;
+    if ((rc = upload(c->dNodes, nodes.data(), nodes.size() * sizeof(DevNode), c->stream)) != SGE_OK) return rc;
+    if ((rc = upload(c->dTris, tris.data(), tris.size() * sizeof(DevTri), c->stream)) != SGE_OK) return rc;
+    if ((rc = upload(c->dMaterials, mats.data(), mats.size() * sizeof(DevMaterial), c->stream)) != SGE_OK) return rc;
+    SGE_HIP(hipStreamSynchronize(c->stream));
+    c->col = DevCollision{(int)nodes.size(), T, hc.root, c->dNodes.as<DevNode>(), c->dTris.as<DevTri>(), c->dMaterials.as<DevMaterial>()};
+    return SGE_OK;
+}
+
+int sge_collision_counts(sge_context* c, int32_t* v, int32_t* t, int32_t* n) {
+    if (!c) return SGE_ERR_INVALID;
+    if (v) *v = (int32_t)(c->hostCol.positions.size() / 3);
+    if (t) *t = (int32_t)c->hostCol.layers.size();
+    if (n) *n = (int32_t)c->hostCol.nodes.size();
+    return SGE_OK;
+}
+
+int sge_collision_copy(sge_context* c, float* positions, uint32_t* indices, float* aabbs, sge_bvh_node* nodes,
+                       int32_t* triOrder, int32_t* triLeaf) {
+    if (!c) return SGE_ERR_INVALID;
+    const HostCollision& hc = c->hostCol;
+    if (positions) std::memcpy(positions, hc.positions.data(), hc.positions.size() * 4);
+    if (indices) std::memcpy(indices, hc.indices.data(), hc.indices.size() * 4);
+    if (aabbs) std::memcpy(aabbs, hc.aabbs.data(), hc.aabbs.size() * 4);
+    if (nodes)
+        for (size_t i = 0; i < hc.nodes.size(); ++i) {
+            const HostBVHNode& b = hc.nodes[i];
+            nodes[i] = sge_bvh_node{{b.mn[0], b.mn[1], b.mn[2]}, {b.mx[0], b.mx[1], b.mx[2]}, b.left, b.right, b.start, b.count, b.parent};
+        }
+    if (triOrder) std::memcpy(triOrder, hc.triOrder.data(), hc.triOrder.size() * 4);
+    if (triLeaf) std::memcpy(triLeaf, hc.triLeaf.data(), hc.triLeaf.size() * 4);
+    return SGE_OK;
+}
+
+int sge_capsule_cast_batch(sge_context* c, const sge_capsule_query* q, int32_t count, sge_capsule_cast_hit* out) {
+    if (!c || count < 0 || (count > 0 && (!q || !out))) { set_error("sge_capsule_cast_batch: bad argument"); return SGE_ERR_INVALID; }
+    if (count == 0) return SGE_OK;
+    (void)hipSetDevice(c->device);
+    int rc;
+    if ((rc = upload(c->dQueries, q, (size_t)count * sizeof(*q), c->stream)) != SGE_OK) return rc;
+    if ((rc = c->dCastOut.alloc((size_t)count * sizeof(*out))) != SGE_OK) return rc;
+    launch_cast_queries(c->col, c->dQueries.as<sge_capsule_query>(), count, c->dCastOut.as<sge_capsule_cast_hit>(),
+                        c->dStats.as<unsigned long long>(), c->stream);
+    SGE_HIP(hipGetLastError());
+    SGE_HIP(hipMemcpyAsync(out, c->dCastOut.p, (size_t)count * sizeof(*out), hipMemcpyDeviceToHost, c->stream));
+    SGE_HIP(hipStreamSynchronize(c->stream));
+    return SGE_OK;
+}
+
+int sge_capsule_overlap_all_batch(sge_context* c, const sge_capsule_query* q, int32_t count, int32_t max_hits,
+                                  sge_capsule_overlap_hit* out, int32_t* out_counts) {
+    if (!c || count < 0 || max_hits < 1 || max_hits > SGE_MAX_OVERLAP_HITS || (count > 0 && (!q || !out || !out_counts))) {
+        set_error("sge_capsule_overlap_all_batch: bad argument");
+        return SGE_ERR_INVALID;
+    }
+    if (count == 0) return SGE_OK;
+    (void)hipSetDevice(c->device);
+    int rc;
+    if ((rc = upload(c->dQueries, q, (size_t)count * sizeof(*q), c->stream)) != SGE_OK) return rc;
+    if ((rc = c->dOverlapOut.alloc((size_t)count * max_hits * sizeof(*out))) != SGE_OK) return rc;
+    if ((rc = c->dCounts.alloc((size_t)count * 4)) != SGE_OK) return rc;
+    launch_overlap_queries(c->col, c->dQueries.as<sge_capsule_query>(), count, max_hits, c->dOverlapOut.as<sge_capsule_overlap_hit>(),
+                           c->dCounts.as<int32_t>(), c->dStats.as<unsigned long long>(), c->stream);
+    SGE_HIP(hipGetLastError());
+    SGE_HIP(hipMemcpyAsync(out, c->dOverlapOut.p, (size_t)count * max_hits * sizeof(*out), hipMemcpyDeviceToHost, c->stream));
+    SGE_HIP(hipMemcpyAsync(out_counts, c->dCounts.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
+    SGE_HIP(hipStreamSynchronize(c->stream));
+    return SGE_OK;
+}
+
+// ---- characters ----------------------------------------------------------------------
+int sge_characters_resize(sge_context* c, int32_t count) {
+    if (!c || count < 0) { set_error("sge_characters_resize: bad argument"); return SGE_ERR_INVALID; }
+    (void)hipSetDevice(c->device);
+    SGE_HIP(hipStreamSynchronize(c->stream));
+    const size_t N = (size_t)count, B = (size_t)c->boneCount;
+    int rc;
+#define SGE_ZALLOC(buf, bytes) if ((rc = (buf).alloc(bytes)) != SGE_OK) return rc; if ((bytes) > 0) SGE_HIP(hipMemsetAsync((buf).p, 0, (bytes), c->stream));
+    SGE_ZALLOC(c->dBodies, N * sizeof(sge_body_state));
+    SGE_ZALLOC(c->dParams, N * sizeof(sge_controller_params));
+    SGE_ZALLOC(c->dCtrl, N * sizeof(sge_controller_state));
+    SGE_ZALLOC(c->dIntents, N * sizeof(sge_move_intent));
+    SGE_ZALLOC(c->dLoco, N * sizeof(sge_locomotion_state));
+    SGE_ZALLOC(c->dActions, N * sizeof(sge_action_state));
+    SGE_ZALLOC(c->dPalettes, N * B * 64);
+    if (c->storePoseDebug) { SGE_ZALLOC(c->dPoseModel, N * B * 64); SGE_ZALLOC(c->dPoseLocal, N * B * 64); }
+#undef SGE_ZALLOC
+    c->crowd = DevCrowd{count, c->dBodies.as<sge_body_state>(), c->dParams.as<sge_controller_params>(),
+                        c->dCtrl.as<sge_controller_state>(), c->dIntents.as<sge_move_intent>(),
+                        c->dLoco.as<sge_locomotion_state>(), c->dActions.as<sge_action_state>(), c->dPalettes.as<float>(),
+                        c->storePoseDebug ? c->dPoseModel.as<float>() : nullptr, c->storePoseDebug ? c->dPoseLocal.as<float>() : nullptr};
+    if (c->mesh.vertexCount > 0 && (rc = allocCrowdOutputs(c)) != SGE_OK) return rc;
+    SGE_HIP(hipStreamSynchronize(c->stream));
+    return SGE_OK;
+}
+
+#define SGE_RANGE_CHECK() \
+    if (!c || first < 0 || count < 0 || first + count > c->crowd.count) { set_error("character range out of bounds"); return SGE_ERR_INVALID; }
+
+int sge_characters_upload(sge_context* c, int32_t first, int32_t count, const sge_body_state* b, const sge_controller_params* p,
+                          const sge_controller_state* cs, const sge_move_intent* in, const sge_locomotion_state* l,
+                          const sge_action_state* a) {
+    SGE_RANGE_CHECK();
+    (void)hipSetDevice(c->device);
+    if (l) {
+        for (int i = 0; i < count; ++i) {
+            for (int k = 0; k < 4; ++k)
+                if ((l[i].flags & SGE_LOCO_PRESENT) && (l[i].profile[k] < 0 || l[i].profile[k] >= c->prof.count)) { set_error("locomotion profile index out of range"); return SGE_ERR_INVALID; }
+            if ((l[i].flags & SGE_MOTION_PRESENT) && (l[i].motionProfile < 0 || l[i].motionProfile >= c->prof.count)) { set_error("motion profile index out of range"); return SGE_ERR_INVALID; }
+            if ((l[i].flags & SGE_LOCO_PRESENT) && ((unsigned)l[i].state > 3u || (unsigned)l[i].fromState > 3u)) { set_error("locomotion state out of range"); return SGE_ERR_INVALID; }
+        }
+    }
+    if (a)
+        for (int i = 0; i < count; ++i)
+            if ((a[i].flags & SGE_ACTION_PRESENT) && (a[i].profile < 0 || a[i].profile >= c->prof.count)) { set_error("action profile index out of range"); return SGE_ERR_INVALID; }
+    hipStream_t s = c->stream;
+#define SGE_UP(ptr, buf, T) if (ptr) SGE_HIP(hipMemcpyAsync((buf).template as<T>() + first, ptr, (size_t)count * sizeof(T), hipMemcpyHostToDevice, s));
+    SGE_UP(b, c->dBodies, sge_body_state) SGE_UP(p, c->dParams, sge_controller_params) SGE_UP(cs, c->dCtrl, sge_controller_state)
+    SGE_UP(in, c->dIntents, sge_move_intent) SGE_UP(l, c->dLoco, sge_locomotion_state) SGE_UP(a, c->dActions, sge_action_state)
+#undef SGE_UP
+    SGE_HIP(hipStreamSynchronize(s));
+    return SGE_OK;
+}
+
+int sge_characters_download(sge_context* c, int32_t first, int32_t count, sge_body_state* b, sge_controller_params* p,
+                            sge_controller_state* cs, sge_move_intent* in, sge_locomotion_state* l, sge_action_state* a) {
+    SGE_RANGE_CHECK();
+    (void)hipSetDevice(c->device);
+    hipStream_t s = c->stream;
+#define SGE_DN(ptr, buf, T) if (ptr) SGE_HIP(hipMemcpyAsync(ptr, (buf).template as<T>() + first, (size_t)count * sizeof(T), hipMemcpyDeviceToHost, s));
+    SGE_DN(b, c->dBodies, sge_body_state) SGE_DN(p, c->dParams, sge_controller_params) SGE_DN(cs, c->dCtrl, sge_controller_state)
+    SGE_DN(in, c->dIntents, sge_move_intent) SGE_DN(l, c->dLoco, sge_locomotion_state) SGE_DN(a, c->dActions, sge_action_state)
+#undef SGE_DN
+    SGE_HIP(hipStreamSynchronize(s));
+    return SGE_OK;
+}
+
+int sge_palettes_download(sge_context* c, int32_t first, int32_t count, float* palette, float* model, float* local) {
+    SGE_RANGE_CHECK();
+    if ((model || local) && !c->crowd.poseModel) { set_error("model/local need SGE_OPT_STORE_POSE_DEBUG set before sge_characters_resize"); return SGE_ERR_STATE; }
+    (void)hipSetDevice(c->device);
+    const size_t B = (size_t)c->boneCount, off = (size_t)first * B * 16, n = (size_t)count * B * 64;
+    if (palette) SGE_HIP(hipMemcpyAsync(palette, c->dPalettes.as<float>() + off, n, hipMemcpyDeviceToHost, c->stream));
+    if (model) SGE_HIP(hipMemcpyAsync(model, c->dPoseModel.as<float>() + off, n, hipMemcpyDeviceToHost, c->stream));
+    if (local) SGE_HIP(hipMemcpyAsync(local, c->dPoseLocal.as<float>() + off, n, hipMemcpyDeviceToHost, c->stream));
+    SGE_HIP(hipStreamSynchronize(c->stream));
+    return SGE_OK;
+}
+
+int sge_skinned_download(sge_context* c, int64_t first_vertex, int64_t vertex_count, float* positions, float* normals, float* tangents) {
+    if (!c || first_vertex < 0 || vertex_count < 0 ||
+        (size_t)(first_vertex + vertex_count) > (size_t)c->crowd.count * (size_t)c->mesh.vertexCount) { set_error("vertex range out of bounds"); return SGE_ERR_INVALID; }
+    (void)hipSetDevice(c->device);
+    const bool padded = c->outLayoutAllocated == SGE_LAYOUT_PADDED16;
+    const size_t n = (size_t)vertex_count, f = (size_t)first_vertex;
+    hipStream_t s = c->stream;
+    if (!padded) {
+        if (positions) SGE_HIP(hipMemcpyAsync(positions, c->dOutPos.as<float>() + f * 3, n * 12, hipMemcpyDeviceToHost, s));
+        if (normals) SGE_HIP(hipMemcpyAsync(normals, c->dOutNrm.as<float>() + f * 3, n * 12, hipMemcpyDeviceToHost, s));
+    } else { // strided 16 B -> packed 12 B
+        if (positions) SGE_HIP(hipMemcpy2DAsync(positions, 12, c->dOutPos.as<float>() + f * 4, 16, 12, n, hipMemcpyDeviceToHost, s));
+        if (normals) SGE_HIP(hipMemcpy2DAsync(normals, 12, c->dOutNrm.as<float>() + f * 4, 16, 12, n, hipMemcpyDeviceToHost, s));
+    }
+    if (tangents) SGE_HIP(hipMemcpyAsync(tangents, c->dOutTan.as<float>() + f * 4, n * 16, hipMemcpyDeviceToHost, s));
+    SGE_HIP(hipStreamSynchronize(s));
+    return SGE_OK;
+}
+
+// ---- the batched fixed step --------------------------------------------------------------
+int sge_tick(sge_context* c, const sge_tick_desc* d) {
+    if (!c || !d) { set_error("sge_tick: bad argument"); return SGE_ERR_INVALID; }
+    int first = d->first, count = d->count;
+    if (count == 0) { first = 0; count = c->crowd.count; }
+    SGE_RANGE_CHECK();
+    if (count == 0) return SGE_OK;
+    (void)hipSetDevice(c->device);
+    const uint32_t st = d->stages;
+    if (st & (SGE_STAGE_INTENT | SGE_STAGE_GRAVITY | SGE_STAGE_MOVE)) {
+        if ((st & SGE_STAGE_MOVE) && c->col.root < 0 && c->col.triCount != 0) { set_error("collision world not built"); return SGE_ERR_STATE; }
+        if ((st & SGE_STAGE_AGENTS) && (st & SGE_STAGE_MOVE)) {
+            if (!c->agents.all) { set_error("SGE_STAGE_AGENTS needs sge_agents_import"); return SGE_ERR_STATE; }
+            Bracket br(c, &c->evAgents);
+            int rc = buildAgentGrid(c);
+            if (rc != SGE_OK) return rc;
+        }
+        MoveLaunch L{c->crowd, c->col, c->agents, d->dt, d->gravity[0], d->gravity[1], d->gravity[2], st, first, count,
+                     c->dStats.as<unsigned long long>()};
+        if (!(st & SGE_STAGE_AGENTS) || c->agents.nx == 0) L.agents.all = nullptr;
+        Bracket br(c, &c->evMove);
+        launch_move(L, c->stream);
+    }
+    if (st & (SGE_STAGE_LOCOMOTION | SGE_STAGE_ACTION | SGE_STAGE_POSE | SGE_STAGE_WRITEBACK)) {
+        if ((st & SGE_STAGE_POSE) && (c->boneCount == 0 || c->prof.count == 0)) { set_error("pose stage needs a skeleton and motion profiles"); return SGE_ERR_STATE; }
+        PoseLaunch L{c->crowd, c->sk, c->prof, d->dt, st, first, count};
+        Bracket br(c, &c->evPose);
+        launch_pose(L, c->stream);
+    }
+    if (st & SGE_STAGE_SKIN) {
+        if (c->mesh.vertexCount == 0) { set_error("skin stage needs a skinned mesh"); return SGE_ERR_STATE; }
+        if (c->outLayoutAllocated != c->skinLayout) { int rc = allocCrowdOutputs(c); if (rc != SGE_OK) return rc; }
+        // one RTSkinningJob per character, dstBaseVertex = running vertex offset (RTGeometryCache.swift:266-315)
+        SkinLaunch L{c->mesh.positions, c->mesh.normals, c->mesh.tangents, c->mesh.boneIndices, c->mesh.boneWeights,
+                     c->crowd.palettes + (size_t)first * c->boneCount * 16, c->boneCount, c->mesh.vertexCount, count,
+                     (long long)first * c->mesh.vertexCount, SGE_LAYOUT_PACKED, c->skinLayout, c->dOutPos.p, c->dOutNrm.p, c->dOutTan.p};
+        Bracket br(c, &c->evSkin);
+        launch_skin(L, c->stream);
+    }
+    SGE_HIP(hipGetLastError());
+    return SGE_OK;
+}
+
+// ---- agents ---------------------------------------------------------------------------------
+int sge_agents_export(sge_context* c, void* d_out) {
+    if (!c || !d_out) { set_error("sge_agents_export: bad argument"); return SGE_ERR_INVALID; }
+    (void)hipSetDevice(c->device);
+    launch_agents_export(c->crowd, reinterpret_cast<sge_agent_state*>(d_out), c->stream);
+    SGE_HIP(hipGetLastError());
+    return SGE_OK;
+}
+
+int sge_agents_import(sge_context* c, const void* d_all, int32_t total, int32_t self_offset) {
+    if (!c || total < 0 || self_offset < 0 || (total > 0 && !d_all)) { set_error("sge_agents_import: bad argument"); return SGE_ERR_INVALID; }
+    c->agents = DevAgents{};
+    c->agents.all = total > 0 ? reinterpret_cast<const sge_agent_state*>(d_all) : nullptr;
+    c->agents.total = total;
+    c->agents.selfOffset = self_offset;
+    return SGE_OK;
+}
+
+// ---- diagnostics ------------------------------------------------------------------------------
+int sge_profile_read(sge_context* c, sge_stage_times* out, int reset) {
+    if (!c || !out) return SGE_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    int rc;
+    if ((rc = drainEvents(c->evMove)) != SGE_OK || (rc = drainEvents(c->evPose)) != SGE_OK ||
+        (rc = drainEvents(c->evSkin)) != SGE_OK || (rc = drainEvents(c->evAgents)) != SGE_OK) return rc;
+    *out = sge_stage_times{c->evMove.ms, c->evPose.ms, c->evSkin.ms, c->evAgents.ms,
+                           c->evMove.launches, c->evPose.launches, c->evSkin.launches, c->evAgents.launches};
+    if (reset) {
+        for (Events* e : {&c->evMove, &c->evPose, &c->evSkin, &c->evAgents}) { e->ms = 0; e->launches = 0; }
+    }
+    return SGE_OK;
+}
+
+int sge_move_stats_read(sge_context* c, sge_move_stats* out, int reset) {
+    if (!c || !out) return SGE_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    unsigned long long h[4];
+    SGE_HIP(hipMemcpyAsync(h, c->dStats.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    SGE_HIP(hipStreamSynchronize(c->stream));
+    out->queries = h[0]; out->candidates = h[1]; out->sweepIterations = h[2]; out->overflow = h[3];
+    if (reset) { SGE_HIP(hipMemsetAsync(c->dStats.p, 0, 32, c->stream)); SGE_HIP(hipStreamSynchronize(c->stream)); }
+    return SGE_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,1193 @@
+// Capsule-CCD move-and-slide against the static triangle set, for gfx950.
+// Replaces, per fixed step and per character:
+//   PhysicsIntentSystem (controller branch)   Game/Systems.swift:205-250
+//   GravitySystem                             Game/Systems.swift:596-620
+//   KinematicMoveStopSystem.fixedUpdate       Game/Systems.swift:1823-1902
+//     DepenetrationResolver :734-808, resolveKinematicSweep :1658-1765,
+//     SlideResolver.resolveHit :1229-1375, GroundProbe/GroundSnap/SlopeFriction :826-1021,
+//     DefaultContactCachePolicy/ContactManifoldCache :1102-1205, AgentSweepSolver :1053-1091
+//   CollisionQuery.capsuleCast* / capsuleOverlapAll   Game/CollisionQuery.swift:96-159, 852-1283
+//   sweepCapsuleTriangle / refineTOI / segmentTriangleDistance  Game/CollisionQuery.swift:1285-1573
+//
+// Mapping: ONE WAVEFRONT PER CHARACTER (64-thread workgroups). The per-character
+// state machine (depenetration -> slide iterations -> ground probe -> snap ->
+// friction -> write-back) is wave-uniform; each BVH query inside it is
+// wave-cooperative:
+//   * traversal: an LDS stack of node indices, up to 64 nodes popped and AABB-tested
+//     per step (one per lane), children / leaf triangles appended with ballot +
+//     prefix-popcount compaction;
+//   * candidates: batches of <= 64 triangles, one per lane. The reference's result
+//     depends on its right-child-first visit order only through strict `<`
+//     tie-breaks and capsuleOverlapAll's "first maxHits"; every triangle carries its
+//     visit rank, so lanes may run in any order and the wave reduces on
+//     (toi, rank) / selects by rank;
+//   * sweep: the reference's conservative advancement + 10-step bisection + final
+//     contact evaluation is rescheduled as a per-lane state machine in which every
+//     loop trip performs exactly one segmentTriangleDistance evaluation, so lanes in
+//     different phases stay convergent on the expensive code. A lane stops early
+//     once its last safe t exceeds the best accepted TOI of the wave (its hit could
+//     no longer win the strict `<`), which is what makes the 200-unit fall probe
+//     cheap.
+// Compiled with -ffp-contract=off; float32 arithmetic is IEEE and in the oracle's
+// order, so TOIs, normals and the discrete contact state match bit for bit.
+#include "sge_internal.hpp"
+
+namespace sge {
+
+constexpr int kWave = 64;
+constexpr int kStackCap = 1024;
+constexpr int kStackSoft = 768;   // above this, pop one node at a time (growth <= tree depth)
+constexpr int kCandCap = 512;
+
+struct OverlapRec { float depth; F3 position, normal, triNormal; int triIndex, rank; };
+struct CastRec { float toi; F3 position, normal, triNormal; int triIndex; };
+
+struct WaveShared {
+    int stack[kStackCap];
+    int cand[kCandCap];
+    CastRec bestCast;
+    OverlapRec ovl[SGE_MAX_OVERLAP_HITS];
+    OverlapRec ovlTmp[SGE_MAX_OVERLAP_HITS];
+};
+
+struct WaveStats { unsigned int queries, candidates, evals, overflow; };
+
+// One instance per 64-thread workgroup (= per character / per query).
+__shared__ WaveShared sh;
+
+__device__ __forceinline__ int laneId() { return threadIdx.x & (kWave - 1); }
+__device__ __forceinline__ int prefixCount(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+}
+__device__ __forceinline__ unsigned long long waveMinU64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned lo = __shfl_xor((unsigned)v, o, kWave), hi = __shfl_xor((unsigned)(v >> 32), o, kWave);
+        unsigned long long w = ((unsigned long long)hi << 32) | lo;
+        v = w < v ? w : v;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// primitive distance queries (CollisionQuery.swift:1396-1573)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool segmentTriangleIntersect(F3 a, F3 b, F3 v0, F3 v1, F3 v2, F3& out) { // :1440
+    F3 dir = b - a;
+    const float eps = 1e-6f;
+    F3 e1 = v1 - v0, e2 = v2 - v0;
+    F3 pvec = cross(dir, e2);
+    float det = dot(e1, pvec);
+    if (fabsf(det) < eps) return false;
+    float invDet = 1.0f / det;
+    F3 tvec = a - v0;
+    float u = dot(tvec, pvec) * invDet;
+    if (u < 0 || u > 1) return false;
+    F3 qvec = cross(tvec, e1);
+    float v = dot(dir, qvec) * invDet;
+    if (v < 0 || (u + v) > 1) return false;
+    float t = dot(e2, qvec) * invDet;
+    if (t < 0 || t > 1) return false;
+    out = a + dir * t;
+    return true;
+}
+
+__device__ __forceinline__ float closestPointOnTriangle(F3 p, F3 a, F3 b, F3 c, F3& point) { // :1464
+    F3 ab = b - a, ac = c - a, ap = p - a;
+    float d1 = dot(ab, ap), d2 = dot(ac, ap);
+    if (d1 <= 0 && d2 <= 0) { point = a; return lengthSq(p - a); }
+    F3 bp = p - b;
+    float d3 = dot(ab, bp), d4 = dot(ac, bp);
+    if (d3 >= 0 && d4 <= d3) { point = b; return lengthSq(p - b); }
+    float vc = d1 * d4 - d3 * d2;
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) {
+        float v = d1 / (d1 - d3);
+        point = a + ab * v;
+        return lengthSq(p - point);
+    }
+    F3 cp = p - c;
+    float d5 = dot(ab, cp), d6 = dot(ac, cp);
+    if (d6 >= 0 && d5 <= d6) { point = c; return lengthSq(p - c); }
+    float vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) {
+        float w = d2 / (d2 - d6);
+        point = a + ac * w;
+        return lengthSq(p - point);
+    }
+    float va = d3 * d6 - d5 * d4;
+    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+        float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        point = b + (c - b) * w;
+        return lengthSq(p - point);
+    }
+    float denom = 1.0f / (va + vb + vc);
+    float v = vb * denom, w = vc * denom;
+    point = (a + ab * v) + ac * w;
+    return lengthSq(p - point);
+}
+
+__device__ __forceinline__ float segmentSegmentDistanceSq(F3 p1, F3 q1, F3 p2, F3 q2, F3& c1o, F3& c2o) { // :1519
+    F3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
+    float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);
+    float s = 0, t = 0;
+    const float eps = 1e-6f;
+    if (a <= eps && e <= eps) { c1o = p1; c2o = p2; return lengthSq(p1 - p2); }
+    if (a <= eps) {
+        t = sclamp(f / e, 0, 1);
+        F3 c2 = p2 + d2 * t;
+        c1o = p1; c2o = c2;
+        return lengthSq(p1 - c2);
+    }
+    float c = dot(d1, r);
+    if (e <= eps) {
+        s = sclamp(-c / a, 0, 1);
+        F3 c1 = p1 + d1 * s;
+        c1o = c1; c2o = p2;
+        return lengthSq(c1 - p2);
+    }
+    float b = dot(d1, d2);
+    float denom = a * e - b * b;
+    if (denom != 0) s = sclamp((b * f - c * e) / denom, 0, 1);
+    else s = 0;
+    float tNom = b * s + f;
+    if (tNom < 0) { t = 0; s = sclamp(-c / a, 0, 1); }
+    else if (tNom > e) { t = 1; s = sclamp((b - c) / a, 0, 1); }
+    else t = tNom / e;
+    F3 c1 = p1 + d1 * s, c2 = p2 + d2 * t;
+    c1o = c1; c2o = c2;
+    return lengthSq(c1 - c2);
+}
+
+__device__ __forceinline__ float segmentTriangleDistance(F3 center, float halfHeight, F3 v0, F3 v1, F3 v2,
+                                                         F3& segPoint, F3& triPoint) { // :1396
+    F3 up{0, 1, 0};
+    F3 a = center + up * halfHeight;
+    F3 b = center - up * halfHeight;
+    F3 hit;
+    if (segmentTriangleIntersect(a, b, v0, v1, v2, hit)) { segPoint = hit; triPoint = hit; return 0; }
+    float bestDistSq = kFloatMax;
+    F3 bestSeg = a, bestTri = v0;
+    F3 p0, p1;
+    float d0 = closestPointOnTriangle(a, v0, v1, v2, p0);
+    if (d0 < bestDistSq) { bestDistSq = d0; bestSeg = a; bestTri = p0; }
+    float dd1 = closestPointOnTriangle(b, v0, v1, v2, p1);
+    if (dd1 < bestDistSq) { bestDistSq = dd1; bestSeg = b; bestTri = p1; }
+    F3 s, t;
+    float d = segmentSegmentDistanceSq(a, b, v0, v1, s, t);
+    if (d < bestDistSq) { bestDistSq = d; bestSeg = s; bestTri = t; }
+    d = segmentSegmentDistanceSq(a, b, v1, v2, s, t);
+    if (d < bestDistSq) { bestDistSq = d; bestSeg = s; bestTri = t; }
+    d = segmentSegmentDistanceSq(a, b, v2, v0, s, t);
+    if (d < bestDistSq) { bestDistSq = d; bestSeg = s; bestTri = t; }
+    segPoint = bestSeg; triPoint = bestTri;
+    return sqrtf(smax(bestDistSq, 0.0f));
+}
+
+// ---------------------------------------------------------------------------
+// BVH traversal step: pop <= 64 nodes, push children, append leaf triangles
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool boxDisjoint(F3 bmin, F3 bmax, F3 minP, F3 maxP) {
+    return bmax.x < minP.x || bmin.x > maxP.x || bmax.y < minP.y || bmin.y > maxP.y || bmax.z < minP.z || bmin.z > maxP.z;
+}
+
+__device__ __forceinline__ void expandNodes(const DevCollision& col, F3 minP, F3 maxP, uint32_t mask,
+                                            int& stackSize, int& candCount, WaveStats& st) {
+    const int lane = laneId();
+    int n = stackSize > kStackSoft ? 1 : (stackSize < kWave ? stackSize : kWave);
+    int myNode = lane < n ? sh.stack[stackSize - 1 - lane] : -1;
+    stackSize -= n;
+    __syncthreads();
+    bool overlap = false;
+    int a = 0, b = 0;
+    if (myNode >= 0) {
+        const float4* np = reinterpret_cast<const float4*>(col.nodes + myNode);
+        float4 n0 = np[0], n1 = np[1];
+        overlap = !boxDisjoint(F3{n0.x, n0.y, n0.z}, F3{n0.w, n1.x, n1.y}, minP, maxP);
+        a = __float_as_int(n1.z);
+        b = __float_as_int(n1.w);
+    }
+    const bool leaf = a < 0;
+    const bool pushI = overlap && !leaf;
+    unsigned long long m = __ballot(pushI);
+    int tot = __popcll(m);
+    if (stackSize + 2 * tot > kStackCap) { st.overflow += 1; }
+    else if (pushI) {
+        int pre = prefixCount(m);
+        sh.stack[stackSize + 2 * pre] = a;
+        sh.stack[stackSize + 2 * pre + 1] = b;
+    }
+    if (stackSize + 2 * tot <= kStackCap) stackSize += 2 * tot;
+    const int firstSlot = ~a;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        bool c = overlap && leaf && k < b;
+        int slot = firstSlot + k;
+        if (c) {
+            const float4* tp = reinterpret_cast<const float4*>(col.tris + slot);
+            float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+            F3 v0{t0.x, t0.y, t0.z}, v1{t0.w, t1.x, t1.y}, v2{t1.z, t1.w, t2.x};
+            uint32_t layer = __float_as_uint(t2.y);
+            c = (layer & mask) != 0 && !boxDisjoint(vmin(v0, vmin(v1, v2)), vmax(v0, vmax(v1, v2)), minP, maxP);
+        }
+        unsigned long long mc = __ballot(c);
+        int totc = __popcll(mc);
+        if (candCount + totc > kCandCap) { st.overflow += 1; }
+        else {
+            if (c) sh.cand[candCount + prefixCount(mc)] = slot;
+            candCount += totc;
+        }
+    }
+    __syncthreads();
+}
+
+struct Tri { F3 v0, v1, v2; int triIndex, rank; };
+__device__ __forceinline__ Tri loadTri(const DevCollision& col, int slot) {
+    const float4* tp = reinterpret_cast<const float4*>(col.tris + slot);
+    float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+    Tri t;
+    t.v0 = F3{t0.x, t0.y, t0.z}; t.v1 = F3{t0.w, t1.x, t1.y}; t.v2 = F3{t1.z, t1.w, t2.x};
+    t.triIndex = __float_as_int(t2.z);
+    t.rank = __float_as_int(t2.w);
+    return t;
+}
+
+// ---------------------------------------------------------------------------
+// capsuleCastCombined over the static set (CollisionQuery.swift:980-1117)
+// ---------------------------------------------------------------------------
+enum { PH_MARCH = 0, PH_REFINE = 1, PH_FINAL = 2, PH_DONE = 3 };
+
+__device__ __noinline__ bool waveCapsuleCast(const DevCollision& col, F3 from, F3 delta, float radius,
+                                             float halfHeight, bool blockingOnly, bool hasMinNormalY, float minNormalY,
+                                             uint32_t mask, CastRec& out, WaveStats& st) {
+    const int lane = laneId();
+    float len = length(delta);
+    if (len < 1e-6f) return false;       // :987-988
+    if (col.root < 0) return false;      // :1020
+    st.queries += 1;
+    F3 dir = delta / len;
+    F3 up{0, 1, 0};
+    F3 a0 = from + up * halfHeight, b0 = from - up * halfHeight;
+    F3 a1 = a0 + delta, b1 = b0 + delta;
+    F3 minP = vmin(vmin(a0, b0), vmin(a1, b1));
+    F3 maxP = vmax(vmax(a0, b0), vmax(a1, b1));
+    F3 ext{radius, radius, radius};
+    minP = minP - ext; maxP = maxP + ext;
+
+    // sweep constants (:1295-1297)
+    const float minAdvance = smax(radius * 0.02f, 1e-4f);
+    int maxIter = (int)ceilf(len / minAdvance) + 1;
+    maxIter = maxIter < 256 ? maxIter : 256;
+    const float contactEps = 1e-5f;
+
+    unsigned long long bestKey = ~0ull; // (toi bits << 32) | rank, over accepted hits with toi < len
+    float bestToi = len;                // prune bound: a hit must have toi < bestToi (or tie with lower rank)
+    int stackSize = 1, candCount = 0;
+    if (lane == 0) sh.stack[0] = col.root;
+    __syncthreads();
+
+    while (true) {
+        while (stackSize > 0 && candCount < kWave) expandNodes(col, minP, maxP, mask, stackSize, candCount, st);
+        if (candCount == 0) break;
+        int n = candCount < kWave ? candCount : kWave;
+        candCount -= n;
+        st.candidates += n;
+        bool active = lane < n;
+        Tri tri;
+        tri.v0 = tri.v1 = tri.v2 = F3{0, 0, 0}; tri.triIndex = -1; tri.rank = 0x7fffffff;
+        if (active) tri = loadTri(col, sh.cand[candCount + lane]);
+        F3 triNormal = normalize(cross(tri.v1 - tri.v0, tri.v2 - tri.v0));
+
+        int phase = active ? PH_MARCH : PH_DONE;
+        float t = 0, lastSafeT = 0, lo = 0, hi = 0, tEval = 0;
+        int iter = 0, refineK = 0;
+        unsigned long long myKey = ~0ull;
+        CastRec mine;
+        mine.toi = 0; mine.position = mine.normal = mine.triNormal = F3{0, 0, 0}; mine.triIndex = -1;
+
+        while (__any(phase != PH_DONE)) {
+            if (phase == PH_MARCH) {
+                // loop head of :1303-1307 — iteration budget, then `if t > maxDistance return nil`
+                if (iter >= maxIter || t > len || lastSafeT > bestToi) phase = PH_DONE;
+                else { iter += 1; tEval = t; }
+            } else if (phase == PH_REFINE) {
+                if (lo > bestToi) phase = PH_DONE;
+                else tEval = 0.5f * (lo + hi);
+            }
+            if (phase != PH_DONE) {
+                st.evals += 1;
+                F3 center = from + dir * tEval;
+                F3 segP, triP;
+                float dist = segmentTriangleDistance(center, halfHeight, tri.v0, tri.v1, tri.v2, segP, triP);
+                if (phase == PH_MARCH) {
+                    if (dist <= radius + contactEps) {
+                        // refineTOI(t0: lastSafeT, t1: t) :1361-1377
+                        float c0 = smax(0.0f, smin(lastSafeT, len));
+                        float c1 = smax(0.0f, smin(t, len));
+                        lo = smin(c0, c1);
+                        hi = smax(c0, c1);
+                        if (hi - lo < 1e-5f) { phase = PH_FINAL; tEval = hi; }
+                        else { phase = PH_REFINE; refineK = 0; }
+                    } else {
+                        lastSafeT = t;
+                        float advance = smax(dist - radius, minAdvance);
+                        if (advance <= 0) t += minAdvance; else t += advance;
+                    }
+                } else if (phase == PH_REFINE) {
+                    if (dist <= radius) hi = tEval; else lo = tEval;
+                    refineK += 1;
+                    if (refineK == 10) { phase = PH_FINAL; tEval = hi; }
+                } else { // PH_FINAL :1325-1346
+                    float tHit = tEval;
+                    F3 nrm;
+                    if (dist < 1e-6f) nrm = dot(triNormal, dir) > 0 ? -triNormal : triNormal;
+                    else nrm = normalize(segP - triP);
+                    F3 triN = triNormal;
+                    if (dot(triN, nrm) < 0) triN = -triN;
+                    phase = PH_DONE;
+                    // acceptance filters of capsuleCastBVH :1084-1097 (toi < len; blocking; minNormalY)
+                    bool ok = tHit < len;
+                    if (ok && blockingOnly) ok = !(dot(delta, nrm) >= 0) && !(dot(delta, triN) >= 0);
+                    if (ok && hasMinNormalY) ok = !(triN.y < minNormalY);
+                    if (ok) {
+                        mine.toi = tHit; mine.position = triP; mine.normal = nrm; mine.triNormal = triN; mine.triIndex = tri.triIndex;
+                        myKey = ((unsigned long long)__float_as_uint(tHit) << 32) | (unsigned)tri.rank;
+                    }
+                }
+            }
+            // tighten the prune bound as soon as any lane has an accepted hit
+            unsigned long long got = __ballot(myKey != ~0ull && __uint_as_float((unsigned)(myKey >> 32)) < bestToi);
+            if (got) {
+                unsigned long long k = waveMinU64(myKey);
+                bestToi = smin(bestToi, __uint_as_float((unsigned)(k >> 32)));
+            }
+        }
+        unsigned long long k = waveMinU64(myKey);
+        if (k < bestKey) {
+            bestKey = k;
+            if (myKey == k) sh.bestCast = mine;
+        }
+        __syncthreads();
+    }
+    if (bestKey == ~0ull) return false;
+    out = sh.bestCast;
+    __syncthreads();
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// capsuleOverlapAll over the static set (CollisionQuery.swift:852-882, 1201-1283):
+// the first `maxHits` overlapping triangles in visit order = the maxHits lowest ranks
+// ---------------------------------------------------------------------------
+__device__ __noinline__ int waveCapsuleOverlapAll(const DevCollision& col, F3 from, float radius,
+                                                  float halfHeight, int maxHits, uint32_t mask, WaveStats& st) {
+    const int lane = laneId();
+    if (col.root < 0) return 0;
+    st.queries += 1;
+    F3 up{0, 1, 0};
+    F3 a0 = from + up * halfHeight, b0 = from - up * halfHeight;
+    F3 minP = vmin(a0, b0), maxP = vmax(a0, b0);
+    F3 ext{radius, radius, radius};
+    minP = minP - ext; maxP = maxP + ext;
+    int count = 0; // entries in sh.ovl, sorted by rank
+    int stackSize = 1, candCount = 0;
+    if (lane == 0) sh.stack[0] = col.root;
+    __syncthreads();
+    while (true) {
+        while (stackSize > 0 && candCount < kWave) expandNodes(col, minP, maxP, mask, stackSize, candCount, st);
+        if (candCount == 0) break;
+        int n = candCount < kWave ? candCount : kWave;
+        candCount -= n;
+        st.candidates += n;
+        bool pending = false;
+        OverlapRec rec;
+        rec.depth = 0; rec.position = rec.normal = rec.triNormal = F3{0, 0, 0}; rec.triIndex = -1; rec.rank = 0x7fffffff;
+        if (lane < n) {
+            Tri tri = loadTri(col, sh.cand[candCount + lane]);
+            st.evals += 1;
+            F3 segP, triP;
+            float dist = segmentTriangleDistance(from, halfHeight, tri.v0, tri.v1, tri.v2, segP, triP);
+            if (!(dist >= radius)) { // :1253
+                F3 triNormal = normalize(cross(tri.v1 - tri.v0, tri.v2 - tri.v0));
+                F3 nn = dist < 1e-6f ? triNormal : normalize(segP - triP);
+                F3 triN = triNormal;
+                if (dot(triN, nn) < 0) triN = -triN;
+                rec.depth = radius - dist; rec.position = triP; rec.normal = nn; rec.triNormal = triN;
+                rec.triIndex = tri.triIndex; rec.rank = tri.rank;
+                pending = true;
+            }
+        }
+        if (__any(pending)) {
+            // merge: existing sorted list (sh.ovl[0..count)) with this batch's hits extracted in rank order
+            int ie = 0, k = 0;
+            for (; k < maxHits; ++k) {
+                unsigned pr = pending ? (unsigned)rec.rank : 0xffffffffu;
+                unsigned long long pmin = waveMinU64((unsigned long long)pr);
+                unsigned er = ie < count ? (unsigned)sh.ovl[ie].rank : 0xffffffffu;
+                if (pmin == 0xffffffffull && er == 0xffffffffu) break;
+                if ((unsigned)pmin < er) {
+                    if (pending && (unsigned)rec.rank == (unsigned)pmin) { sh.ovlTmp[k] = rec; pending = false; }
+                } else {
+                    if (lane == 0) sh.ovlTmp[k] = sh.ovl[ie];
+                    ie += 1;
+                }
+            }
+            __syncthreads();
+            if (lane < k) sh.ovl[lane] = sh.ovlTmp[lane];
+            count = k;
+            __syncthreads();
+        }
+    }
+    return count;
+}
+
+// ---------------------------------------------------------------------------
+// contact cache (Systems.swift:1102-1205)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ F3 ld3(const float* p) { return F3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ void st3(float* p, F3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+
+__device__ __forceinline__ void cacheDecay(sge_controller_state& c) { // :1105
+    if (c.sideContactFrames > 0) c.sideContactFrames -= 1;
+    if (c.manifoldFrames > 0) {
+        c.manifoldFrames -= 1;
+        if (c.manifoldFrames == 0) {
+            c.manifoldCount = 0;
+            c.manifoldFrames = 0;
+            st3(c.sideContactNormal, F3{0, 0, 0});
+        }
+    }
+}
+__device__ __forceinline__ bool cachedNormal(const sge_controller_state& c, int triangleIndex, F3& out) { // :1169
+#pragma unroll
+    for (int i = 0; i < SGE_MANIFOLD_MAX; ++i)
+        if (i < c.manifoldCount && c.manifoldTriangles[i] == triangleIndex) { out = ld3(c.manifoldNormals[i]); return true; }
+    return false;
+}
+__device__ __forceinline__ void manifoldUpdate(sge_controller_state& c, int triangleIndex, F3 normal) { // :1177
+    F3 n = normal;
+    if (lengthSq(n) < 1e-8f) return;
+    c.manifoldFrames = 8;
+#pragma unroll
+    for (int i = 0; i < SGE_MANIFOLD_MAX; ++i) {
+        if (i < c.manifoldCount && c.manifoldTriangles[i] == triangleIndex) {
+            F3 cached = ld3(c.manifoldNormals[i]);
+            if (dot(cached, n) < 0) n = -n;
+            const float blend = 0.25f;
+            F3 combined = normalize(cached * (1 - blend) + n * blend);
+            st3(c.manifoldNormals[i], combined);
+            st3(c.sideContactNormal, combined);
+            return;
+        }
+    }
+    if (c.manifoldCount >= SGE_MANIFOLD_MAX) c.manifoldCount -= 1;
+#pragma unroll
+    for (int i = SGE_MANIFOLD_MAX - 1; i > 0; --i) {
+        if (i <= c.manifoldCount) {
+            c.manifoldTriangles[i] = c.manifoldTriangles[i - 1];
+            st3(c.manifoldNormals[i], ld3(c.manifoldNormals[i - 1]));
+        }
+    }
+    c.manifoldTriangles[0] = triangleIndex;
+    st3(c.manifoldNormals[0], normalize(n));
+    c.manifoldCount += 1;
+    st3(c.sideContactNormal, ld3(c.manifoldNormals[0]));
+}
+__device__ __forceinline__ void cacheRecord(sge_controller_state& c, int triangleIndex, F3 normal, bool isSideContact) { // :1122
+    manifoldUpdate(c, triangleIndex, normal);
+    if (isSideContact) {
+        st3(c.sideContactNormal, normalize(normal));
+        c.sideContactFrames = 3;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// capsule-capsule sweep (Systems.swift:1417-1590)
+// ---------------------------------------------------------------------------
+struct Interval { float s, e; bool ok; };
+__device__ __forceinline__ Interval clampInterval(float start, float end) {
+    float s = smax(start, 0.0f), e = smin(end, 1.0f);
+    if (e < s) return Interval{0, 0, false};
+    return Interval{s, e, true};
+}
+__device__ __forceinline__ Interval intervalGreaterEqual(float y0, float vy, float threshold) {
+    if (fabsf(vy) < 1e-6f) return y0 >= threshold ? Interval{0, 1, true} : Interval{0, 0, false};
+    float t = (threshold - y0) / vy;
+    if (vy > 0) return clampInterval(t, 1);
+    return clampInterval(0, t);
+}
+__device__ __forceinline__ Interval intervalLessEqual(float y0, float vy, float threshold) {
+    if (fabsf(vy) < 1e-6f) return y0 <= threshold ? Interval{0, 1, true} : Interval{0, 0, false};
+    float t = (threshold - y0) / vy;
+    if (vy > 0) return clampInterval(0, t);
+    return clampInterval(t, 1);
+}
+__device__ __forceinline__ bool earliestRoot(float A, float B, float C, float tMin, float tMax, float& out) {
+    const float eps = 1e-6f;
+    if (fabsf(A) < eps) {
+        if (fabsf(B) < eps) { if (C <= 0) { out = tMin; return true; } return false; }
+        float t = -C / B;
+        if (t >= tMin && t <= tMax) { out = t; return true; }
+        return false;
+    }
+    float disc = B * B - 4 * A * C;
+    if (disc < 0) return false;
+    float sqrtD = sqrtf(disc);
+    float inv2A = 1 / (2 * A);
+    float t0 = (-B - sqrtD) * inv2A;
+    float t1 = (-B + sqrtD) * inv2A;
+    float enter = smin(t0, t1), exit = smax(t0, t1);
+    float s = smax(enter, tMin), e = smin(exit, tMax);
+    if (e >= s) { out = s; return true; }
+    return false;
+}
+__device__ __forceinline__ float capsuleSeparationY(float yRel, float hSum) {
+    if (yRel > hSum) return yRel - hSum;
+    if (yRel < -hSum) return yRel + hSum;
+    return 0;
+}
+__device__ __forceinline__ F3 capsuleHitNormal(F3 rel, float hSum) {
+    float sepY = capsuleSeparationY(rel.y, hSum);
+    F3 sep{rel.x, sepY, rel.z};
+    float lenSq = lengthSq(sep);
+    if (lenSq > 1e-8f) return sep / sqrtf(lenSq);
+    F3 lateral{rel.x, 0, rel.z};
+    float l2 = lengthSq(lateral);
+    if (l2 > 1e-8f) return lateral / sqrtf(l2);
+    return F3{1, 0, 0};
+}
+__device__ __forceinline__ bool capsuleCapsuleSweep(F3 from, F3 delta, float radius, float halfHeight, F3 otherPos,
+                                                    F3 otherDelta, float otherRadius, float otherHalfHeight,
+                                                    float& toiOut, F3& normalOut) {
+    F3 relStart = from - otherPos;
+    F3 relDelta = delta - otherDelta;
+    float rSum = radius + otherRadius, hSum = halfHeight + otherHalfHeight;
+    float relLen = length(relDelta), moveLen = length(delta);
+    if (relLen < 1e-6f) {
+        float sepY = capsuleSeparationY(relStart.y, hSum);
+        float distSq = relStart.x * relStart.x + relStart.z * relStart.z + sepY * sepY;
+        if (distSq <= rSum * rSum) { toiOut = 0; normalOut = capsuleHitNormal(relStart, hSum); return true; }
+        return false;
+    }
+    float y0 = relStart.y, vy = relDelta.y, vx = relDelta.x, vz = relDelta.z, r0x = relStart.x, r0z = relStart.z;
+    bool have = false;
+    float bestT = 0, t;
+    Interval upper = intervalGreaterEqual(y0, vy, hSum);
+    if (upper.ok) {
+        float A = vx * vx + vz * vz + vy * vy;
+        float B = 2 * (r0x * vx + r0z * vz + (y0 - hSum) * vy);
+        float C = r0x * r0x + r0z * r0z + (y0 - hSum) * (y0 - hSum) - rSum * rSum;
+        if (earliestRoot(A, B, C, upper.s, upper.e, t)) { bestT = t; have = true; }
+    }
+    Interval lower = intervalLessEqual(y0, vy, -hSum);
+    if (lower.ok) {
+        float A = vx * vx + vz * vz + vy * vy;
+        float B = 2 * (r0x * vx + r0z * vz + (y0 + hSum) * vy);
+        float C = r0x * r0x + r0z * r0z + (y0 + hSum) * (y0 + hSum) - rSum * rSum;
+        if (earliestRoot(A, B, C, lower.s, lower.e, t)) { if (!have || t < bestT) { bestT = t; have = true; } }
+    }
+    if (fabsf(vy) < 1e-6f) {
+        if (fabsf(y0) <= hSum) {
+            float A = vx * vx + vz * vz;
+            float B = 2 * (r0x * vx + r0z * vz);
+            float C = r0x * r0x + r0z * r0z - rSum * rSum;
+            if (earliestRoot(A, B, C, 0, 1, t)) { if (!have || t < bestT) { bestT = t; have = true; } }
+        }
+    } else {
+        float t1 = (hSum - y0) / vy, t2 = (-hSum - y0) / vy;
+        Interval ov = clampInterval(smin(t1, t2), smax(t1, t2));
+        if (ov.ok) {
+            float A = vx * vx + vz * vz;
+            float B = 2 * (r0x * vx + r0z * vz);
+            float C = r0x * r0x + r0z * r0z - rSum * rSum;
+            if (earliestRoot(A, B, C, ov.s, ov.e, t)) { if (!have || t < bestT) { bestT = t; have = true; } }
+        }
+    }
+    if (!have) return false;
+    F3 relAtHit = relStart + relDelta * bestT;
+    normalOut = capsuleHitNormal(relAtHit, hSum);
+    toiOut = bestT * moveLen;
+    return true;
+}
+
+// AgentSweepSolver.bestHit (Systems.swift:1053-1091). The reference loops over every
+// solid agent; only agents whose XZ footprint can be reached within this segment can
+// hit, so the wave scans the grid cells covering that reach, 64 agents at a time, and
+// reduces on (toi, agent index) — the index reproduces the reference's first-wins
+// `<` over its (index-ordered) snapshot.
+__device__ __noinline__ bool waveAgentBestHit(const DevAgents& ag, F3 position, F3 remaining, float remainingLen,
+                                              float baseMoveLen, float dt, int selfIndex, float selfRadius,
+                                              float halfHeight, float maxAgentRadius, float maxAgentSpeed,
+                                              float& toiOut, F3& normalOut) {
+    const int lane = laneId();
+    float timeScale = baseMoveLen > 1e-6f ? smin(remainingLen / baseMoveLen, 1.0f) : 1.0f;
+    float segmentDt = dt * timeScale;
+    // conservative XZ reach: own move + the fastest other agent's move + both radii
+    float reach = remainingLen + maxAgentSpeed * segmentDt + selfRadius + maxAgentRadius + 1e-3f;
+    int cx0 = (int)floorf((position.x - reach - ag.originX) * ag.invCell), cx1 = (int)floorf((position.x + reach - ag.originX) * ag.invCell);
+    int cz0 = (int)floorf((position.z - reach - ag.originZ) * ag.invCell), cz1 = (int)floorf((position.z + reach - ag.originZ) * ag.invCell);
+    cx0 = cx0 < 0 ? 0 : cx0; cz0 = cz0 < 0 ? 0 : cz0;
+    cx1 = cx1 >= ag.nx ? ag.nx - 1 : cx1; cz1 = cz1 >= ag.nz ? ag.nz - 1 : cz1;
+    unsigned long long bestKey = ~0ull;
+    F3 bestN{0, 0, 0};
+    for (int cz = cz0; cz <= cz1; ++cz) {
+        // cells of one row are contiguous in cellStart: scan [start(cx0), start(cx1+1))
+        int s = ag.cellStart[cz * ag.nx + cx0], e = ag.cellStart[cz * ag.nx + cx1 + 1];
+        for (int base = s; base < e; base += kWave) {
+            int j = base + lane;
+            unsigned long long key = ~0ull;
+            F3 nrm{0, 0, 0};
+            if (j < e) {
+                int other = ag.cellItems[j];
+                if (other != selfIndex) {
+                    sge_agent_state o = ag.all[other];
+                    F3 otherDelta = F3{o.velocity[0], o.velocity[1], o.velocity[2]} * segmentDt;
+                    float toi;
+                    if (capsuleCapsuleSweep(position, remaining, selfRadius, halfHeight,
+                                            F3{o.position[0], o.position[1], o.position[2]}, otherDelta, o.radius,
+                                            o.halfHeight, toi, nrm)) {
+                        // toi >= 0 by construction (bestT in [0,1], moveLen >= 0): float bits order as integers
+                        key = ((unsigned long long)__float_as_uint(toi) << 32) | (unsigned)other;
+                    }
+                }
+            }
+            unsigned long long k = waveMinU64(key);
+            if (k < bestKey) {
+                bestKey = k;
+                int src = __ffsll((long long)__ballot(key == k)) - 1;
+                bestN = F3{__shfl(nrm.x, src, kWave), __shfl(nrm.y, src, kWave), __shfl(nrm.z, src, kWave)};
+            }
+        }
+    }
+    if (bestKey == ~0ull) return false;
+    toiOut = __uint_as_float((unsigned)(bestKey >> 32));
+    normalOut = bestN;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// the per-character step
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ D3 approachVecD(D3 current, D3 target, double maxDelta) { // Systems.swift:419
+    D3 delta = target - current;
+    double len = length(delta);
+    if (len <= maxDelta || len < 0.00001) return target;
+    return current + delta / len * maxDelta;
+}
+
+struct SlideHit { bool isStatic; CastRec s; float aToi; F3 aNormal; };
+
+// SlideResolver.resolveHit with options .kinematicMove (Systems.swift:1229-1375)
+__device__ __forceinline__ bool resolveHit(F3& remaining, float len, const SlideHit& hit, const sge_controller_params& P,
+                                           const sge_controller_state& C, bool wasGrounded, bool wasGroundedNear,
+                                           D3& velocity, F3& position, bool hasCachedSide, F3 cachedSide) {
+    float contactSkin, hitToi;
+    F3 slideNormal, hitTriNormal{0, 0, 0};
+    bool hitIsStatic = false, hitIsGroundLike = false;
+    if (hit.isStatic) {
+        hitToi = hit.s.toi;
+        slideNormal = hit.s.normal;
+        hitIsGroundLike = hit.s.triNormal.y >= P.minGroundDot;
+        contactSkin = hitIsGroundLike ? P.groundSnapSkin : P.skinWidth;
+        hitTriNormal = hit.s.triNormal;
+        hitIsStatic = true;
+    } else {
+        hitToi = hit.aToi;
+        slideNormal = hit.aNormal;
+        contactSkin = 0;
+    }
+    if (hitIsStatic && slideNormal.y < P.minGroundDot && C.sideContactFrames > 0) {
+        if (hasCachedSide) {
+            F3 cachedN = cachedSide;
+            if (dot(cachedN, slideNormal) < 0) cachedN = -cachedN;
+            slideNormal = cachedN;
+        } else {
+            F3 cached = ld3(C.sideContactNormal);
+            float cachedLen = lengthSq(cached);
+            if (cachedLen > 1e-6f) {
+                F3 cachedN = cached / sqrtf(cachedLen);
+                float dotC = dot(cachedN, slideNormal);
+                if (fabsf(dotC) > 0.5f) slideNormal = dotC >= 0 ? cachedN : -cachedN;
+            }
+        }
+    }
+    if (slideNormal.y < P.minGroundDot) {
+        if (hitIsStatic && hitIsGroundLike) slideNormal = hitTriNormal;
+        if (slideNormal.y < P.minGroundDot) {
+            slideNormal.y = 0;
+            float nLen = length(slideNormal);
+            if (nLen > 1e-5f) {
+                slideNormal = slideNormal / nLen;
+            } else {
+                position = position + remaining;
+                remaining = F3{0, 0, 0};
+                return true;
+            }
+        }
+    }
+    float into = dot(remaining, slideNormal);
+    float intoEps = 1e-4f * len;
+    float effectiveSkin;
+    if (hitToi <= contactSkin && into < -intoEps) effectiveSkin = smin(contactSkin, hitToi * 0.5f);
+    else effectiveSkin = contactSkin;
+    float stickyThreshold = contactSkin * 0.1f;
+    if (hitToi <= stickyThreshold && into < -intoEps) {
+        remaining = remaining - slideNormal * into;
+        return false;
+    }
+    if (into >= -intoEps) {
+        if (wasGroundedNear && hitIsStatic && !hitIsGroundLike && remaining.y < 0) remaining.y = 0;
+        position = position + remaining;
+        remaining = F3{0, 0, 0};
+        return true;
+    }
+    if (hitToi <= effectiveSkin && fabsf(into) <= intoEps) {
+        position = position + remaining;
+        remaining = F3{0, 0, 0};
+        return true;
+    }
+    if (into >= 0) {
+        position = position + remaining;
+        remaining = F3{0, 0, 0};
+        return true;
+    }
+    float rawMoveDist = smax(hitToi - effectiveSkin, 0.0f);
+    float moveDist = rawMoveDist;
+    if (slideNormal.y >= P.minGroundDot && remaining.y < 0 && moveDist > P.groundSweepMaxStep) moveDist = P.groundSweepMaxStep;
+    F3 dir = remaining / len;
+    position = position + dir * moveDist;
+    F3 leftover = remaining - dir * moveDist;
+    leftover = leftover - slideNormal * dot(leftover, slideNormal);
+    if (wasGrounded && wasGroundedNear && leftover.y < 0) leftover.y = 0;
+    float residual = dot(leftover, slideNormal);
+    if (fabsf(residual) < 1e-5f) leftover = leftover - slideNormal * residual;
+    if (lengthSq(leftover) < 1e-8f) {
+        remaining = F3{0, 0, 0};
+        return true;
+    }
+    remaining = leftover;
+    D3 snD = toD(slideNormal);
+    double vInto = dot(velocity, snD);
+    if (vInto < 0) velocity = velocity - snD * vInto;
+    return false;
+}
+
+__global__ __launch_bounds__(kWave) void move_kernel(MoveLaunch K) {
+    const int e = K.first + blockIdx.x;
+    const int lane = laneId();
+    WaveStats st{0, 0, 0, 0};
+    const DevCollision& col = K.col;
+
+    sge_body_state body = K.crowd.bodies[e];
+    const sge_controller_params P = K.crowd.params[e];
+    sge_controller_state C = K.crowd.controllers[e];
+    const float dt = K.dt;
+    const F3 gravity{K.gx, K.gy, K.gz};
+    D3 velocity{body.linearVelocity[0], body.linearVelocity[1], body.linearVelocity[2]};
+
+    // ---- PhysicsIntentSystem, controller branch (Systems.swift:217-247) ----
+    if (K.stages & SGE_STAGE_INTENT) {
+        const sge_move_intent in = K.crowd.intents[e];
+        if ((in.flags & SGE_INTENT_PRESENT) && (body.bodyType == SGE_BODY_DYNAMIC || body.bodyType == SGE_BODY_KINEMATIC)) {
+            if (in.flags & SGE_INTENT_DODGE_ACTIVE) {
+                velocity.x = (double)in.desiredVelocity[0];
+                velocity.z = (double)in.desiredVelocity[2];
+            } else {
+                D3 target{(double)in.desiredVelocity[0], 0.0, (double)in.desiredVelocity[2]};
+                D3 current{velocity.x, 0.0, velocity.z};
+                float accel = length(target) >= length(current) ? in.maxAcceleration : in.maxDeceleration;
+                D3 next = approachVecD(current, target, (double)accel * (double)dt);
+                velocity.x = next.x;
+                velocity.z = next.z;
+            }
+            if (in.flags & SGE_INTENT_HAS_FACING_YAW) {
+                Quat q = quatAngleAxis(in.desiredFacingYaw, F3{0, 1, 0});
+                body.rotation[0] = q.x; body.rotation[1] = q.y; body.rotation[2] = q.z; body.rotation[3] = q.w;
+            }
+        }
+    }
+    // ---- GravitySystem (Systems.swift:609-618) ----
+    if ((K.stages & SGE_STAGE_GRAVITY) && body.bodyType == SGE_BODY_DYNAMIC &&
+        !((C.flags & SGE_CTRL_GROUNDED) && (C.flags & SGE_CTRL_GROUNDED_NEAR))) {
+        velocity = velocity + toD(gravity) * (double)dt;
+    }
+
+    F3 position = toF(D3{body.position[0], body.position[1], body.position[2]});
+    if ((K.stages & SGE_STAGE_MOVE) && body.bodyType != SGE_BODY_STATIC) {
+        cacheDecay(C);
+        const bool hasAgent = (P.agentFlags & SGE_AGENT_PRESENT) != 0;
+        const bool selfSolid = hasAgent && (P.agentFlags & SGE_AGENT_SOLID);
+        const float selfRadius = (hasAgent && (P.agentFlags & SGE_AGENT_RADIUS_OVERRIDE)) ? P.agentRadiusOverride : P.radius;
+        const bool wasGrounded = (C.flags & SGE_CTRL_GROUNDED) != 0;
+        const bool wasGroundedNear = (C.flags & SGE_CTRL_GROUNDED_NEAR) != 0;
+        // VelocityGate.apply :1037-1051
+        if (wasGrounded && wasGroundedNear && velocity.y < 0) velocity.y = 0;
+        D3 remD = velocity * (double)dt;
+        if (wasGrounded && wasGroundedNear && remD.y < 0) remD.y = 0;
+        F3 remaining = toF(remD);
+
+        // ---- DepenetrationResolver.resolve :734-808 + applyPreSweepDepenetration :1642-1655 ----
+        {
+            const float slop = smax(P.skinWidth * 0.5f, 0.001f);
+            bool didResolve = false;
+            F3 normalSum{0, 0, 0};
+            float normalWeight = 0;
+            for (int it = 0; it < 4; ++it) {
+                int n = waveCapsuleOverlapAll(col, position, P.radius, P.halfHeight, 8, P.collisionMask, st);
+                if (n == 0) break;
+                // stable sort by depth descending: pick the deepest and second deepest (first occurrence wins ties)
+                int i0 = 0;
+                for (int k = 1; k < n; ++k) if (sh.ovl[k].depth > sh.ovl[i0].depth) i0 = k;
+                int i1 = -1;
+                for (int k = 0; k < n; ++k) {
+                    if (k == i0) continue;
+                    if (i1 < 0 || sh.ovl[k].depth > sh.ovl[i1].depth) i1 = k;
+                }
+                OverlapRec deepest = sh.ovl[i0];
+                OverlapRec second = i1 >= 0 ? sh.ovl[i1] : deepest;
+                __syncthreads();
+                bool sideContact = deepest.normal.y < P.minGroundDot;
+                int useCount = sideContact ? 1 : (n < 2 ? n : 2);
+                float maxDepth = deepest.depth;
+                F3 frameNormal{0, 0, 0};
+                for (int k = 0; k < useCount; ++k) {
+                    const OverlapRec& hit = k == 0 ? deepest : second;
+                    maxDepth = smax(maxDepth, hit.depth);
+                    F3 nn = hit.normal, cached;
+                    if (cachedNormal(C, hit.triIndex, cached)) nn = cached;
+                    frameNormal = frameNormal + nn * hit.depth;
+                    cacheRecord(C, hit.triIndex, nn, hit.normal.y < P.minGroundDot);
+                }
+                float frameNormalLen = length(frameNormal);
+                F3 depenNormal = frameNormalLen > 1e-6f ? frameNormal / frameNormalLen : frameNormal;
+                float push = sideContact ? smax(maxDepth, 0.0f) : smax(maxDepth + slop, 0.0f);
+                if (sideContact) push = smin(push, P.skinWidth);
+                if (push <= 1e-6f) break;
+                position = position + depenNormal * push;
+                D3 dn = toD(depenNormal);
+                double vInto = dot(velocity, dn);
+                if (vInto < 0) velocity = velocity - dn * vInto;
+                didResolve = true;
+                normalSum = normalSum + depenNormal * maxDepth;
+                normalWeight += maxDepth;
+            }
+            if (didResolve) {
+                F3 depenNormal = normalWeight > 1e-6f ? normalize(normalSum / normalWeight) : normalize(normalSum);
+                float into = dot(remaining, depenNormal);
+                if (into < 0) remaining = remaining - depenNormal * into;
+            }
+        }
+
+        // ---- resolveKinematicSweep :1658-1765 ----
+        {
+            F3 baseMove = toF(velocity) * dt;
+            float baseMoveLen = length(baseMove);
+            bool haveLast = false;
+            F3 lastSlideNormal{0, 0, 0};
+            const bool useAgents = (K.stages & SGE_STAGE_AGENTS) && selfSolid && K.agents.all != nullptr;
+            for (int it = 0; it < P.maxSlideIterations; ++it) {
+                float len = length(remaining);
+                if (len < 1e-6f) break;
+                SlideHit hit;
+                hit.aToi = 0; hit.aNormal = F3{0, 0, 0};
+                bool haveStatic = waveCapsuleCast(col, position, remaining, P.radius, P.halfHeight, true, false, 0.0f,
+                                                  P.collisionMask, hit.s, st);
+                if (haveStatic && hit.s.normal.y < P.minGroundDot && C.sideContactFrames > 0) {
+                    F3 cached;
+                    if (cachedNormal(C, hit.s.triIndex, cached)) {
+                        if (dot(cached, hit.s.normal) < 0) cached = -cached;
+                        hit.s.normal = cached;
+                    }
+                }
+                bool haveAgent = false;
+                if (useAgents)
+                    haveAgent = waveAgentBestHit(K.agents, position, remaining, len, baseMoveLen, dt, K.agents.selfOffset + e,
+                                                 selfRadius, P.halfHeight, K.agents.maxRadius, K.agents.maxSpeed, hit.aToi, hit.aNormal);
+                if (haveStatic || haveAgent) {
+                    if (haveStatic && haveAgent) { // HitSelector.selectBestHit :1382-1390
+                        float staticSkin = hit.s.normal.y >= P.minGroundDot ? P.groundSnapSkin : P.skinWidth;
+                        float staticStop = smax(hit.s.toi - staticSkin, 0.0f);
+                        float agentStop = smax(hit.aToi, 0.0f);
+                        hit.isStatic = staticStop <= agentStop;
+                    } else {
+                        hit.isStatic = haveStatic;
+                    }
+                    F3 hitNormal = hit.isStatic ? hit.s.normal : hit.aNormal;
+                    bool hasCachedSide = false;
+                    F3 cachedSide{0, 0, 0};
+                    if (hit.isStatic && hit.s.normal.y < P.minGroundDot && C.sideContactFrames > 0)
+                        hasCachedSide = cachedNormal(C, hit.s.triIndex, cachedSide);
+                    bool shouldBreak = resolveHit(remaining, len, hit, P, C, wasGrounded, wasGroundedNear, velocity, position,
+                                                  hasCachedSide, cachedSide);
+                    if (hit.isStatic && hit.s.normal.y < P.minGroundDot) cacheRecord(C, hit.s.triIndex, hit.s.normal, true);
+                    if (haveLast) {
+                        float dotN = dot(lastSlideNormal, hitNormal);
+                        if (fabsf(dotN) < 0.98f) {
+                            F3 axis = cross(lastSlideNormal, hitNormal);
+                            float axisLen = length(axis);
+                            if (axisLen > 1e-5f) {
+                                F3 axisN = axis / axisLen;
+                                remaining = axisN * dot(remaining, axisN);
+                            }
+                        }
+                    }
+                    lastSlideNormal = hitNormal;
+                    haveLast = true;
+                    if (shouldBreak) break;
+                } else {
+                    position = position + remaining;
+                    remaining = F3{0, 0, 0};
+                    break;
+                }
+            }
+        }
+
+        // ---- resolveGroundContact :1767-1800: GroundProbe.resolve :826-943 ----
+        bool gGrounded = false, gNear = false, canSnap = false, nearGround = false, haveCenter = false;
+        F3 gNormal{0, 1, 0};
+        DevMaterial gMat{0.8f, 0.6f, 0};
+        int gTri = -1;
+        float gDistance = kFloatMax;
+        CastRec centerHit;
+        {
+            const F3 down{0, -1, 0};
+            const F3 snapDelta = down * P.snapDistance;
+            if (P.snapDistance > 0)
+                haveCenter = waveCapsuleCast(col, position, snapDelta, P.radius, P.halfHeight, false, true, P.minGroundDot,
+                                             P.collisionMask, centerHit, st);
+            if (P.fallProbeDistance > 0) {
+                CastRec fallHit;
+                if (waveCapsuleCast(col, position, down * P.fallProbeDistance, P.radius, P.halfHeight, false, true,
+                                    P.minGroundDot, P.collisionMask, fallHit, st))
+                    gDistance = fallHit.toi;
+            }
+            if (haveCenter && centerHit.toi <= P.snapDistance) {
+                const F3 prevNormal = ld3(C.groundNormal);
+                float baseCenterY = position.y - P.halfHeight;
+                float bottomY = baseCenterY - P.radius;
+                float groundTol = smax(P.skinWidth, P.groundSnapSkin);
+                bool validGroundPoint = centerHit.position.y <= bottomY + groundTol;
+                float groundNearThreshold = smax(P.groundSnapSkin, P.skinWidth);
+                nearGround = centerHit.toi <= groundNearThreshold;
+                gNear = nearGround;
+                gDistance = centerHit.toi;
+                bool groundGateVel = velocity.y <= 0;
+                double vInto = dot(velocity, toD(centerHit.normal));
+                bool groundGateSpeed = vInto >= -(double)P.groundSnapMaxSpeed;
+                bool groundGateToi = centerHit.toi <= P.groundSnapMaxToi;
+                canSnap = validGroundPoint && groundGateVel && (nearGround || groundGateSpeed || groundGateToi);
+                if (wasGroundedNear && centerHit.toi <= P.snapDistance) canSnap = validGroundPoint;
+                if (validGroundPoint && (nearGround || canSnap)) {
+                    gGrounded = true;
+                    gMat = col.materials[centerHit.triIndex];
+                    gTri = centerHit.triIndex;
+                    F3 normalSum = centerHit.triNormal;
+                    if (centerHit.triNormal.y < 0.98f && (wasGroundedNear || nearGround)) {
+                        float offset = P.radius * 0.6f;
+                        float combineTol = smax(smax(P.groundSnapSkin, P.skinWidth), 0.05f);
+                        for (int k = 0; k < 4; ++k) {
+                            float ox = k == 0 ? offset : (k == 1 ? -offset : 0.0f);
+                            float oz = k == 2 ? offset : (k == 3 ? -offset : 0.0f);
+                            F3 samplePos = position + F3{ox, 0, oz};
+                            CastRec sHit;
+                            if (waveCapsuleCast(col, samplePos, snapDelta, P.radius, P.halfHeight, false, true, P.minGroundDot,
+                                                P.collisionMask, sHit, st) &&
+                                sHit.toi <= centerHit.toi + combineTol) {
+                                if (dot(sHit.triNormal, centerHit.triNormal) > 0.98f) normalSum = normalSum + sHit.triNormal;
+                            }
+                        }
+                    }
+                    float nLen = length(normalSum);
+                    gNormal = nLen > 1e-6f ? normalSum / nLen : centerHit.triNormal;
+                }
+                if (gGrounded && wasGroundedNear) {
+                    float dotN = dot(prevNormal, gNormal);
+                    if (dotN > 0.9f) {
+                        const float blend = 0.2f;
+                        gNormal = normalize(prevNormal * (1 - blend) + gNormal * blend);
+                    }
+                }
+                if (gGrounded && gMat.flatten) gNormal = F3{0, 1, 0};
+            } else {
+                haveCenter = false; // guard failed: GroundProbeResult(hit: nil)
+            }
+        }
+        // GroundSnap.apply :945-963
+        if (canSnap && haveCenter) {
+            float rawMove = smax(centerHit.toi - P.groundSnapSkin, 0.0f);
+            float moveDist = rawMove;
+            if (nearGround && moveDist > P.groundSnapMaxStep) moveDist = P.groundSnapMaxStep;
+            position = position + F3{0, -1, 0} * moveDist;
+            D3 nD = toD(centerHit.normal);
+            double vIntoSnap = dot(velocity, nD);
+            if (vIntoSnap < 0) velocity = velocity - nD * vIntoSnap;
+        }
+        if (gGrounded) {
+            float normalUpDelta = gNormal.y - C.groundNormal[1];
+            if (gTri != C.groundTriangleIndex && normalUpDelta > 0.02f) C.groundTransitionFrames = 3;
+        }
+        // SlopeFriction.apply :965-1021
+        if (!gGrounded) {
+            C.flags &= ~(uint32_t)SGE_CTRL_GROUND_SLIDING;
+        } else {
+            F3 normal = normalize(gNormal);
+            if (normal.y > 0.98f) {
+                C.groundTransitionFrames = 0;
+                C.flags &= ~(uint32_t)SGE_CTRL_GROUND_SLIDING;
+            } else if (C.groundTransitionFrames > 0) {
+                C.groundTransitionFrames -= 1;
+                C.flags &= ~(uint32_t)SGE_CTRL_GROUND_SLIDING;
+            } else {
+                float gN = dot(gravity, normal);
+                F3 gTan = gravity - normal * gN;
+                float gTanLen = length(gTan);
+                if (gTanLen > 0.5f) {
+                    float gNMag = fabsf(gN);
+                    F3 gTanDir = gTan / gTanLen;
+                    D3 gTanDirD = toD(gTanDir), normalD = toD(normal);
+                    float stickLimit = gMat.muS * gNMag;
+                    bool enterSlide = gTanLen > stickLimit * 1.05f;
+                    bool exitSlide = gTanLen < stickLimit * 0.9f;
+                    bool sliding = (C.flags & SGE_CTRL_GROUND_SLIDING) != 0;
+                    if (sliding) { if (exitSlide) sliding = false; }
+                    else if (enterSlide) sliding = true;
+                    if (sliding) C.flags |= SGE_CTRL_GROUND_SLIDING; else C.flags &= ~(uint32_t)SGE_CTRL_GROUND_SLIDING;
+                    if (!sliding && gTanLen <= stickLimit) {
+                        D3 vTan = velocity - normalD * dot(velocity, normalD);
+                        double downhillSpeed = dot(vTan, gTanDirD);
+                        if (downhillSpeed > 0) velocity = velocity - gTanDirD * downhillSpeed;
+                    } else {
+                        float slideAccelMag = smax(gTanLen - gMat.muK * gNMag, 0.0f);
+                        if (slideAccelMag > 0) velocity = velocity + gTanDirD * (double)slideAccelMag * (double)dt;
+                    }
+                }
+            }
+        }
+        // writeBack :1802-1821
+        D3 pd = toD(position);
+        body.position[0] = pd.x; body.position[1] = pd.y; body.position[2] = pd.z;
+        C.flags &= ~(uint32_t)(SGE_CTRL_GROUNDED | SGE_CTRL_GROUNDED_NEAR);
+        if (gGrounded) C.flags |= SGE_CTRL_GROUNDED;
+        if (gNear) C.flags |= SGE_CTRL_GROUNDED_NEAR;
+        st3(C.groundNormal, gGrounded ? gNormal : F3{0, 1, 0});
+        C.groundDistance = gDistance;
+        if (gGrounded) C.groundTriangleIndex = gTri;
+    }
+
+    if (lane == 0) {
+        body.linearVelocity[0] = velocity.x; body.linearVelocity[1] = velocity.y; body.linearVelocity[2] = velocity.z;
+        K.crowd.bodies[e] = body;
+        K.crowd.controllers[e] = C;
+        if (K.stats) {
+            atomicAdd(&K.stats[0], (unsigned long long)st.queries);
+            atomicAdd(&K.stats[1], (unsigned long long)st.candidates);
+            atomicAdd(&K.stats[3], (unsigned long long)st.overflow);
+        }
+    }
+    if (K.stats) {
+        // evals are counted per lane; sum over the wave
+        unsigned v = st.evals;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+        if (lane == 0) atomicAdd(&K.stats[2], (unsigned long long)v);
+    }
+}
+
+void launch_move(const MoveLaunch& L, hipStream_t s) {
+    if (L.count <= 0) return;
+    hipLaunchKernelGGL(move_kernel, dim3(L.count), dim3(kWave), 0, s, L);
+}
+
+// ---- batched single queries (the CollisionQuery facade) ---------------------
+__global__ __launch_bounds__(kWave) void cast_query_kernel(DevCollision col, const sge_capsule_query* q, int n,
+                                                           sge_capsule_cast_hit* out, unsigned long long* stats) {
+    const int i = blockIdx.x;
+    WaveStats st{0, 0, 0, 0};
+    sge_capsule_query Q = q[i];
+    CastRec r;
+    bool got = waveCapsuleCast(col, F3{Q.from[0], Q.from[1], Q.from[2]}, F3{Q.delta[0], Q.delta[1], Q.delta[2]}, Q.radius,
+                               Q.halfHeight, Q.mode == SGE_CAST_BLOCKING, Q.mode == SGE_CAST_GROUND, Q.minNormalY, Q.mask, r, st);
+    if (laneId() == 0) {
+        sge_capsule_cast_hit h;
+        h.hit = got ? 1 : 0;
+        h.toi = got ? r.toi : 0;
+        F3 z{0, 0, 0};
+        F3 p = got ? r.position : z, nn = got ? r.normal : z, tn = got ? r.triNormal : z;
+        h.position[0] = p.x; h.position[1] = p.y; h.position[2] = p.z;
+        h.normal[0] = nn.x; h.normal[1] = nn.y; h.normal[2] = nn.z;
+        h.triangleNormal[0] = tn.x; h.triangleNormal[1] = tn.y; h.triangleNormal[2] = tn.z;
+        h.triangleIndex = got ? r.triIndex : -1;
+        DevMaterial m = got ? col.materials[r.triIndex] : DevMaterial{0, 0, 0};
+        h.material.muS = m.muS; h.material.muK = m.muK; h.material.flattenGround = m.flatten;
+        out[i] = h;
+        if (stats) {
+            atomicAdd(&stats[0], (unsigned long long)st.queries);
+            atomicAdd(&stats[1], (unsigned long long)st.candidates);
+            atomicAdd(&stats[3], (unsigned long long)st.overflow);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kWave) void overlap_query_kernel(DevCollision col, const sge_capsule_query* q, int n, int maxHits,
+                                                              sge_capsule_overlap_hit* out, int32_t* counts,
+                                                              unsigned long long* stats) {
+    const int i = blockIdx.x;
+    const int lane = laneId();
+    WaveStats st{0, 0, 0, 0};
+    sge_capsule_query Q = q[i];
+    int cnt = waveCapsuleOverlapAll(col, F3{Q.from[0], Q.from[1], Q.from[2]}, Q.radius, Q.halfHeight, maxHits, Q.mask, st);
+    if (lane < maxHits) {
+        sge_capsule_overlap_hit h;
+        if (lane < cnt) {
+            OverlapRec r = sh.ovl[lane];
+            h.depth = r.depth;
+            h.position[0] = r.position.x; h.position[1] = r.position.y; h.position[2] = r.position.z;
+            h.normal[0] = r.normal.x; h.normal[1] = r.normal.y; h.normal[2] = r.normal.z;
+            h.triangleNormal[0] = r.triNormal.x; h.triangleNormal[1] = r.triNormal.y; h.triangleNormal[2] = r.triNormal.z;
+            h.triangleIndex = r.triIndex;
+            DevMaterial m = col.materials[r.triIndex];
+            h.material.muS = m.muS; h.material.muK = m.muK; h.material.flattenGround = m.flatten;
+        } else {
+            h.depth = 0;
+            for (int k = 0; k < 3; ++k) { h.position[k] = 0; h.normal[k] = 0; h.triangleNormal[k] = 0; }
+            h.triangleIndex = -1;
+            h.material.muS = 0; h.material.muK = 0; h.material.flattenGround = 0;
+        }
+        out[(size_t)i * maxHits + lane] = h;
+    }
+    if (lane == 0) {
+        counts[i] = cnt;
+        if (stats) atomicAdd(&stats[3], (unsigned long long)st.overflow);
+    }
+}
+
+void launch_cast_queries(const DevCollision& col, const sge_capsule_query* d_q, int n, sge_capsule_cast_hit* d_out,
+                         unsigned long long* stats, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(cast_query_kernel, dim3(n), dim3(kWave), 0, s, col, d_q, n, d_out, stats);
+}
+void launch_overlap_queries(const DevCollision& col, const sge_capsule_query* d_q, int n, int maxHits,
+                            sge_capsule_overlap_hit* d_out, int32_t* d_counts, unsigned long long* stats, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(overlap_query_kernel, dim3(n), dim3(kWave), 0, s, col, d_q, n, maxHits, d_out, d_counts, stats);
+}
+
+// collectAgentStates (Systems.swift:1592-1611) as a device pack
+__global__ void agents_export_kernel(DevCrowd crowd, sge_agent_state* out) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= crowd.count) return;
+    const sge_controller_params& P = crowd.params[e];
+    const sge_body_state& b = crowd.bodies[e];
+    bool solid = (P.agentFlags & SGE_AGENT_PRESENT) && (P.agentFlags & SGE_AGENT_SOLID);
+    float radius = (P.agentFlags & SGE_AGENT_RADIUS_OVERRIDE) ? P.agentRadiusOverride : P.radius;
+    sge_agent_state a;
+    for (int k = 0; k < 3; ++k) { a.position[k] = (float)b.position[k]; a.velocity[k] = (float)b.linearVelocity[k]; }
+    a.radius = solid ? radius : -1.0f;
+    a.halfHeight = P.halfHeight;
+    out[e] = a;
+}
+void launch_agents_export(const DevCrowd& crowd, sge_agent_state* d_out, hipStream_t s) {
+    if (crowd.count <= 0) return;
+    hipLaunchKernelGGL(agents_export_kernel, dim3((crowd.count + 255) / 256), dim3(256), 0, s, crowd, d_out);
+}
+
+} // namespace sge

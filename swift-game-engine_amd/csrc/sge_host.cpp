@@ -1,0 +1,261 @@
+// Host-side (CPU) parts of libsge_amd.so that run once at load / rebuild time:
+//   sge_skeleton_build          SkeletonLoader.buildSkeleton  (Game/SkeletonLoader.swift:28-87)
+//                               + Skeleton.init invBindModel  (Game/Skeleton.swift:153-156)
+//   sge_mesh_tangents_compute   MeshTangents.compute          (Game/MeshTangents.swift:10-83)
+//   HostCollision::rebuild      TriangleMeshSet.rebuild       (Game/CollisionQuery.swift:331-417)
+//                               + BVH.build                   (Game/CollisionQuery.swift:577-706)
+// The BVH must reproduce the reference's triOrder exactly: first-hit selection
+// and capsuleOverlapAll's "first maxHits" depend on the order in which its
+// right-child-first traversal reaches triangles; that order is flattened here
+// into a per-triangle visit rank the kernels use as a tie-breaker.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include "sge_internal.hpp"
+
+namespace sge {
+
+struct M4 { float m[16]; }; // column-major
+
+static M4 m4FromAff(const Aff& a) {
+    M4 r;
+    const F3 c[4] = {a.c0, a.c1, a.c2, a.c3};
+    for (int j = 0; j < 4; ++j) {
+        r.m[j * 4 + 0] = c[j].x; r.m[j * 4 + 1] = c[j].y; r.m[j * 4 + 2] = c[j].z; r.m[j * 4 + 3] = j == 3 ? 1.0f : 0.0f;
+    }
+    return r;
+}
+
+// simd_inverse(float4x4) restated as adjugate / determinant.
+static M4 m4Inverse(const M4& in) {
+    const float* m = in.m;
+    float inv[16];
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    float id = 1.0f / det;
+    M4 r;
+    for (int i = 0; i < 16; ++i) r.m[i] = inv[i] * id;
+    return r;
+}
+
+// ---- collision world ----------------------------------------------------- //
+
+static inline float axisOf(const float* v, int axis) { return v[axis]; }
+
+struct Builder {
+    HostCollision& hc;
+    const float* aabb(int t) const { return &hc.aabbs[(size_t)t * 6]; }
+    void centroid(int t, float c[3]) const { // (min + max) * 0.5
+        const float* b = aabb(t);
+        for (int k = 0; k < 3; ++k) c[k] = (b[k] + b[3 + k]) * 0.5f;
+    }
+    void rangeBounds(int start, int count, float mn[3], float mx[3]) const {
+        const float* f = aabb(hc.triOrder[start]);
+        for (int k = 0; k < 3; ++k) { mn[k] = f[k]; mx[k] = f[3 + k]; }
+        for (int i = 1; i < count; ++i) {
+            const float* b = aabb(hc.triOrder[start + i]);
+            for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], b[k]); mx[k] = fmaxf(mx[k], b[3 + k]); }
+        }
+    }
+    int build(int start, int count, int parent, int depth) {
+        int nodeIndex = (int)hc.nodes.size();
+        HostBVHNode n;
+        rangeBounds(start, count, n.mn, n.mx);
+        n.left = n.right = -1; n.start = start; n.count = count; n.parent = parent;
+        hc.nodes.push_back(n);
+        hc.maxDepth = std::max(hc.maxDepth, depth);
+        if (count <= 4) { // StaticTriMesh.leafTriangleLimit
+            for (int i = 0; i < count; ++i) hc.triLeaf[hc.triOrder[start + i]] = nodeIndex;
+            return nodeIndex;
+        }
+        float cmn[3], cmx[3], c[3];
+        centroid(hc.triOrder[start], c);
+        for (int k = 0; k < 3; ++k) cmn[k] = cmx[k] = c[k];
+        for (int i = 1; i < count; ++i) {
+            centroid(hc.triOrder[start + i], c);
+            for (int k = 0; k < 3; ++k) { cmn[k] = fminf(cmn[k], c[k]); cmx[k] = fmaxf(cmx[k], c[k]); }
+        }
+        float ex = cmx[0] - cmn[0], ey = cmx[1] - cmn[1], ez = cmx[2] - cmn[2];
+        int axis = (ex >= ey && ex >= ez) ? 0 : (ey >= ez ? 1 : 2);
+        float pivot = (cmn[axis] + cmx[axis]) * 0.5f;
+        int i = start, j = start + count - 1;
+        while (i <= j) {
+            centroid(hc.triOrder[i], c);
+            if (c[axis] < pivot) {
+                ++i;
+            } else {
+                std::swap(hc.triOrder[i], hc.triOrder[j]);
+                --j;
+            }
+        }
+        int end = start + count;
+        if (i == start || i == end) {
+            // Swift's sort is stable (merge sort since Swift 5).
+            std::stable_sort(hc.triOrder.begin() + start, hc.triOrder.begin() + end, [&](int a, int b) {
+                float ca[3], cb[3];
+                centroid(a, ca); centroid(b, cb);
+                return ca[axis] < cb[axis];
+            });
+            i = start + count / 2;
+        }
+        int mid = i;
+        int left = build(start, mid - start, nodeIndex, depth + 1);
+        int right = build(mid, end - mid, nodeIndex, depth + 1);
+        HostBVHNode& me = hc.nodes[nodeIndex];
+        me.left = left; me.right = right; me.start = 0; me.count = 0;
+        for (int k = 0; k < 3; ++k) {
+            me.mn[k] = fminf(hc.nodes[left].mn[k], hc.nodes[right].mn[k]);
+            me.mx[k] = fmaxf(hc.nodes[left].mx[k], hc.nodes[right].mx[k]);
+        }
+        return nodeIndex;
+    }
+};
+
+void HostCollision::rebuild(const sge_static_mesh_entity* ents, int count) {
+    positions.clear(); indices.clear(); aabbs.clear(); materials.clear(); layers.clear();
+    nodes.clear(); triOrder.clear(); triLeaf.clear(); rank.clear();
+    root = -1; maxDepth = 0;
+    const float areaEps = 1e-10f;
+    for (int e = 0; e < count; ++e) {
+        const sge_static_mesh_entity& m = ents[e];
+        const float* M = m.modelMatrix;
+        uint32_t baseVertex = (uint32_t)(positions.size() / 3);
+        for (int v = 0; v < m.vertexCount; ++v) {
+            float x = m.positions[v * 3], y = m.positions[v * 3 + 1], z = m.positions[v * 3 + 2];
+            for (int r = 0; r < 3; ++r) // simd_mul(modelMatrix, (p,1)).xyz
+                positions.push_back(((M[r] * x + M[4 + r] * y) + M[8 + r] * z) + M[12 + r] * 1.0f);
+        }
+        int triCount = m.indexCount / 3;
+        bool perTri = m.triangleMaterials && m.triangleMaterialCount == triCount;
+        int t = 0, triLocal = 0;
+        while (t + 2 < m.indexCount) {
+            uint32_t i0 = baseVertex + m.indices[t], i1 = baseVertex + m.indices[t + 1], i2 = baseVertex + m.indices[t + 2];
+            F3 p0{positions[i0 * 3], positions[i0 * 3 + 1], positions[i0 * 3 + 2]};
+            F3 p1{positions[i1 * 3], positions[i1 * 3 + 1], positions[i1 * 3 + 2]};
+            F3 p2{positions[i2 * 3], positions[i2 * 3 + 1], positions[i2 * 3 + 2]};
+            if (lengthSq(cross(p1 - p0, p2 - p0)) <= areaEps) { t += 3; ++triLocal; continue; }
+            indices.push_back(i0); indices.push_back(i1); indices.push_back(i2);
+            F3 mn = vmin(p0, vmin(p1, p2)), mx = vmax(p0, vmax(p1, p2));
+            const float bb[6] = {mn.x, mn.y, mn.z, mx.x, mx.y, mx.z};
+            aabbs.insert(aabbs.end(), bb, bb + 6);
+            materials.push_back(perTri ? m.triangleMaterials[triLocal] : m.material);
+            layers.push_back(m.collisionLayer);
+            t += 3; ++triLocal;
+        }
+    }
+    int T = (int)layers.size();
+    triOrder.resize(T);
+    for (int i = 0; i < T; ++i) triOrder[i] = i;
+    triLeaf.assign(T, -1);
+    rank.assign(T, -1);
+    if (T == 0) return;
+    nodes.reserve((size_t)T);
+    Builder b{*this};
+    root = b.build(0, T, -1, 0);
+    // visit rank: CollisionQuery's DFS pushes left then right and pops the last (CollisionQuery.swift:1106-1108)
+    std::vector<int> stack{root};
+    int counter = 0;
+    while (!stack.empty()) {
+        int ni = stack.back(); stack.pop_back();
+        const HostBVHNode& n = nodes[ni];
+        if (n.left < 0) {
+            for (int i = n.start; i < n.start + n.count; ++i) rank[triOrder[i]] = counter++;
+        } else {
+            stack.push_back(n.left);
+            stack.push_back(n.right);
+        }
+    }
+}
+
+} // namespace sge
+
+using namespace sge;
+
+extern "C" {
+
+int sge_skeleton_build(int32_t boneCount, const int32_t* parent, const float* rawTranslations,
+                       const float* preRotationDegrees, const float rootFixDegrees[3], float unitScale, int zeroRoot,
+                       float* restTranslation, float* bindLocal, float* invBindModel, float* rootRotationFix) {
+    if (boneCount <= 0 || boneCount > SGE_MAX_BONES || !parent || !rawTranslations || !preRotationDegrees ||
+        !rootFixDegrees || !restTranslation || !bindLocal || !invBindModel || !rootRotationFix) {
+        set_error("sge_skeleton_build: bad argument");
+        return SGE_ERR_INVALID;
+    }
+    Aff rootFix = rotationXYZDegrees(F3{rootFixDegrees[0], rootFixDegrees[1], rootFixDegrees[2]});
+    std::vector<Aff> local(boneCount), model(boneCount);
+    for (int i = 0; i < boneCount; ++i) {
+        if (parent[i] >= i) { set_error("sge_skeleton_build: parent index must precede child"); return SGE_ERR_INVALID; }
+        F3 raw = (zeroRoot && i == 0) ? F3{0, 0, 0} : F3{rawTranslations[i * 3], rawTranslations[i * 3 + 1], rawTranslations[i * 3 + 2]};
+        F3 t = raw * unitScale;
+        restTranslation[i * 3] = t.x; restTranslation[i * 3 + 1] = t.y; restTranslation[i * 3 + 2] = t.z;
+        Aff rot = affMul(rotationXYZDegrees(F3{preRotationDegrees[i * 3], preRotationDegrees[i * 3 + 1], preRotationDegrees[i * 3 + 2]}),
+                         rotationXYZDegrees(F3{0, 0, 0}));
+        if (i == 0) rot = affMul(rootFix, rot);
+        Aff tr = affIdentity();
+        tr.c3 = t;
+        local[i] = affMul(tr, rot); // simd_mul(trans, rot)
+        model[i] = parent[i] < 0 ? local[i] : affMul(model[parent[i]], local[i]);
+    }
+    for (int i = 0; i < boneCount; ++i) {
+        M4 l = m4FromAff(local[i]);
+        M4 inv = m4Inverse(m4FromAff(model[i]));
+        std::memcpy(bindLocal + i * 16, l.m, 64);
+        std::memcpy(invBindModel + i * 16, inv.m, 64);
+    }
+    M4 rf = m4FromAff(rootFix);
+    std::memcpy(rootRotationFix, rf.m, 64);
+    return SGE_OK;
+}
+
+int sge_mesh_tangents_compute(int32_t vCount, const float* positions, const float* normals, const float* uvs,
+                              const uint16_t* indices16, const uint32_t* indices32, int32_t indexCount, float* tangents) {
+    if (vCount < 0 || !positions || !normals || !uvs || !tangents || (indices16 && indices32)) {
+        set_error("sge_mesh_tangents_compute: bad argument");
+        return SGE_ERR_INVALID;
+    }
+    std::vector<F3> tan1(vCount, F3{0, 0, 0}), tan2(vCount, F3{0, 0, 0});
+    auto P = [&](int i) { return F3{positions[i * 3], positions[i * 3 + 1], positions[i * 3 + 2]}; };
+    for (int idx = 0; idx + 2 < indexCount; idx += 3) {
+        int i0, i1, i2;
+        if (indices16) { i0 = indices16[idx]; i1 = indices16[idx + 1]; i2 = indices16[idx + 2]; }
+        else if (indices32) { i0 = (int)indices32[idx]; i1 = (int)indices32[idx + 1]; i2 = (int)indices32[idx + 2]; }
+        else break;
+        F3 dp1 = P(i1) - P(i0), dp2 = P(i2) - P(i0);
+        float d1x = uvs[i1 * 2] - uvs[i0 * 2], d1y = uvs[i1 * 2 + 1] - uvs[i0 * 2 + 1];
+        float d2x = uvs[i2 * 2] - uvs[i0 * 2], d2y = uvs[i2 * 2 + 1] - uvs[i0 * 2 + 1];
+        float denom = d1x * d2y - d1y * d2x;
+        if (fabsf(denom) < 1e-6f) continue;
+        float r = 1.0f / denom;
+        F3 t = (dp1 * d2y - dp2 * d1y) * r;
+        F3 b = (dp2 * d1x - dp1 * d2x) * r;
+        tan1[i0] = tan1[i0] + t; tan1[i1] = tan1[i1] + t; tan1[i2] = tan1[i2] + t;
+        tan2[i0] = tan2[i0] + b; tan2[i1] = tan2[i1] + b; tan2[i2] = tan2[i2] + b;
+    }
+    for (int i = 0; i < vCount; ++i) {
+        F3 n = normalize(F3{normals[i * 3], normals[i * 3 + 1], normals[i * 3 + 2]});
+        F3 t = tan1[i];
+        float* o = tangents + i * 4;
+        if (lengthSq(t) < 1e-8f) { o[0] = 1; o[1] = 0; o[2] = 0; o[3] = 1; continue; }
+        t = normalize(t - n * dot(n, t));
+        float w = dot(cross(n, t), tan2[i]) < 0.0f ? -1.0f : 1.0f;
+        o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = w;
+    }
+    return SGE_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,156 @@
+// Internal declarations of libsge_amd.so (context, device layouts, launchers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "../../include/sge_amd.h"
+#include "sge_math.hpp"
+
+namespace sge {
+
+static_assert(sizeof(sge_body_state) == 96, "layout");
+static_assert(sizeof(sge_controller_params) == 64, "layout");
+static_assert(sizeof(sge_controller_state) == 128, "layout");
+static_assert(sizeof(sge_move_intent) == 32, "layout");
+static_assert(sizeof(sge_locomotion_state) == 96, "layout");
+static_assert(sizeof(sge_action_state) == 32, "layout");
+static_assert(sizeof(sge_agent_state) == 32, "layout");
+static_assert(sizeof(sge_capsule_query) == 44, "layout");
+static_assert(sizeof(sge_capsule_cast_hit) == 60, "layout");
+static_assert(sizeof(sge_capsule_overlap_hit) == 56, "layout");
+static_assert(sizeof(sge_bvh_node) == 44, "layout");
+static_assert(sizeof(sge_tick_desc) == 32, "layout");
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+#define SGE_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return ::sge::hip_fail(_e, #expr); } while (0)
+
+// ---- device-side layouts ------------------------------------------------- //
+
+// BVH node as the kernels read it (32 B). Interior: a = left, b = right (>= 0).
+// Leaf: a = ~firstSlot (< 0), b = triangle count (1..4).
+struct DevNode { float mnx, mny, mnz, mxx, mxy, mxz; int32_t a, b; };
+static_assert(sizeof(DevNode) == 32, "layout");
+
+// One collision triangle in triOrder ("slot") order (48 B): world-space vertices,
+// collision layer, the reference's triangle index and its DFS visit rank (the
+// position at which CollisionQuery's right-child-first traversal reaches it).
+struct DevTri { float v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z; uint32_t layer; int32_t triIndex; int32_t rank; };
+static_assert(sizeof(DevTri) == 48, "layout");
+
+struct DevMaterial { float muS, muK; uint32_t flatten; };
+
+// Skeleton constants in device memory (SoA over bones).
+struct DevSkeleton {
+    int boneCount;
+    int pelvisIndex, leanIndex, leanParent;
+    int maxDepth;          // deepest hierarchy level
+    int leanChainLen;      // ancestors of leanIndex, root first, leanIndex last
+    float unitScale;
+    const int32_t* parent;      // [B]
+    const int32_t* depth;       // [B]
+    const int32_t* leanChain;   // [leanChainLen]
+    const float* bindLocal;     // [B][12] affine by column
+    const float* invBind;       // [B][16] full 4x4 used for the palette (mesh re-bind applied at upload)
+    const float* restT;         // [B][3]
+    const float* rawRestT;      // [B][3]
+    const float* preRot;        // [B][12] rotationXYZDegrees(preRotationDegrees[i]) (c3 = 0), bone 0 NOT yet rootFix'ed
+    float rootFix[12];          // rotation part of rootRotationFix
+};
+
+struct DevProfiles {
+    int count;
+    int stride;                 // floats per (bone,axis) = max coefficient count over everything uploaded
+    int32_t order[SGE_MAX_PROFILES];
+    float cycleRaw[SGE_MAX_PROFILES];
+    const float* coeffs;        // [P][B][6][stride]
+    const uint8_t* coeffCount;  // [P][B][6]
+    const uint8_t* bonePresent; // [P][B]
+};
+
+struct DevCollision {
+    int nodeCount, triCount, root;
+    const DevNode* nodes;
+    const DevTri* tris;             // slot order
+    const DevMaterial* materials;   // by triIndex
+};
+
+struct DevCrowd {
+    int count;
+    sge_body_state* bodies;
+    sge_controller_params* params;
+    sge_controller_state* controllers;
+    sge_move_intent* intents;
+    sge_locomotion_state* locomotion;
+    sge_action_state* actions;
+    float* palettes;   // [N][B][16]
+    float* poseModel;  // [N][B][16] (debug) or null
+    float* poseLocal;  // [N][B][16] (debug) or null
+};
+
+struct DevMesh {
+    int vertexCount;
+    const float* positions;       // [V][3]
+    const float* normals;         // [V][3]
+    const float* tangents;        // [V][4]
+    const uint16_t* boneIndices;  // [V][4]
+    const float* boneWeights;     // [V][4]
+};
+
+struct DevAgents {
+    const sge_agent_state* all; // gathered snapshot
+    int total, selfOffset;
+    // uniform XZ grid over the snapshot
+    const int32_t* cellStart;   // [cells+1]
+    const int32_t* cellItems;   // [total] agent indices sorted by cell
+    float originX, originZ, invCell;
+    int nx, nz;
+    float maxRadius, maxSpeed;  // over the solid agents of the snapshot (bounds the XZ reach of a sweep)
+};
+
+// ---- host-side collision build (sge_host.cpp) ---------------------------- //
+struct HostBVHNode { float mn[3], mx[3]; int left, right, start, count, parent; };
+struct HostCollision {
+    std::vector<float> positions;   // xyz
+    std::vector<uint32_t> indices;
+    std::vector<float> aabbs;       // [T][6] min xyz max xyz
+    std::vector<sge_surface_material> materials;
+    std::vector<uint32_t> layers;
+    std::vector<HostBVHNode> nodes;
+    std::vector<int> triOrder, triLeaf, rank; // rank[tri]
+    int root = -1;
+    int maxDepth = 0;
+    void rebuild(const sge_static_mesh_entity* ents, int count);
+};
+
+// ---- kernel launchers ----------------------------------------------------- //
+struct MoveLaunch {
+    DevCrowd crowd; DevCollision col; DevAgents agents;
+    float dt; float gx, gy, gz; uint32_t stages; int first, count;
+    unsigned long long* stats; // [4]
+};
+void launch_move(const MoveLaunch& L, hipStream_t s);
+void launch_cast_queries(const DevCollision& col, const sge_capsule_query* d_q, int n, sge_capsule_cast_hit* d_out,
+                         unsigned long long* stats, hipStream_t s);
+void launch_overlap_queries(const DevCollision& col, const sge_capsule_query* d_q, int n, int maxHits,
+                            sge_capsule_overlap_hit* d_out, int32_t* d_counts, unsigned long long* stats, hipStream_t s);
+
+struct PoseLaunch {
+    DevCrowd crowd; DevSkeleton sk; DevProfiles prof;
+    float dt; uint32_t stages; int first, count;
+};
+void launch_pose(const PoseLaunch& L, hipStream_t s);
+
+struct SkinLaunch {
+    const void* srcPos; const void* srcNrm; const void* srcTan; const void* srcIdx; const void* srcWgt;
+    const float* palettes;      // [chars][paletteCount][16]
+    int paletteCount, vertexCount, chars;
+    long long dstBaseVertex;    // of the first character; character c writes at dstBaseVertex + c*vertexCount
+    int srcLayout, dstLayout;
+    void* outPos; void* outNrm; void* outTan;
+};
+void launch_skin(const SkinLaunch& L, hipStream_t s);
+
+void launch_agents_export(const DevCrowd& crowd, sge_agent_state* d_out, hipStream_t s);
+
+} // namespace sge

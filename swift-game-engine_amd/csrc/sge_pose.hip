@@ -1,0 +1,427 @@
+// Pose evaluation + bone palette for gfx950 — replaces, per fixed step,
+//   LocomotionProfileSystem.fixedUpdate   Game/Systems.swift:279-407
+//   ActionAnimationSystem.fixedUpdate     Game/Systems.swift:475-517
+//   PoseStackSystem.fixedUpdate           Game/ProceduralPoseSystem.swift:13-406
+//   the palette re-bind of RenderExtract  Game/Systems.swift:2519-2527 (folded into invBind at upload)
+//   PhysicsWritebackSystem (rotation)     Game/Systems.swift:2259-2265
+//
+// Mapping: one wavefront (64 lanes) per character, lane = bone (bones 64.. take
+// a second pass).  The reference's per-bone String-keyed dictionary lookups become
+// a dense [profile][bone][axis][k] coefficient table; the Fourier harmonics
+// cos/sin(2*pi*k*p) depend only on the phase, so they are evaluated once per
+// character and profile instead of once per axis.  The parent-before-child model
+// product runs level by level through LDS (12 levels for the Y-Bot).  Scalar
+// per-character state (clocks, blend weights) is computed redundantly by all lanes
+// and written back by lane 0.
+//
+// Compiled with -ffp-contract=off: same operation order as the float32 oracle.
+#include "sge_internal.hpp"
+
+namespace sge {
+
+constexpr int kWave = 64;
+
+struct Harmonics { float c[SGE_MAX_FOURIER_ORDER], s[SGE_MAX_FOURIER_ORDER]; };
+
+// Animation.swift:68,73 — p = clamp(phase), angle = 2 * Float.pi * Float(k) * p
+__device__ __forceinline__ void harmonics(float phase, int order, Harmonics& h) {
+    float p = smax(0.0f, smin(phase, 1.0f));
+#pragma unroll
+    for (int k = 1; k <= SGE_MAX_FOURIER_ORDER; ++k) {
+        if (k <= order) {
+            float angle = 2 * kSwiftPi * (float)k * p;
+            h.c[k - 1] = cosf(angle);
+            h.s[k - 1] = sinf(angle);
+        } else {
+            h.c[k - 1] = 0.f; h.s[k - 1] = 0.f;
+        }
+    }
+}
+
+// Animation.swift:66-78
+__device__ __forceinline__ float evalAxis(const float* coeffs, int cnt, int order, const Harmonics& h) {
+    if (cnt <= 0) return 0.0f;
+    float result = coeffs[0];
+    int index = 1;
+#pragma unroll
+    for (int k = 1; k <= SGE_MAX_FOURIER_ORDER; ++k) {
+        if (k > order || index + 1 >= cnt) break;
+        result += coeffs[index] * h.c[k - 1] + coeffs[index + 1] * h.s[k - 1];
+        index += 2;
+    }
+    return result;
+}
+
+struct BoneEval { F3 t; Aff rot; bool present; };
+
+__device__ __forceinline__ Aff loadAff12(const float* p) {
+    return Aff{{p[0], p[1], p[2]}, {p[3], p[4], p[5]}, {p[6], p[7], p[8]}, {p[9], p[10], p[11]}};
+}
+__device__ __forceinline__ void storeAff12(float* p, const Aff& a) {
+    p[0] = a.c0.x; p[1] = a.c0.y; p[2] = a.c0.z; p[3] = a.c1.x; p[4] = a.c1.y; p[5] = a.c1.z;
+    p[6] = a.c2.x; p[7] = a.c2.y; p[8] = a.c2.z; p[9] = a.c3.x; p[10] = a.c3.y; p[11] = a.c3.z;
+}
+
+// translation + rotation of bone i under one profile (ProceduralPoseSystem.swift:146-200 / 249-271)
+__device__ __forceinline__ BoneEval evalBone(const DevSkeleton& sk, const DevProfiles& pf, int prof, int i,
+                                             const Harmonics& h, bool inPlace, const Aff& rootFix) {
+    BoneEval r;
+    const int B = sk.boneCount;
+    F3 restScaled{sk.restT[i * 3], sk.restT[i * 3 + 1], sk.restT[i * 3 + 2]};
+    F3 restRaw{sk.rawRestT[i * 3], sk.rawRestT[i * 3 + 1], sk.rawRestT[i * 3 + 2]};
+    r.present = pf.bonePresent[prof * B + i] != 0;
+    const int order = pf.order[prof];
+    float raw[3] = {restRaw.x, restRaw.y, restRaw.z};
+    float deg[3] = {0.f, 0.f, 0.f};
+    if (r.present) {
+        const uint8_t* cc = pf.coeffCount + ((size_t)prof * B + i) * 6;
+        const float* co = pf.coeffs + ((size_t)prof * B + i) * 6 * pf.stride;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            int cnt = cc[a];
+            if (cnt != SGE_AXIS_ABSENT) raw[a] = evalAxis(co + a * pf.stride, cnt, order, h);
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            int cnt = cc[3 + a];
+            if (cnt != SGE_AXIS_ABSENT) deg[a] = evalAxis(co + (3 + a) * pf.stride, cnt, order, h);
+        }
+    }
+    F3 delta = F3{raw[0], raw[1], raw[2]} - restRaw;
+    F3 t = restScaled + (delta * sk.unitScale);
+    if (i == 0 && inPlace) { t.x = restScaled.x; t.z = restScaled.z; }
+    Aff rot = affMul(loadAff12(sk.preRot + i * 12), rotationXYZDegrees(F3{deg[0], deg[1], deg[2]}));
+    if (i == 0) rot = affMul(rootFix, rot);
+    r.t = t;
+    r.rot = rot;
+    return r;
+}
+
+__device__ __forceinline__ float cycleOf(const DevProfiles& pf, int p) { return smax(pf.cycleRaw[p], 0.001f); }
+
+// Systems.swift:297-324
+__device__ __forceinline__ int groundedNextState(int current, float speed, const sge_locomotion_state& L) {
+    int g = current == SGE_LOCO_FALLING ? SGE_LOCO_IDLE : current;
+    if (g == SGE_LOCO_IDLE) {
+        if (speed >= L.runEnterSpeed) return SGE_LOCO_RUN;
+        if (speed >= L.idleExitSpeed) return SGE_LOCO_WALK;
+        return SGE_LOCO_IDLE;
+    }
+    if (g == SGE_LOCO_WALK) {
+        if (speed >= L.runEnterSpeed) return SGE_LOCO_RUN;
+        if (speed < L.idleEnterSpeed) return SGE_LOCO_IDLE;
+        return SGE_LOCO_WALK;
+    }
+    if (g == SGE_LOCO_RUN) {
+        if (speed < L.runExitSpeed) return speed < L.idleEnterSpeed ? SGE_LOCO_IDLE : SGE_LOCO_WALK;
+        return SGE_LOCO_RUN;
+    }
+    return SGE_LOCO_FALLING;
+}
+
+__global__ __launch_bounds__(kWave) void pose_kernel(PoseLaunch K) {
+    __shared__ float sLocal[SGE_MAX_BONES * 12];
+    __shared__ float sModel[SGE_MAX_BONES * 12];
+    const int e = K.first + blockIdx.x;
+    const int lane = threadIdx.x;
+    const DevSkeleton& sk = K.sk;
+    const DevProfiles& pf = K.prof;
+    const int B = sk.boneCount;
+    const float dt = K.dt;
+
+    sge_locomotion_state L = K.crowd.locomotion[e];
+    sge_action_state A = K.crowd.actions[e];
+    const sge_body_state& body = K.crowd.bodies[e];
+    const sge_controller_state& C = K.crowd.controllers[e];
+    const uint32_t ctrlFlags = C.flags;
+    const bool hasLoco = (L.flags & SGE_LOCO_PRESENT) != 0;
+    const bool hasMotion = (L.flags & SGE_MOTION_PRESENT) != 0;
+
+    // ---- LocomotionProfileSystem (Systems.swift:326-406) ----
+    if ((K.stages & SGE_STAGE_LOCOMOTION) && hasLoco && hasMotion) {
+        D3 hv{body.linearVelocity[0], 0.0, body.linearVelocity[2]};
+        float speed = (float)length(hv);
+        bool isAirborne = !(ctrlFlags & SGE_CTRL_GROUNDED_NEAR);
+        int nextState;
+        if (isAirborne) {
+            bool highFall = C.groundDistance >= L.fallMinDropHeight;
+            if (L.state == SGE_LOCO_FALLING || highFall) nextState = SGE_LOCO_FALLING;
+            else nextState = groundedNextState(L.state, speed, L);
+        } else {
+            nextState = groundedNextState(L.state, speed, L);
+        }
+        if (nextState != L.state) {
+            int fromState = L.state;
+            float fromCycle = cycleOf(pf, L.profile[fromState]);
+            float fromPhase = smax(0.0f, smin(L.time[fromState] / fromCycle, 1.0f));
+            float toCycle = cycleOf(pf, L.profile[nextState]);
+            L.time[nextState] = fromPhase * toCycle;
+            L.fromState = L.state;
+            L.state = nextState;
+            L.flags |= SGE_LOCO_IS_BLENDING;
+            L.blendT = 0;
+            if (nextState == SGE_LOCO_IDLE) L.idleInertia = 1.0f;
+        }
+        L.motionTime = L.time[L.state];
+    }
+
+    // ---- ActionAnimationSystem (Systems.swift:482-516) ----
+    if ((K.stages & SGE_STAGE_ACTION) && dt > 0 && (A.flags & SGE_ACTION_PRESENT) && (A.flags & SGE_ACTION_ACTIVE)) {
+        float cycle = cycleOf(pf, A.profile);
+        float capTime = cycle;
+        if (A.flags & SGE_ACTION_HAS_DODGE) capTime = smax(smin(A.dodgeEnd, cycle), 0.001f);
+        bool exiting = (A.flags & SGE_ACTION_EXITING) != 0;
+        if (!exiting) {
+            A.time += dt * A.playbackRate;
+            if (A.flags & SGE_ACTION_LOOP) {
+                A.time = fmodf(A.time, capTime);
+            } else if (A.time >= capTime) {
+                A.time = capTime;
+                exiting = true;
+            }
+        }
+        bool active = true;
+        if (exiting) {
+            float halfLife = smax(A.blendOutHalfLife, 0.001f);
+            float decay = powf(0.5f, dt / halfLife);
+            A.weight *= decay;
+            if (A.weight <= 0.001f) { A.weight = 0; active = false; exiting = false; }
+        } else {
+            float blendIn = smax(A.blendInTime, 0.001f);
+            A.weight = smin(A.weight + dt / blendIn, 1.0f);
+        }
+        A.flags &= ~(uint32_t)(SGE_ACTION_ACTIVE | SGE_ACTION_EXITING);
+        if (active) A.flags |= SGE_ACTION_ACTIVE;
+        if (exiting) A.flags |= SGE_ACTION_EXITING;
+    }
+
+    if (K.stages & SGE_STAGE_POSE) {
+        const bool loop = (L.flags & SGE_MOTION_LOOP) != 0;
+        const bool inPlace = (L.flags & SGE_MOTION_IN_PLACE) != 0;
+        const Aff rootFix = loadAff12(sk.rootFix);
+        float runLeanWeight = 0;
+
+        if (hasLoco && hasMotion) { // ProceduralPoseSystem.swift:36-223
+            float cyc[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) cyc[s] = cycleOf(pf, L.profile[s]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                L.time[s] += dt * L.playbackRate;
+                L.time[s] = loop ? fmodf(L.time[s], cyc[s]) : smin(L.time[s], cyc[s]);
+            }
+            bool isBlending = (L.flags & SGE_LOCO_IS_BLENDING) != 0;
+            if (isBlending) {
+                if (L.state == SGE_LOCO_IDLE) {
+                    float halfLife = smax(L.idleInertiaHalfLife, 0.001f);
+                    float decay = powf(0.5f, dt / halfLife);
+                    L.idleInertia *= decay;
+                    if (L.idleInertia <= 0.001f) { L.idleInertia = 0; L.blendT = 1.0f; isBlending = false; }
+                } else {
+                    float blendDuration = smax(L.blendTime, 0.001f);
+                    L.blendT = smin(L.blendT + dt / blendDuration, 1.0f);
+                    if (L.blendT >= 1.0f) isBlending = false;
+                }
+            }
+            if (isBlending) L.flags |= SGE_LOCO_IS_BLENDING; else L.flags &= ~(uint32_t)SGE_LOCO_IS_BLENDING;
+            float phase4[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) phase4[s] = smax(0.0f, smin(L.time[s] / cyc[s], 1.0f));
+            L.posePhase = phase4[L.state & 3];
+
+            const int fromState = (isBlending ? L.fromState : L.state) & 3;
+            const int toState = L.state & 3;
+            float weightTo = 1.0f;
+            if (isBlending) {
+                if (L.state == SGE_LOCO_IDLE) {
+                    float inertia = smax(0.0f, smin(L.idleInertia, 1.0f));
+                    weightTo = 1.0f - inertia;
+                } else {
+                    float t = smax(0.0f, smin(L.blendT, 1.0f));
+                    weightTo = t * t * t * (t * (t * 6 - 15) + 10);
+                }
+            }
+            float runWeight;
+            if (isBlending) {
+                if (L.state == SGE_LOCO_RUN) runWeight = weightTo;
+                else if (L.fromState == SGE_LOCO_RUN) runWeight = 1.0f - weightTo;
+                else runWeight = 0.0f;
+            } else {
+                runWeight = L.state == SGE_LOCO_RUN ? 1.0f : 0.0f;
+            }
+            runLeanWeight = runWeight;
+
+            const int fromProf = L.profile[fromState], toProf = L.profile[toState];
+            Harmonics hTo, hFrom;
+            harmonics(phase4[toState], pf.order[toProf], hTo);
+            const bool sameEval = fromState == toState;
+            if (!sameEval) harmonics(phase4[fromState], pf.order[fromProf], hFrom);
+            for (int i = lane; i < B; i += kWave) {
+                BoneEval to = evalBone(sk, pf, toProf, i, hTo, inPlace, rootFix);
+                BoneEval from = sameEval ? to : evalBone(sk, pf, fromProf, i, hFrom, inPlace, rootFix);
+                F3 t = from.t + (to.t - from.t) * weightTo;
+                Quat fromQuat = quatFromRotation(from.rot);
+                Quat toQuat = quatFromRotation(to.rot);
+                Quat rotQuat;
+                if (i == 0 && isBlending) { // yaw-stable root, :206-215
+                    float yaw = atan2f(from.rot.c2.x, from.rot.c2.z);
+                    Quat yawQuat = quatAngleAxis(yaw, F3{0, 1, 0});
+                    Quat fromPR = quatMul(quatInverse(yawQuat), fromQuat);
+                    Quat toPR = quatMul(quatInverse(yawQuat), toQuat);
+                    rotQuat = quatMul(yawQuat, quatSlerp(fromPR, toPR, weightTo));
+                } else {
+                    rotQuat = quatSlerp(fromQuat, toQuat, weightTo);
+                }
+                Aff loc = rotationFromQuat(rotQuat);
+                loc.c3 = t;
+                storeAff12(sLocal + i * 12, loc);
+            }
+        } else if (hasMotion) { // :224-276
+            const int prof = L.motionProfile;
+            float cycle = cycleOf(pf, prof);
+            L.motionTime += dt * L.playbackRate;
+            L.motionTime = loop ? fmodf(L.motionTime, cycle) : smin(L.motionTime, cycle);
+            float phase = smax(0.0f, smin(L.motionTime / cycle, 1.0f));
+            L.posePhase = phase;
+            Harmonics h;
+            harmonics(phase, pf.order[prof], h);
+            for (int i = lane; i < B; i += kWave) {
+                BoneEval ev = evalBone(sk, pf, prof, i, h, inPlace, rootFix);
+                Aff loc = ev.rot;
+                loc.c3 = ev.t;
+                if (!ev.present) loc = loadAff12(sk.bindLocal + i * 12);
+                storeAff12(sLocal + i * 12, loc);
+            }
+        } else { // :277-284
+            for (int i = lane; i < B; i += kWave) storeAff12(sLocal + i * 12, loadAff12(sk.bindLocal + i * 12));
+        }
+        __syncthreads();
+
+        // ---- action layer :286-338 ----
+        if ((A.flags & SGE_ACTION_PRESENT) && (A.flags & SGE_ACTION_ACTIVE) && A.weight > 0.001f) {
+            const int prof = A.profile;
+            float cycle = cycleOf(pf, prof);
+            float phase = smax(0.0f, smin(A.time / cycle, 1.0f));
+            Harmonics h;
+            harmonics(phase, pf.order[prof], h);
+            float wgt = smax(0.0f, smin(A.weight, 1.0f));
+            float iw = 1 - wgt;
+            runLeanWeight *= iw;
+            const bool actInPlace = (A.flags & SGE_ACTION_IN_PLACE) != 0;
+            for (int i = lane; i < B; i += kWave) {
+                BoneEval ev = evalBone(sk, pf, prof, i, h, actInPlace, rootFix);
+                Aff act = ev.rot;
+                act.c3 = ev.t;
+                if (!ev.present) act = loadAff12(sk.bindLocal + i * 12);
+                Aff base = loadAff12(sLocal + i * 12);
+                F3 t = base.c3 + (act.c3 - base.c3) * wgt;
+                Quat q = quatSlerp(quatFromRotation(base), quatFromRotation(act), wgt);
+                Aff loc = rotationFromQuat(q);
+                loc.c3 = t;
+                storeAff12(sLocal + i * 12, loc);
+            }
+            __syncthreads();
+        }
+
+        // ---- ground align + run lean :344-394 (uniform; lane 0 commits) ----
+        if (sk.pelvisIndex >= 0) {
+            Quat trot{body.transformRotation[0], body.transformRotation[1], body.transformRotation[2], body.transformRotation[3]};
+            F3 forward = quatAct(trot, F3{0, 0, -1});
+            F3 fh{forward.x, 0, forward.z};
+            F3 forwardHoriz = lengthSq(fh) > 0.0001f ? normalize(fh) : F3{0, 0, -1};
+            F3 groundNormal{C.groundNormal[0], C.groundNormal[1], C.groundNormal[2]};
+            bool useTilt = (ctrlFlags & SGE_CTRL_GROUNDED_NEAR) != 0;
+            Quat alignQuat;
+            if (!useTilt) {
+                alignQuat = quatAngleAxis(0, F3{0, 1, 0});
+            } else {
+                F3 up{0, 1, 0};
+                F3 right = normalize(cross(up, forwardHoriz));
+                F3 nProj = normalize(groundNormal - right * dot(groundNormal, right));
+                F3 crossUp = cross(up, nProj);
+                float angle = atan2f(dot(crossUp, right), dot(up, nProj)) * 0.33f;
+                alignQuat = quatAngleAxis(angle, right);
+            }
+            if (lane == 0) {
+                Aff p = affMul(rotationFromQuat(alignQuat), loadAff12(sLocal + sk.pelvisIndex * 12));
+                storeAff12(sLocal + sk.pelvisIndex * 12, p);
+            }
+            __syncthreads();
+            if (runLeanWeight > 0.001f && sk.leanIndex >= 0) {
+                // model[leanIndex] needs only the ancestor chain of leanIndex (Skeleton.swift:189-203)
+                Aff m = loadAff12(sLocal + sk.leanChain[0] * 12), parentModel = m;
+                for (int k = 1; k < sk.leanChainLen; ++k) {
+                    parentModel = m;
+                    m = affMul(m, loadAff12(sLocal + sk.leanChain[k] * 12));
+                }
+                F3 rightWorld = normalize(m.c0);
+                F3 rightLocal = rightWorld;
+                if (sk.leanParent >= 0) {
+                    Quat parentQuat = quatFromRotation(parentModel);
+                    rightLocal = quatAct(quatInverse(parentQuat), rightWorld);
+                }
+                float leanAngle = radiansFromDegrees(10.0f) * runLeanWeight;
+                Quat leanQuat = quatAngleAxis(leanAngle, rightLocal);
+                __syncthreads();
+                if (lane == 0) {
+                    Aff l = affMul(rotationFromQuat(leanQuat), loadAff12(sLocal + sk.leanIndex * 12));
+                    storeAff12(sLocal + sk.leanIndex * 12, l);
+                }
+                __syncthreads();
+            }
+        }
+
+        // ---- model transforms level by level, then the palette :396-402 ----
+        for (int d = 0; d <= sk.maxDepth; ++d) {
+            for (int i = lane; i < B; i += kWave) {
+                if (sk.depth[i] != d) continue;
+                int p = sk.parent[i];
+                Aff loc = loadAff12(sLocal + i * 12);
+                Aff mod = p < 0 ? loc : affMul(loadAff12(sModel + p * 12), loc);
+                storeAff12(sModel + i * 12, mod);
+            }
+            __syncthreads();
+        }
+        float* pal = K.crowd.palettes + ((size_t)e * B) * 16;
+        for (int i = lane; i < B; i += kWave) {
+            Aff M = loadAff12(sModel + i * 12);
+            const float* ib = sk.invBind + i * 16;
+            float4* out = reinterpret_cast<float4*>(pal + i * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float b0 = ib[j * 4], b1 = ib[j * 4 + 1], b2 = ib[j * 4 + 2], b3 = ib[j * 4 + 3];
+                F3 c = ((M.c0 * b0 + M.c1 * b1) + M.c2 * b2) + M.c3 * b3;
+                float w = ((0.0f * b0 + 0.0f * b1) + 0.0f * b2) + 1.0f * b3;
+                out[j] = make_float4(c.x, c.y, c.z, w);
+            }
+            if (K.crowd.poseModel) {
+                float* dm = K.crowd.poseModel + ((size_t)e * B + i) * 16;
+                float* dl = K.crowd.poseLocal + ((size_t)e * B + i) * 16;
+                Aff Lc = loadAff12(sLocal + i * 12);
+                const F3 mc[4] = {M.c0, M.c1, M.c2, M.c3}, lc[4] = {Lc.c0, Lc.c1, Lc.c2, Lc.c3};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    reinterpret_cast<float4*>(dm)[j] = make_float4(mc[j].x, mc[j].y, mc[j].z, j == 3 ? 1.f : 0.f);
+                    reinterpret_cast<float4*>(dl)[j] = make_float4(lc[j].x, lc[j].y, lc[j].z, j == 3 ? 1.f : 0.f);
+                }
+            }
+        }
+    }
+
+    if (lane == 0) {
+        if (K.stages & (SGE_STAGE_LOCOMOTION | SGE_STAGE_POSE)) K.crowd.locomotion[e] = L;
+        if (K.stages & SGE_STAGE_ACTION) K.crowd.actions[e] = A;
+        if (K.stages & SGE_STAGE_WRITEBACK) {
+            sge_body_state& b = K.crowd.bodies[e];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) b.transformRotation[k] = b.rotation[k];
+        }
+    }
+}
+
+void launch_pose(const PoseLaunch& L, hipStream_t s) {
+    if (L.count <= 0) return;
+    hipLaunchKernelGGL(pose_kernel, dim3(L.count), dim3(kWave), 0, s, L);
+}
+
+} // namespace sge

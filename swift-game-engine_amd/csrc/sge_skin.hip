@@ -1,0 +1,120 @@
+// 4-weight linear-blend skinning for gfx950 — replaces the reference's Metal
+// `skinningKernel` (Game/RayTracing.metalinc:737-776) and the per-job dispatch of
+// RTSkinningEncoder.encode (Game/RTSkinningEncoder.swift:27-56).
+//
+// Mapping: one thread per vertex, 256-thread workgroups (4 wavefronts), grid =
+// characters x ceil(V/256) so every workgroup belongs to exactly one character.
+// The character's bone palette (<= 256 x 3 float4 rows, 3.1 KB for the 65-bone
+// Y-Bot) is staged once per workgroup in LDS; source streams are SoA and read
+// coalesced (they are shared by all clones and stay L2-resident); the three output
+// streams are written coalesced and dominate HBM traffic (40 B/vertex packed).
+//
+// Arithmetic: per influence j with w_j > 0:  acc += (palette[idx_j] * v).xyz * w_j,
+// in the reference's order x,y,z,w; normals/tangents are normalised with v_rsq_f32.
+// This translation unit is compiled with the default -ffp-contract=fast: the Metal
+// original is built with MTL_FAST_MATH (project.pbxproj:328,386), there are no
+// thresholds downstream of this arithmetic, and the parity bound is 1e-5 relative.
+#include "sge_internal.hpp"
+
+namespace sge {
+
+constexpr int kSkinBlock = 256;
+
+struct Row3 { float4 r0, r1, r2; };
+
+__device__ __forceinline__ Row3 loadRows(const float4* pal, int bone) {
+    Row3 m;
+    m.r0 = pal[bone * 3 + 0];
+    m.r1 = pal[bone * 3 + 1];
+    m.r2 = pal[bone * 3 + 2];
+    return m;
+}
+
+// (M * (v, w)).xyz with the reference's left-to-right column accumulation
+__device__ __forceinline__ float3 xform(const Row3& m, float3 v, float w) {
+    float3 r;
+    r.x = ((m.r0.x * v.x + m.r0.y * v.y) + m.r0.z * v.z) + m.r0.w * w;
+    r.y = ((m.r1.x * v.x + m.r1.y * v.y) + m.r1.z * v.z) + m.r1.w * w;
+    r.z = ((m.r2.x * v.x + m.r2.y * v.y) + m.r2.z * v.z) + m.r2.w * w;
+    return r;
+}
+
+__device__ __forceinline__ float3 normalizeFast(float3 a) {
+    float d = (a.x * a.x + a.y * a.y) + a.z * a.z;
+    float r = __builtin_amdgcn_rsqf(d);
+    return make_float3(a.x * r, a.y * r, a.z * r);
+}
+
+template <int SRC_STRIDE, int DST_STRIDE>
+__global__ __launch_bounds__(kSkinBlock) void skin_kernel(SkinLaunch L, int blocksPerChar) {
+    __shared__ float4 pal[SGE_MAX_BONES * 3];
+    const int c = blockIdx.x / blocksPerChar;
+    const int vb = blockIdx.x - c * blocksPerChar;
+    const int tid = threadIdx.x;
+
+    // stage the palette: thread -> one float4 COLUMN (coalesced), scattered into rows
+    const float4* gp = reinterpret_cast<const float4*>(L.palettes + (size_t)c * L.paletteCount * 16);
+    float* palf = reinterpret_cast<float*>(pal);
+    for (int i = tid; i < L.paletteCount * 4; i += kSkinBlock) {
+        float4 col = gp[i];
+        int bone = i >> 2, cc = i & 3;
+        palf[bone * 12 + 0 + cc] = col.x;
+        palf[bone * 12 + 4 + cc] = col.y;
+        palf[bone * 12 + 8 + cc] = col.z;
+    }
+    __syncthreads();
+
+    const int gid = vb * kSkinBlock + tid;
+    if (gid >= L.vertexCount) return;
+
+    const float* sp = reinterpret_cast<const float*>(L.srcPos) + (size_t)gid * SRC_STRIDE;
+    const float* sn = reinterpret_cast<const float*>(L.srcNrm) + (size_t)gid * SRC_STRIDE;
+    float3 p = make_float3(sp[0], sp[1], sp[2]);
+    float3 n = make_float3(sn[0], sn[1], sn[2]);
+    float4 t = reinterpret_cast<const float4*>(L.srcTan)[gid];
+    ushort4 idx = reinterpret_cast<const ushort4*>(L.srcIdx)[gid];
+    float4 w = reinterpret_cast<const float4*>(L.srcWgt)[gid];
+    float3 tv = make_float3(t.x, t.y, t.z);
+
+    float3 acc = make_float3(0.f, 0.f, 0.f), nAcc = acc, tAcc = acc;
+#define SGE_INFLUENCE(BONE, WGT)                                              \
+    if ((WGT) > 0.0f) {                                                       \
+        Row3 m = loadRows(pal, (BONE));                                       \
+        float3 a = xform(m, p, 1.0f), b = xform(m, n, 0.0f), d = xform(m, tv, 0.0f); \
+        acc.x += a.x * (WGT); acc.y += a.y * (WGT); acc.z += a.z * (WGT);     \
+        nAcc.x += b.x * (WGT); nAcc.y += b.y * (WGT); nAcc.z += b.z * (WGT);  \
+        tAcc.x += d.x * (WGT); tAcc.y += d.y * (WGT); tAcc.z += d.z * (WGT);  \
+    }
+    SGE_INFLUENCE(idx.x, w.x)
+    SGE_INFLUENCE(idx.y, w.y)
+    SGE_INFLUENCE(idx.z, w.z)
+    SGE_INFLUENCE(idx.w, w.w)
+#undef SGE_INFLUENCE
+    float3 nn = normalizeFast(nAcc);
+    float3 tn = normalizeFast(tAcc);
+
+    const size_t o = (size_t)L.dstBaseVertex + (size_t)c * L.vertexCount + gid;
+    float* op = reinterpret_cast<float*>(L.outPos) + o * DST_STRIDE;
+    float* on = reinterpret_cast<float*>(L.outNrm) + o * DST_STRIDE;
+    if (DST_STRIDE == 4) {
+        *reinterpret_cast<float4*>(op) = make_float4(acc.x, acc.y, acc.z, 0.f);
+        *reinterpret_cast<float4*>(on) = make_float4(nn.x, nn.y, nn.z, 0.f);
+    } else {
+        op[0] = acc.x; op[1] = acc.y; op[2] = acc.z;
+        on[0] = nn.x; on[1] = nn.y; on[2] = nn.z;
+    }
+    reinterpret_cast<float4*>(L.outTan)[o] = make_float4(tn.x, tn.y, tn.z, t.w);
+}
+
+void launch_skin(const SkinLaunch& L, hipStream_t s) {
+    if (L.chars <= 0 || L.vertexCount <= 0) return;
+    int blocksPerChar = (L.vertexCount + kSkinBlock - 1) / kSkinBlock;
+    dim3 grid((unsigned)((size_t)blocksPerChar * L.chars));
+    int ss = L.srcLayout == SGE_LAYOUT_PADDED16 ? 4 : 3, ds = L.dstLayout == SGE_LAYOUT_PADDED16 ? 4 : 3;
+    if (ss == 3 && ds == 3) hipLaunchKernelGGL((skin_kernel<3, 3>), grid, dim3(kSkinBlock), 0, s, L, blocksPerChar);
+    else if (ss == 3 && ds == 4) hipLaunchKernelGGL((skin_kernel<3, 4>), grid, dim3(kSkinBlock), 0, s, L, blocksPerChar);
+    else if (ss == 4 && ds == 3) hipLaunchKernelGGL((skin_kernel<4, 3>), grid, dim3(kSkinBlock), 0, s, L, blocksPerChar);
+    else hipLaunchKernelGGL((skin_kernel<4, 4>), grid, dim3(kSkinBlock), 0, s, L, blocksPerChar);
+}
+
+} // namespace sge

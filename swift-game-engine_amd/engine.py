@@ -265,6 +265,15 @@ class CharacterEngine:
         d.first, d.count = first, count
         self._call("tick", C.byref(d))
 
+    # -- agents (config 5) -------------------------------------------------- #
+    def agents_export(self, out_ptr):
+        """Packs this engine's characters as AgentSweepState[count] at `out_ptr`
+        (device pointer for the product, host pointer for the test oracle)."""
+        self._call("agents_export", C.c_void_p(out_ptr))
+
+    def agents_import(self, all_ptr, total, self_offset):
+        self._call("agents_import", C.c_void_p(all_ptr), int(total), int(self_offset))
+
     # -- diagnostics ------------------------------------------------------- #
     def profile_read(self, reset=True):
         st = abi.StageTimes()

@@ -1,0 +1,234 @@
+"""GPU parity tests: the HIP product (through the C ABI) against the CPU oracle on identical inputs.
+
+Bars (BASELINE.json north_star: 1e-5 relative):
+  - BVH structure, query TOIs/normals/triangle ids, and the whole CCD state: BIT-EXACT
+    (both sides run IEEE float32 in the same order with contraction off);
+  - palettes and skinned vertices: |gpu - cpu| <= 1e-5 * max|cpu| (libm vs OCML trig, FMA in the LBS kernel).
+"""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from scenes import assert_struct_equal, build_scene, compare_states
+
+pytestmark = pytest.mark.gpu
+REL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def engines(sge):
+    gpu = sge.CharacterEngine(0)
+    cpu = ob.oracle_engine()
+    yield gpu, cpu
+    gpu.close()
+    cpu.close()
+
+
+def test_library_refuses_without_fallback(sge):
+    # the product path is the HIP library; the loader has no alternative
+    assert sge.abi.load_library().sge_abi_version() == 1
+
+
+def test_bvh_build_bit_exact(sge, engines):
+    gpu, cpu = engines
+    for cells in ((7, 5), (40, 28)):
+        for e in engines:
+            sge.crowd.upload_terrain(e, cells=cells)
+        g, c = gpu.collision_copy(), cpu.collision_copy()
+        for k in ("positions", "indices", "aabbs", "triOrder", "triLeaf"):
+            assert np.array_equal(g[k], c[k]), k
+        assert_struct_equal(g["nodes"], c["nodes"], "nodes")
+        # invariants: every triangle in exactly one leaf, leaves hold <= 4
+        nodes = g["nodes"]
+        leaves = nodes[nodes["left"] < 0]
+        assert leaves["count"].max() <= 4 and leaves["count"].sum() == len(g["triOrder"])
+        assert sorted(g["triOrder"].tolist()) == list(range(len(g["triOrder"])))
+
+
+def test_bvh_ornate_mirror(sge, engines):
+    gpu, cpu = engines
+    z = np.load(sge.assets.GOLDEN_DIR + "/ornate_mirror_static.npz")
+    # row-major JSON -> simd columns (StaticMeshLoader.swift:127-134), then the demo's x8 scale and offset
+    # (DemoScene.swift:328-335; without the scale most triangles fall under the 1e-10 area filter)
+    m = z["transformRowMajor"].reshape(4, 4).astype(np.float32)
+    m = (np.diag([1, 1, 1, 1]).astype(np.float32) @ m @ np.diag([8, 8, 8, 1]).astype(np.float32))
+    m[:3, 3] += (-10, 1, 4)
+    ents = [{"positions": z["positions"], "indices": z["indices"], "modelMatrix": m.T.reshape(16)}]
+    for e in engines:
+        e.rebuild_static(ents)
+    g, c = gpu.collision_copy(), cpu.collision_copy()
+    assert 14000 < g["triOrder"].shape[0] <= 14246
+    for k in ("positions", "indices", "aabbs", "triOrder", "triLeaf"):
+        assert np.array_equal(g[k], c[k]), k
+    assert_struct_equal(g["nodes"], c["nodes"], "nodes")
+    # queries against a real asset
+    rng = np.random.default_rng(5)
+    lo, hi = g["positions"].min(0), g["positions"].max(0)
+    n = 512
+    origin = rng.uniform(lo - 0.5, hi + 0.5, (n, 3)).astype(np.float32)
+    delta = rng.normal(0, 1.0, (n, 3)).astype(np.float32)
+    q = sge.make_queries(origin, delta, radius=0.4, half_height=0.3, mode=sge.abi.CAST)
+    q["mode"] = rng.integers(0, 3, n)
+    assert_struct_equal(gpu.capsule_cast(q), cpu.capsule_cast(q), "cast")
+    go, gc = gpu.capsule_overlap_all(q, 8)
+    co, cc = cpu.capsule_overlap_all(q, 8)
+    assert np.array_equal(gc, cc)
+    assert_struct_equal(go, co, "overlap")
+    assert gc.max() > 0 and gpu.capsule_cast(q)["hit"].sum() > 10
+
+
+def test_queries_bit_exact_on_terrain(sge, engines):
+    gpu, cpu = engines
+    for e in engines:
+        terrain = sge.crowd.upload_terrain(e, cells=(64, 48))
+    rng = np.random.default_rng(11)
+    n = 2000
+    x = rng.uniform(-30, 30, n)
+    z = rng.uniform(-22, 22, n)
+    y = sge.assets.terrain_height(x, z, *terrain["half"]) + rng.uniform(1.0, 6.0, n)
+    origin = np.stack([x, y, z], -1).astype(np.float32)
+    delta = np.zeros((n, 3), np.float32)
+    kind = rng.integers(0, 4, n)
+    delta[kind == 0] = (0, -0.8, 0)            # snap probe
+    delta[kind == 1] = (0, -200.0, 0)          # fall probe
+    delta[kind >= 2] = rng.normal(0, 1.5, ((kind >= 2).sum(), 3))
+    q = sge.make_queries(origin, delta)
+    q["mode"] = np.where(kind <= 1, sge.abi.CAST_GROUND, np.where(kind == 2, sge.abi.CAST_BLOCKING, sge.abi.CAST))
+    gh, ch = gpu.capsule_cast(q), cpu.capsule_cast(q)
+    assert ch["hit"].sum() > n // 3
+    assert_struct_equal(gh, ch, "cast")
+    # overlaps: push the capsules into the ground
+    q2 = sge.make_queries(origin - np.array([0, 2.2, 0], np.float32))
+    go, gc = gpu.capsule_overlap_all(q2, 8)
+    co, cc = cpu.capsule_overlap_all(q2, 8)
+    assert cc.max() == 8 and np.array_equal(gc, cc)
+    assert_struct_equal(go, co, "overlap")
+    for mh in (1, 3):
+        go, gc = gpu.capsule_overlap_all(q2[:200], mh)
+        co, cc = cpu.capsule_overlap_all(q2[:200], mh)
+        assert np.array_equal(gc, cc)
+        assert_struct_equal(go, co, "overlap%d" % mh)
+    assert gpu.move_stats().overflow == 0
+
+
+def test_cast_edge_cases(sge, engines):
+    gpu, cpu = engines
+    for e in engines:
+        sge.crowd.upload_ground_plane(e)
+    origin = np.array([[0, 0.5, 0], [0, 0.5, 0], [100, 5, 0], [0, -0.6, 0], [39.9, 2, 39.9]], np.float32)
+    delta = np.array([[0, 0, 0], [0, -1e-7, 0], [0, -10, 0], [0, -1, 0], [0, -20, 0]], np.float32)
+    q = sge.make_queries(origin, delta, mode=sge.abi.CAST_GROUND)
+    gh, ch = gpu.capsule_cast(q), cpu.capsule_cast(q)
+    assert_struct_equal(gh, ch, "cast")
+    assert gh["hit"].tolist() == ch["hit"].tolist() and gh["hit"][0] == 0 and gh["hit"][1] == 0 and gh["hit"][2] == 0
+    # analytic: vertical capsule at height h above y=-3 plane: toi ~= h - r - hh
+    q = sge.make_queries([[0, 7.5, 0]], [[0, -200, 0]], mode=sge.abi.CAST_GROUND)
+    h = gpu.capsule_cast(q)[0]
+    assert h["hit"] == 1 and abs(h["toi"] - (7.5 + 3 - 2.5)) < 2e-3 and h["normal"][1] > 0.999
+    # empty world
+    for e in engines:
+        e.rebuild_static([])
+    assert gpu.capsule_cast(q)["hit"][0] == 0 and cpu.capsule_cast(q)["hit"][0] == 0
+
+
+def test_skinning_kernel_vs_oracle(sge, engines):
+    gpu, cpu = engines
+    n = 5
+    for e in engines:
+        build_scene(sge, e, n, terrain_cells=(16, 12), rings=9, segments=7)
+    for e in engines:
+        e.tick(stages=sge.abi.STAGE_ALL)
+    gpu.synchronize()
+    gp, gn, gt = gpu.skinned()
+    cp, cn, ct = cpu.skinned()
+    assert gp.shape[0] == n * gpu.vertex_count
+    assert np.abs(gp - cp).max() <= REL * np.abs(cp).max()
+    assert np.abs(gn - cn).max() <= 2e-6 and np.abs(gt - ct).max() <= 2e-6
+    assert np.allclose(np.linalg.norm(gn, axis=1), 1, atol=1e-5)
+    # padded (Metal float3 stride) layout gives the same numbers
+    gpu.set_option(sge.abi.OPT_SKIN_LAYOUT, sge.abi.LAYOUT_PADDED16)
+    gpu.tick(dt=0.0, stages=sge.abi.STAGE_SKIN)
+    pp, pn, pt = gpu.skinned()
+    gpu.set_option(sge.abi.OPT_SKIN_LAYOUT, sge.abi.LAYOUT_PACKED)
+    gpu.tick(dt=0.0, stages=sge.abi.STAGE_SKIN)
+    qp, qn, qt = gpu.skinned()
+    assert np.array_equal(pp, qp) and np.array_equal(pn, qn) and np.array_equal(pt, qt)
+
+
+def test_bind_pose_identity_palette(sge, engines):
+    """Known answer: palette = model(bindLocal) * invBindModel = I, so skinned == source."""
+    gpu, _ = engines
+    ybot, _, _ = build_scene(sge, gpu, 2, terrain_cells=(16, 12), rings=5, segments=5)
+    L = sge.assets.default_locomotion(2, ybot)
+    L["flags"] = 0  # no locomotion, no motion profile -> bind pose branch
+    a = sge.assets.default_actions(2)
+    gpu.upload(locomotion=L, actions=a)
+    gpu.tick(dt=0.0, stages=sge.abi.STAGE_POSE | sge.abi.STAGE_SKIN)
+    pal, _, _ = gpu.palettes()
+    assert np.abs(pal - np.eye(4, dtype=np.float32).reshape(16)).max() < 2e-6
+    p, nrm, _ = gpu.skinned()
+    V = gpu.vertex_count
+    assert np.abs(p[:V] - gpu.mesh["positions"]).max() < 5e-6
+    assert np.abs(p[V:] - gpu.mesh["positions"]).max() < 5e-6
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_full_tick_parity(sge, engines, mixed):
+    gpu, cpu = engines
+    n = 96
+    for e in engines:
+        build_scene(sge, e, n, terrain_cells=(56, 40), seed=21 + mixed, mixed=mixed)
+    steps = 150
+    for s in range(steps):
+        for e in engines:
+            e.tick()
+        if s in (0, 1, 5, 20, 60, steps - 1):
+            gpu.synchronize()
+            compare_states(sge, gpu, cpu, n)
+    g = gpu.download()
+    grounded = (g["controllers"]["flags"] & sge.abi.CTRL_GROUNDED_NEAR) != 0
+    assert grounded.mean() > 0.8, "most characters should have landed"
+    assert (g["locomotion"]["state"] != 0).any()
+    gp, gn, gt = gpu.skinned()
+    cp, cn, ct = cpu.skinned()
+    assert np.abs(gp - cp).max() <= REL * np.abs(cp).max()
+    assert gpu.move_stats().overflow == 0
+
+
+def test_action_layer_and_mesh_rebind(sge, engines):
+    gpu, cpu = engines
+    n = 16
+    for e in engines:
+        ybot, _, st = build_scene(sge, e, n, terrain_cells=(32, 24), seed=4, mesh_inv_bind=True)
+        a = st["actions"].copy()
+        a["flags"] |= sge.abi.ACTION_ACTIVE
+        a["weight"] = np.linspace(0.0, 1.0, n).astype(np.float32)
+        a["time"] = np.linspace(0.0, 1.0, n).astype(np.float32)
+        e.upload(actions=a)
+    for s in range(40):
+        for e in engines:
+            e.tick()
+    gpu.synchronize()
+    compare_states(sge, gpu, cpu, n)
+
+
+def test_config1_single_ybot_settles(sge, engines):
+    """config 1: one Y-Bot dropped on the 80x80 quad at y=-3 settles with its bottom groundSnapSkin above it."""
+    gpu, cpu = engines
+    for e in engines:
+        ybot, _, _ = build_scene(sge, e, 1, terrain_cells=None)
+        e.resize(1)
+        e.upload(bodies=sge.assets.default_bodies(1, np.array([[0, 7.5, 0]])),
+                 params=sge.assets.default_controller_params(1), controllers=sge.assets.default_controller_state(1),
+                 intents=sge.assets.default_intents(1), locomotion=sge.assets.default_locomotion(1, ybot),
+                 actions=sge.assets.default_actions(1, ybot, present=True))
+    ys = []
+    for s in range(240):
+        for e in engines:
+            e.tick()
+        if s % 30 == 29:
+            gpu.synchronize()
+            compare_states(sge, gpu, cpu, 1)
+        ys.append(gpu.download(what=("bodies",))["bodies"]["position"][0, 1])
+    assert abs(ys[-1] - (-3 + 2.5 + 0.05)) < 2e-3, ys[-1]
+    assert abs(ys[-1] - ys[-20]) < 1e-6
