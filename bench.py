@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Headline benchmark: characters/sec through the per-frame character update on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+A "step" is one fixed step (dt = 1/60) of the whole hot path over one batch of synthetic
+characters already resident in HBM: intent -> gravity -> capsule-CCD move-and-slide ->
+locomotion -> action -> pose + palette -> 4-weight LBS of every vertex.
+Workload (BASELINE.json configs[2]): 10,000 Y-Bot clones per GPU
+(65 bones, 14,080 skinned vertices each) against a 71,680-triangle static mesh; characters
+shard by index across GPUs with no data-path collective ("weak" scaling: per-GPU work fixed).
+`--workload lbs` is configs[1] (pose + LBS only), `--workload agents` is configs[4]'s
+character-vs-character exchange (one RCCL all-gather of capsule state per step).
+
+Rank 0 prints ONE JSON line. `roofline` prices the LBS kernel (the HBM-bound kernel of the
+path) from HIP events recorded on the stream it runs on; `cpu_baseline` times the CPU oracle
+(a float32 port of the reference's Swift path, which cannot be built here) on a bounded
+sample of the same crowd, on this box's host cores.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+SETTLE_STEPS = 120     # scene preparation: let the spawned crowd land and reach its walk/run speed
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--chars", type=int, default=10000, help="characters per GPU")
+    ap.add_argument("--workload", choices=["ccd", "lbs", "agents"], default="ccd")
+    ap.add_argument("--layout", choices=["packed", "padded16"], default="packed")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-chars", type=int, default=384)
+    ap.add_argument("--cpu-sample-steps", type=int, default=8)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__
+    sge = __graft_entry__.build()
+    abi = sge.abi
+
+    # ---- world: replicated per GPU ------------------------------------------------
+    eng = sge.CharacterEngine(local_rank)
+    eng.set_option(abi.OPT_SKIN_LAYOUT, abi.LAYOUT_PADDED16 if args.layout == "padded16" else abi.LAYOUT_PACKED)
+    ybot = sge.assets.YBotAssets()
+    sge.crowd.upload_character_assets(eng, ybot)  # 22 x 10 vertices on 64 bones = 14,080
+    terrain = sge.crowd.upload_terrain(eng)       # 224 x 160 x 2 = 71,680 triangles
+    n_total = args.chars * world
+    first, count = sge.parallel.shard_range(n_total, rank, world)
+    mode = "lbs" if args.workload == "lbs" else "ccd"
+    # every rank draws the whole seeded crowd and keeps its contiguous block
+    full_eng_state = None
+    eng.resize(count)
+    state = _spawn_block(sge, eng, ybot, n_total, first, count, terrain, mode, agents=args.workload == "agents")
+    stages = abi.STAGE_ALL if mode == "ccd" else (abi.STAGE_LOCOMOTION | abi.STAGE_ACTION | abi.STAGE_POSE | abi.STAGE_WRITEBACK | abi.STAGE_SKIN)
+    exchange = None
+    if args.workload == "agents":
+        exchange = sge.parallel.AgentExchange(eng, n_total, rank, world, torch.device("cuda", local_rank), dist)
+
+    def step():
+        if exchange is not None:
+            exchange.step(stages=stages)
+        else:
+            eng.tick(stages=stages)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if mode == "ccd":
+        for _ in range(SETTLE_STEPS):
+            step()
+    for _ in range(args.warmup):
+        step()
+    eng.synchronize()
+    eng.set_option(abi.OPT_PROFILE, 1)
+    eng.profile_read(reset=True)
+    eng.move_stats(reset=True)
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    prof = eng.profile_read(reset=True)
+    stats = eng.move_stats(reset=True)
+    eng.set_option(abi.OPT_PROFILE, 0)
+
+    V, B = eng.vertex_count, eng.bone_count
+    # ALGORITHMIC bytes of one LBS launch: per character 40*V written, 4160 B palette read,
+    # source streams 64*V read once per launch (shared by all clones of the mesh)
+    lbs_bytes = count * (40.0 * V + B * 64.0) + 64.0 * V
+    lbs_ms = prof.skin_ms / max(prof.skin_launches, 1)
+    achieved = lbs_bytes / (lbs_ms * 1e-3) / 1e9 if lbs_ms > 0 else 0.0
+    traffic = _recorded_traffic(count, V)
+    value = n_total * args.steps / elapsed
+    out = {
+        "metric": "characters/sec (skin+CCD)" if mode == "ccd" else "characters/sec (pose+skin, no CCD)",
+        "value": value,
+        "unit": "characters/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": {"ccd": "configs[2]: 10k Y-Bot clones/GPU, pose + LBS + capsule-CCD vs 71,680-tri static mesh",
+                         "lbs": "configs[1]: 10k Y-Bot clones/GPU, Running profile, pose + LBS only",
+                         "agents": "configs[4]-style: configs[2] + character-vs-character sweeps, RCCL all-gather of capsule state"}[args.workload],
+            "characters_per_gpu": args.chars, "characters_total": n_total, "bones": B, "vertices_per_character": V,
+            "static_triangles": int(terrain["indices"].size // 3), "dt": 1.0 / 60.0, "sharding": f"by-character x{world}",
+            "skin_layout": args.layout, "settle_steps": SETTLE_STEPS if mode == "ccd" else 0, "seed": 1234,
+        },
+        "roofline": {"bound": "hbm", "kernel": "skin_kernel (4-weight LBS)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "bytes_per_launch": lbs_bytes, "ms_per_launch": lbs_ms},
+        "whole_path_hbm_frac": (value / world) * (40.0 * V + 64.0 * V / count + 2 * B * 64.0 + 640.0) / (HBM_PEAK_GBS * 1e9),
+        "kernels_ms_per_step": {"move_ccd": prof.move_ms / args.steps, "pose": prof.pose_ms / args.steps,
+                                "lbs": prof.skin_ms / args.steps, "agents_grid": prof.agents_ms / args.steps},
+        "ccd": {"bvh_queries_per_char_step": stats.queries / max(count * args.steps, 1),
+                "candidates_per_query": stats.candidates / max(stats.queries, 1),
+                "distance_evals_per_query": stats.sweepIterations / max(stats.queries, 1),
+                "queries_per_s": stats.queries / max(prof.move_ms * 1e-3, 1e-9), "overflow": int(stats.overflow)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = _cpu_baseline(sge, eng, ybot, terrain, stages, args, mode)
+    if rank == 0:
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def _spawn_block(sge, eng, ybot, n_total, first, count, terrain, mode, agents):
+    """Draw the seeded crowd of all ranks (host numpy, cheap) and upload this rank's block."""
+    class _Capture:
+        def resize(self, n):
+            pass
+
+        def upload(self, **kw):
+            self.kw = kw
+
+    cap = _Capture()
+    sge.crowd.spawn_crowd(cap, ybot, n_total, terrain, seed=1234, mode=mode, agents=agents)
+    block = {k: v[first:first + count] for k, v in cap.kw.items()}
+    eng.upload(**block)
+    return block
+
+
+def _recorded_traffic(count, V):
+    """HBM bytes per LBS launch from the committed rocprofv3 --pmc pass, if it matches this shape."""
+    path = os.path.join(ROOT, "profiles", "lbs_traffic.json")
+    try:
+        rec = json.load(open(path))
+        if rec.get("characters") == count and rec.get("vertices") == V:
+            return rec["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
+def _cpu_baseline(sge, eng, ybot, terrain, stages, args, mode):
+    """The oracle (a CPU port of the reference path) on a bounded sample of the SAME settled crowd."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+
+    n = min(args.cpu_sample_chars, eng.count)
+    steps = args.cpu_sample_steps
+    state = eng.download(0, n)
+    cores = min(os.cpu_count() or 1, 16)  # the GPU box's CPU share for one GPU
+    res = {}
+    for label, threads in (("single_thread", 1), ("all_cores", cores)):
+        cpu = ob.oracle_engine()
+        sge.crowd.upload_character_assets(cpu, ybot)
+        cpu.rebuild_static([{"positions": terrain["positions"], "indices": terrain["indices"]}])
+        cpu.resize(n)
+        cpu.upload(**state)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ob.tick_mt(cpu, threads, stages=stages)
+        dt = time.perf_counter() - t0
+        res[label] = n * steps / dt
+        cpu.close()
+    return {"value": res["all_cores"], "unit": "characters/s", "cores": cores, "kind": "port",
+            "single_thread_value": res["single_thread"],
+            "sample": f"{n} characters of the settled crowd x {steps} fixed steps, same stages, CPU oracle "
+                      f"(oracle/, float32 C++ port of the Swift path; the Swift reference has no toolchain here)"}
+
+
+if __name__ == "__main__":
+    main()
