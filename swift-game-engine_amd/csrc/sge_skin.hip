@@ -45,12 +45,36 @@ __device__ __forceinline__ float3 normalizeFast(float3 a) {
     return make_float3(a.x * r, a.y * r, a.z * r);
 }
 
+struct VertexIn { float3 p, n; float4 t; ushort4 idx; float4 w; };
+
+template <int SRC_STRIDE>
+__device__ __forceinline__ VertexIn loadVertex(const SkinLaunch& L, int gid) {
+    VertexIn v;
+    const float* sp = reinterpret_cast<const float*>(L.srcPos) + (size_t)gid * SRC_STRIDE;
+    const float* sn = reinterpret_cast<const float*>(L.srcNrm) + (size_t)gid * SRC_STRIDE;
+    v.p = make_float3(sp[0], sp[1], sp[2]);
+    v.n = make_float3(sn[0], sn[1], sn[2]);
+    v.t = reinterpret_cast<const float4*>(L.srcTan)[gid];
+    v.idx = reinterpret_cast<const ushort4*>(L.srcIdx)[gid];
+    v.w = reinterpret_cast<const float4*>(L.srcWgt)[gid];
+    return v;
+}
+
+// One workgroup = one character (or 1/splits of its vertices): the palette is staged once,
+// then the 256 threads walk the vertex stream 256 at a time with the next chunk's source
+// attributes already in flight while the current chunk is transformed and stored.
 template <int SRC_STRIDE, int DST_STRIDE>
-__global__ __launch_bounds__(kSkinBlock) void skin_kernel(SkinLaunch L, int blocksPerChar) {
+__global__ __launch_bounds__(kSkinBlock) void skin_kernel(SkinLaunch L, int splits, int vertsPerSplit) {
     __shared__ float4 pal[SGE_MAX_BONES * 3];
-    const int c = blockIdx.x / blocksPerChar;
-    const int vb = blockIdx.x - c * blocksPerChar;
+    const int c = blockIdx.x / splits;
+    const int sp = blockIdx.x - c * splits;
     const int tid = threadIdx.x;
+
+    const int vBegin = sp * vertsPerSplit;
+    const int vEnd = min(L.vertexCount, vBegin + vertsPerSplit);
+    int gid = vBegin + tid;
+    VertexIn cur{};
+    if (gid < vEnd) cur = loadVertex<SRC_STRIDE>(L, gid);
 
     // stage the palette: thread -> one float4 COLUMN (coalesced), scattered into rows
     const float4* gp = reinterpret_cast<const float4*>(L.palettes + (size_t)c * L.paletteCount * 16);
@@ -64,57 +88,59 @@ __global__ __launch_bounds__(kSkinBlock) void skin_kernel(SkinLaunch L, int bloc
     }
     __syncthreads();
 
-    const int gid = vb * kSkinBlock + tid;
-    if (gid >= L.vertexCount) return;
+    const size_t obase = (size_t)L.dstBaseVertex + (size_t)c * L.vertexCount;
+    for (; gid < vEnd; gid += kSkinBlock) {
+        VertexIn nxt = cur;
+        const int gnext = gid + kSkinBlock;
+        if (gnext < vEnd) nxt = loadVertex<SRC_STRIDE>(L, gnext);
 
-    const float* sp = reinterpret_cast<const float*>(L.srcPos) + (size_t)gid * SRC_STRIDE;
-    const float* sn = reinterpret_cast<const float*>(L.srcNrm) + (size_t)gid * SRC_STRIDE;
-    float3 p = make_float3(sp[0], sp[1], sp[2]);
-    float3 n = make_float3(sn[0], sn[1], sn[2]);
-    float4 t = reinterpret_cast<const float4*>(L.srcTan)[gid];
-    ushort4 idx = reinterpret_cast<const ushort4*>(L.srcIdx)[gid];
-    float4 w = reinterpret_cast<const float4*>(L.srcWgt)[gid];
-    float3 tv = make_float3(t.x, t.y, t.z);
-
-    float3 acc = make_float3(0.f, 0.f, 0.f), nAcc = acc, tAcc = acc;
+        const float3 p = cur.p, n = cur.n;
+        const float3 tv = make_float3(cur.t.x, cur.t.y, cur.t.z);
+        float3 acc = make_float3(0.f, 0.f, 0.f), nAcc = acc, tAcc = acc;
 #define SGE_INFLUENCE(BONE, WGT)                                              \
-    if ((WGT) > 0.0f) {                                                       \
-        Row3 m = loadRows(pal, (BONE));                                       \
-        float3 a = xform(m, p, 1.0f), b = xform(m, n, 0.0f), d = xform(m, tv, 0.0f); \
-        acc.x += a.x * (WGT); acc.y += a.y * (WGT); acc.z += a.z * (WGT);     \
-        nAcc.x += b.x * (WGT); nAcc.y += b.y * (WGT); nAcc.z += b.z * (WGT);  \
-        tAcc.x += d.x * (WGT); tAcc.y += d.y * (WGT); tAcc.z += d.z * (WGT);  \
-    }
-    SGE_INFLUENCE(idx.x, w.x)
-    SGE_INFLUENCE(idx.y, w.y)
-    SGE_INFLUENCE(idx.z, w.z)
-    SGE_INFLUENCE(idx.w, w.w)
+        if ((WGT) > 0.0f) {                                                   \
+            Row3 m = loadRows(pal, (BONE));                                   \
+            float3 a = xform(m, p, 1.0f), b = xform(m, n, 0.0f), d = xform(m, tv, 0.0f); \
+            acc.x += a.x * (WGT); acc.y += a.y * (WGT); acc.z += a.z * (WGT); \
+            nAcc.x += b.x * (WGT); nAcc.y += b.y * (WGT); nAcc.z += b.z * (WGT); \
+            tAcc.x += d.x * (WGT); tAcc.y += d.y * (WGT); tAcc.z += d.z * (WGT); \
+        }
+        SGE_INFLUENCE(cur.idx.x, cur.w.x)
+        SGE_INFLUENCE(cur.idx.y, cur.w.y)
+        SGE_INFLUENCE(cur.idx.z, cur.w.z)
+        SGE_INFLUENCE(cur.idx.w, cur.w.w)
 #undef SGE_INFLUENCE
-    float3 nn = normalizeFast(nAcc);
-    float3 tn = normalizeFast(tAcc);
+        float3 nn = normalizeFast(nAcc);
+        float3 tn = normalizeFast(tAcc);
 
-    const size_t o = (size_t)L.dstBaseVertex + (size_t)c * L.vertexCount + gid;
-    float* op = reinterpret_cast<float*>(L.outPos) + o * DST_STRIDE;
-    float* on = reinterpret_cast<float*>(L.outNrm) + o * DST_STRIDE;
-    if (DST_STRIDE == 4) {
-        *reinterpret_cast<float4*>(op) = make_float4(acc.x, acc.y, acc.z, 0.f);
-        *reinterpret_cast<float4*>(on) = make_float4(nn.x, nn.y, nn.z, 0.f);
-    } else {
-        op[0] = acc.x; op[1] = acc.y; op[2] = acc.z;
-        on[0] = nn.x; on[1] = nn.y; on[2] = nn.z;
+        const size_t o = obase + gid;
+        float* op = reinterpret_cast<float*>(L.outPos) + o * DST_STRIDE;
+        float* on = reinterpret_cast<float*>(L.outNrm) + o * DST_STRIDE;
+        if (DST_STRIDE == 4) {
+            *reinterpret_cast<float4*>(op) = make_float4(acc.x, acc.y, acc.z, 0.f);
+            *reinterpret_cast<float4*>(on) = make_float4(nn.x, nn.y, nn.z, 0.f);
+        } else {
+            op[0] = acc.x; op[1] = acc.y; op[2] = acc.z;
+            on[0] = nn.x; on[1] = nn.y; on[2] = nn.z;
+        }
+        reinterpret_cast<float4*>(L.outTan)[o] = make_float4(tn.x, tn.y, tn.z, cur.t.w);
+        cur = nxt;
     }
-    reinterpret_cast<float4*>(L.outTan)[o] = make_float4(tn.x, tn.y, tn.z, t.w);
 }
 
 void launch_skin(const SkinLaunch& L, hipStream_t s) {
     if (L.chars <= 0 || L.vertexCount <= 0) return;
-    int blocksPerChar = (L.vertexCount + kSkinBlock - 1) / kSkinBlock;
-    dim3 grid((unsigned)((size_t)blocksPerChar * L.chars));
+    // enough workgroups to fill 256 CUs x 8 resident blocks several times over; small crowds split characters
+    int splits = 1;
+    while ((long long)L.chars * splits < 8192 && splits < 64 && (L.vertexCount + splits - 1) / splits > 2 * kSkinBlock) splits *= 2;
+    int vertsPerSplit = ((L.vertexCount + splits - 1) / splits + kSkinBlock - 1) / kSkinBlock * kSkinBlock;
+    splits = (L.vertexCount + vertsPerSplit - 1) / vertsPerSplit;
+    dim3 grid((unsigned)((size_t)splits * L.chars));
     int ss = L.srcLayout == SGE_LAYOUT_PADDED16 ? 4 : 3, ds = L.dstLayout == SGE_LAYOUT_PADDED16 ? 4 : 3;
-    if (ss == 3 && ds == 3) hipLaunchKernelGGL((skin_kernel<3, 3>), grid, dim3(kSkinBlock), 0, s, L, blocksPerChar);
-    else if (ss == 3 && ds == 4) hipLaunchKernelGGL((skin_kernel<3, 4>), grid, dim3(kSkinBlock), 0, s, L, blocksPerChar);
-    else if (ss == 4 && ds == 3) hipLaunchKernelGGL((skin_kernel<4, 3>), grid, dim3(kSkinBlock), 0, s, L, blocksPerChar);
-    else hipLaunchKernelGGL((skin_kernel<4, 4>), grid, dim3(kSkinBlock), 0, s, L, blocksPerChar);
+    if (ss == 3 && ds == 3) hipLaunchKernelGGL((skin_kernel<3, 3>), grid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit);
+    else if (ss == 3 && ds == 4) hipLaunchKernelGGL((skin_kernel<3, 4>), grid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit);
+    else if (ss == 4 && ds == 3) hipLaunchKernelGGL((skin_kernel<4, 3>), grid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit);
+    else hipLaunchKernelGGL((skin_kernel<4, 4>), grid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit);
 }
 
 } // namespace sge
