@@ -45,6 +45,7 @@ struct CastRec { float toi; F3 position, normal, triNormal; int triIndex; };
 struct WaveShared {
     int stack[kStackCap];
     int cand[kCandCap];
+    CastRec laneCast[kWave]; // each lane's accepted hit of the current batch
     CastRec bestCast;
     OverlapRec ovl[SGE_MAX_OVERLAP_HITS];
     OverlapRec ovlTmp[SGE_MAX_OVERLAP_HITS];
@@ -54,6 +55,11 @@ struct WaveStats { unsigned int queries, candidates, evals, overflow; };
 
 // One instance per 64-thread workgroup (= per character / per query).
 __shared__ WaveShared sh;
+// The wave-uniform per-character state lives in LDS, not in registers: it is touched only
+// between queries, and every lane reads/writes the same value in lockstep.
+__shared__ sge_body_state sBody;
+__shared__ sge_controller_params sParams;
+__shared__ sge_controller_state sCtrl;
 
 __device__ __forceinline__ int laneId() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ int prefixCount(unsigned long long m) {
@@ -256,7 +262,7 @@ __device__ __forceinline__ Tri loadTri(const DevCollision& col, int slot) {
 // ---------------------------------------------------------------------------
 enum { PH_MARCH = 0, PH_REFINE = 1, PH_FINAL = 2, PH_DONE = 3 };
 
-__device__ __noinline__ bool waveCapsuleCast(const DevCollision& col, F3 from, F3 delta, float radius,
+__device__ __forceinline__ bool waveCapsuleCast(const DevCollision& col, F3 from, F3 delta, float radius,
                                              float halfHeight, bool blockingOnly, bool hasMinNormalY, float minNormalY,
                                              uint32_t mask, CastRec& out, WaveStats& st) {
     const int lane = laneId();
@@ -301,8 +307,6 @@ __device__ __noinline__ bool waveCapsuleCast(const DevCollision& col, F3 from, F
         float t = 0, lastSafeT = 0, lo = 0, hi = 0, tEval = 0;
         int iter = 0, refineK = 0;
         unsigned long long myKey = ~0ull;
-        CastRec mine;
-        mine.toi = 0; mine.position = mine.normal = mine.triNormal = F3{0, 0, 0}; mine.triIndex = -1;
 
         while (__any(phase != PH_DONE)) {
             if (phase == PH_MARCH) {
@@ -349,7 +353,7 @@ __device__ __noinline__ bool waveCapsuleCast(const DevCollision& col, F3 from, F
                     if (ok && blockingOnly) ok = !(dot(delta, nrm) >= 0) && !(dot(delta, triN) >= 0);
                     if (ok && hasMinNormalY) ok = !(triN.y < minNormalY);
                     if (ok) {
-                        mine.toi = tHit; mine.position = triP; mine.normal = nrm; mine.triNormal = triN; mine.triIndex = tri.triIndex;
+                        sh.laneCast[lane] = CastRec{tHit, triP, nrm, triN, tri.triIndex};
                         myKey = ((unsigned long long)__float_as_uint(tHit) << 32) | (unsigned)tri.rank;
                     }
                 }
@@ -364,7 +368,7 @@ __device__ __noinline__ bool waveCapsuleCast(const DevCollision& col, F3 from, F
         unsigned long long k = waveMinU64(myKey);
         if (k < bestKey) {
             bestKey = k;
-            if (myKey == k) sh.bestCast = mine;
+            if (myKey == k) sh.bestCast = sh.laneCast[lane];
         }
         __syncthreads();
     }
@@ -378,7 +382,7 @@ __device__ __noinline__ bool waveCapsuleCast(const DevCollision& col, F3 from, F
 // capsuleOverlapAll over the static set (CollisionQuery.swift:852-882, 1201-1283):
 // the first `maxHits` overlapping triangles in visit order = the maxHits lowest ranks
 // ---------------------------------------------------------------------------
-__device__ __noinline__ int waveCapsuleOverlapAll(const DevCollision& col, F3 from, float radius,
+__device__ __forceinline__ int waveCapsuleOverlapAll(const DevCollision& col, F3 from, float radius,
                                                   float halfHeight, int maxHits, uint32_t mask, WaveStats& st) {
     const int lane = laneId();
     if (col.root < 0) return 0;
@@ -614,7 +618,7 @@ __device__ __forceinline__ bool capsuleCapsuleSweep(F3 from, F3 delta, float rad
 // hit, so the wave scans the grid cells covering that reach, 64 agents at a time, and
 // reduces on (toi, agent index) — the index reproduces the reference's first-wins
 // `<` over its (index-ordered) snapshot.
-__device__ __noinline__ bool waveAgentBestHit(const DevAgents& ag, F3 position, F3 remaining, float remainingLen,
+__device__ __forceinline__ bool waveAgentBestHit(const DevAgents& ag, F3 position, F3 remaining, float remainingLen,
                                               float baseMoveLen, float dt, int selfIndex, float selfRadius,
                                               float halfHeight, float maxAgentRadius, float maxAgentSpeed,
                                               float& toiOut, F3& normalOut) {
@@ -771,70 +775,145 @@ __device__ __forceinline__ bool resolveHit(F3& remaining, float len, const Slide
     return false;
 }
 
-__global__ __launch_bounds__(kWave) void move_kernel(MoveLaunch K) {
+// Wave-uniform working set of one character step, kept in LDS between queries (every lane
+// reads and writes the same values in lockstep) so that the two big query loops, each
+// instantiated exactly once below, do not have to carry it in registers.
+struct MoveState {
+    F3 position, remaining;
+    D3 velocity;
+    int phase, it;
+    // depenetration
+    int didResolve; F3 normalSum; float normalWeight;
+    // slide
+    float baseMoveLen; int haveLast; F3 lastSlideNormal;
+    // ground probe
+    CastRec centerHit; int haveCenter; float gDistance; F3 gNormalSum; int sampleK;
+    int nearGround, canSnap, gGrounded, gNear;
+    int wasGrounded, wasGroundedNear;
+};
+__shared__ MoveState ms;
+
+enum { MP_DEPEN = 0, MP_SLIDE = 1, MP_GROUND_CENTER = 2, MP_GROUND_FALL = 3, MP_GROUND_EVAL = 4, MP_GROUND_SAMPLE = 5,
+       MP_FINISH = 6, MP_DONE = 7 };
+
+__global__ __launch_bounds__(kWave, 4) void move_kernel(MoveLaunch K) {
     const int e = K.first + blockIdx.x;
     const int lane = laneId();
     WaveStats st{0, 0, 0, 0};
     const DevCollision& col = K.col;
-
-    sge_body_state body = K.crowd.bodies[e];
-    const sge_controller_params P = K.crowd.params[e];
-    sge_controller_state C = K.crowd.controllers[e];
+    {   // 288 B of state: lanes copy dwords
+        const uint32_t* gb = reinterpret_cast<const uint32_t*>(K.crowd.bodies + e);
+        const uint32_t* gp = reinterpret_cast<const uint32_t*>(K.crowd.params + e);
+        const uint32_t* gc = reinterpret_cast<const uint32_t*>(K.crowd.controllers + e);
+        if (lane < 24) reinterpret_cast<uint32_t*>(&sBody)[lane] = gb[lane];
+        if (lane < 16) reinterpret_cast<uint32_t*>(&sParams)[lane] = gp[lane];
+        if (lane < 32) reinterpret_cast<uint32_t*>(&sCtrl)[lane] = gc[lane];
+        __syncthreads();
+    }
+    sge_body_state& body = sBody;
+    const sge_controller_params& P = sParams;
+    sge_controller_state& C = sCtrl;
     const float dt = K.dt;
     const F3 gravity{K.gx, K.gy, K.gz};
-    D3 velocity{body.linearVelocity[0], body.linearVelocity[1], body.linearVelocity[2]};
-
-    // ---- PhysicsIntentSystem, controller branch (Systems.swift:217-247) ----
-    if (K.stages & SGE_STAGE_INTENT) {
-        const sge_move_intent in = K.crowd.intents[e];
-        if ((in.flags & SGE_INTENT_PRESENT) && (body.bodyType == SGE_BODY_DYNAMIC || body.bodyType == SGE_BODY_KINEMATIC)) {
-            if (in.flags & SGE_INTENT_DODGE_ACTIVE) {
-                velocity.x = (double)in.desiredVelocity[0];
-                velocity.z = (double)in.desiredVelocity[2];
-            } else {
-                D3 target{(double)in.desiredVelocity[0], 0.0, (double)in.desiredVelocity[2]};
-                D3 current{velocity.x, 0.0, velocity.z};
-                float accel = length(target) >= length(current) ? in.maxAcceleration : in.maxDeceleration;
-                D3 next = approachVecD(current, target, (double)accel * (double)dt);
-                velocity.x = next.x;
-                velocity.z = next.z;
-            }
-            if (in.flags & SGE_INTENT_HAS_FACING_YAW) {
-                Quat q = quatAngleAxis(in.desiredFacingYaw, F3{0, 1, 0});
-                body.rotation[0] = q.x; body.rotation[1] = q.y; body.rotation[2] = q.z; body.rotation[3] = q.w;
+    {
+        D3 velocity{body.linearVelocity[0], body.linearVelocity[1], body.linearVelocity[2]};
+        // ---- PhysicsIntentSystem, controller branch (Systems.swift:217-247) ----
+        if (K.stages & SGE_STAGE_INTENT) {
+            const sge_move_intent in = K.crowd.intents[e];
+            if ((in.flags & SGE_INTENT_PRESENT) && (body.bodyType == SGE_BODY_DYNAMIC || body.bodyType == SGE_BODY_KINEMATIC)) {
+                if (in.flags & SGE_INTENT_DODGE_ACTIVE) {
+                    velocity.x = (double)in.desiredVelocity[0];
+                    velocity.z = (double)in.desiredVelocity[2];
+                } else {
+                    D3 target{(double)in.desiredVelocity[0], 0.0, (double)in.desiredVelocity[2]};
+                    D3 current{velocity.x, 0.0, velocity.z};
+                    float accel = length(target) >= length(current) ? in.maxAcceleration : in.maxDeceleration;
+                    D3 next = approachVecD(current, target, (double)accel * (double)dt);
+                    velocity.x = next.x;
+                    velocity.z = next.z;
+                }
+                if (in.flags & SGE_INTENT_HAS_FACING_YAW) {
+                    Quat q = quatAngleAxis(in.desiredFacingYaw, F3{0, 1, 0});
+                    body.rotation[0] = q.x; body.rotation[1] = q.y; body.rotation[2] = q.z; body.rotation[3] = q.w;
+                }
             }
         }
+        // ---- GravitySystem (Systems.swift:609-618) ----
+        if ((K.stages & SGE_STAGE_GRAVITY) && body.bodyType == SGE_BODY_DYNAMIC &&
+            !((C.flags & SGE_CTRL_GROUNDED) && (C.flags & SGE_CTRL_GROUNDED_NEAR))) {
+            velocity = velocity + toD(gravity) * (double)dt;
+        }
+        ms.velocity = velocity;
     }
-    // ---- GravitySystem (Systems.swift:609-618) ----
-    if ((K.stages & SGE_STAGE_GRAVITY) && body.bodyType == SGE_BODY_DYNAMIC &&
-        !((C.flags & SGE_CTRL_GROUNDED) && (C.flags & SGE_CTRL_GROUNDED_NEAR))) {
-        velocity = velocity + toD(gravity) * (double)dt;
-    }
+    ms.position = toF(D3{body.position[0], body.position[1], body.position[2]});
+    ms.phase = MP_DONE;
 
-    F3 position = toF(D3{body.position[0], body.position[1], body.position[2]});
-    if ((K.stages & SGE_STAGE_MOVE) && body.bodyType != SGE_BODY_STATIC) {
+    const bool doMove = (K.stages & SGE_STAGE_MOVE) && body.bodyType != SGE_BODY_STATIC;
+    const bool hasAgent = (P.agentFlags & SGE_AGENT_PRESENT) != 0;
+    const bool selfSolid = hasAgent && (P.agentFlags & SGE_AGENT_SOLID);
+    const bool useAgents = (K.stages & SGE_STAGE_AGENTS) && selfSolid && K.agents.all != nullptr;
+    if (doMove) {
         cacheDecay(C);
-        const bool hasAgent = (P.agentFlags & SGE_AGENT_PRESENT) != 0;
-        const bool selfSolid = hasAgent && (P.agentFlags & SGE_AGENT_SOLID);
-        const float selfRadius = (hasAgent && (P.agentFlags & SGE_AGENT_RADIUS_OVERRIDE)) ? P.agentRadiusOverride : P.radius;
-        const bool wasGrounded = (C.flags & SGE_CTRL_GROUNDED) != 0;
-        const bool wasGroundedNear = (C.flags & SGE_CTRL_GROUNDED_NEAR) != 0;
+        ms.wasGrounded = (C.flags & SGE_CTRL_GROUNDED) != 0;
+        ms.wasGroundedNear = (C.flags & SGE_CTRL_GROUNDED_NEAR) != 0;
         // VelocityGate.apply :1037-1051
-        if (wasGrounded && wasGroundedNear && velocity.y < 0) velocity.y = 0;
+        D3 velocity = ms.velocity;
+        const bool wg = ms.wasGrounded && ms.wasGroundedNear;
+        if (wg && velocity.y < 0) velocity.y = 0;
         D3 remD = velocity * (double)dt;
-        if (wasGrounded && wasGroundedNear && remD.y < 0) remD.y = 0;
-        F3 remaining = toF(remD);
+        if (wg && remD.y < 0) remD.y = 0;
+        ms.velocity = velocity;
+        ms.remaining = toF(remD);
+        ms.phase = MP_DEPEN;
+        ms.it = 0;
+        ms.didResolve = 0; ms.normalSum = F3{0, 0, 0}; ms.normalWeight = 0;
+        ms.haveLast = 0; ms.lastSlideNormal = F3{0, 0, 0}; ms.baseMoveLen = 0;
+        ms.haveCenter = 0; ms.gDistance = kFloatMax; ms.gNormalSum = F3{0, 0, 0}; ms.sampleK = 0;
+        ms.nearGround = 0; ms.canSnap = 0; ms.gGrounded = 0; ms.gNear = 0;
+    }
+    __syncthreads();
 
-        // ---- DepenetrationResolver.resolve :734-808 + applyPreSweepDepenetration :1642-1655 ----
-        {
-            const float slop = smax(P.skinWidth * 0.5f, 0.001f);
-            bool didResolve = false;
-            F3 normalSum{0, 0, 0};
-            float normalWeight = 0;
-            for (int it = 0; it < 4; ++it) {
-                int n = waveCapsuleOverlapAll(col, position, P.radius, P.halfHeight, 8, P.collisionMask, st);
-                if (n == 0) break;
-                // stable sort by depth descending: pick the deepest and second deepest (first occurrence wins ties)
+    // Each trip issues at most one BVH query; the two query routines are inlined exactly once.
+    while (ms.phase != MP_DONE) {
+        const int phase = ms.phase;
+        // ---------------- 1. which query does this phase need? ----------------
+        bool doOverlap = false, doCast = false, blocking = false;
+        F3 qFrom = ms.position, qDelta{0, 0, 0};
+        if (phase == MP_DEPEN) {
+            doOverlap = true;
+        } else if (phase == MP_SLIDE) {
+            // head of the slide loop :1674-1676
+            float len = length(ms.remaining);
+            if (ms.it >= P.maxSlideIterations || len < 1e-6f) { ms.phase = MP_GROUND_CENTER; __syncthreads(); continue; }
+            doCast = true; blocking = true; qDelta = ms.remaining;
+        } else if (phase == MP_GROUND_CENTER) {
+            if (!(P.snapDistance > 0)) { ms.haveCenter = 0; ms.phase = MP_GROUND_FALL; __syncthreads(); continue; }
+            doCast = true; qDelta = F3{0, -1, 0} * P.snapDistance;
+        } else if (phase == MP_GROUND_FALL) {
+            if (!(P.fallProbeDistance > 0)) { ms.phase = MP_GROUND_EVAL; __syncthreads(); continue; }
+            doCast = true; qDelta = F3{0, -1, 0} * P.fallProbeDistance;
+        } else if (phase == MP_GROUND_SAMPLE) {
+            const int k = ms.sampleK;
+            float offset = P.radius * 0.6f;
+            float ox = k == 0 ? offset : (k == 1 ? -offset : 0.0f);
+            float oz = k == 2 ? offset : (k == 3 ? -offset : 0.0f);
+            qFrom = ms.position + F3{ox, 0, oz};
+            doCast = true; qDelta = F3{0, -1, 0} * P.snapDistance;
+        }
+        // ---------------- 2. the query ----------------
+        int nOverlap = 0;
+        bool gotCast = false;
+        CastRec rec;
+        rec.toi = 0; rec.position = rec.normal = rec.triNormal = F3{0, 0, 0}; rec.triIndex = -1;
+        if (doOverlap) nOverlap = waveCapsuleOverlapAll(col, qFrom, P.radius, P.halfHeight, 8, P.collisionMask, st);
+        if (doCast) gotCast = waveCapsuleCast(col, qFrom, qDelta, P.radius, P.halfHeight, blocking, !blocking, P.minGroundDot,
+                                              P.collisionMask, rec, st);
+        // ---------------- 3. consume ----------------
+        if (phase == MP_DEPEN) { // DepenetrationResolver.resolve :734-808, one iteration
+            bool stop = nOverlap == 0;
+            if (!stop) {
+                const int n = nOverlap;
+                // stable sort by depth descending: deepest and second deepest (first occurrence wins ties)
                 int i0 = 0;
                 for (int k = 1; k < n; ++k) if (sh.ovl[k].depth > sh.ovl[i0].depth) i0 = k;
                 int i1 = -1;
@@ -845,6 +924,7 @@ __global__ __launch_bounds__(kWave) void move_kernel(MoveLaunch K) {
                 OverlapRec deepest = sh.ovl[i0];
                 OverlapRec second = i1 >= 0 ? sh.ovl[i1] : deepest;
                 __syncthreads();
+                const float slop = smax(P.skinWidth * 0.5f, 0.001f);
                 bool sideContact = deepest.normal.y < P.minGroundDot;
                 int useCount = sideContact ? 1 : (n < 2 ? n : 2);
                 float maxDepth = deepest.depth;
@@ -861,234 +941,255 @@ __global__ __launch_bounds__(kWave) void move_kernel(MoveLaunch K) {
                 F3 depenNormal = frameNormalLen > 1e-6f ? frameNormal / frameNormalLen : frameNormal;
                 float push = sideContact ? smax(maxDepth, 0.0f) : smax(maxDepth + slop, 0.0f);
                 if (sideContact) push = smin(push, P.skinWidth);
-                if (push <= 1e-6f) break;
-                position = position + depenNormal * push;
-                D3 dn = toD(depenNormal);
-                double vInto = dot(velocity, dn);
-                if (vInto < 0) velocity = velocity - dn * vInto;
-                didResolve = true;
-                normalSum = normalSum + depenNormal * maxDepth;
-                normalWeight += maxDepth;
-            }
-            if (didResolve) {
-                F3 depenNormal = normalWeight > 1e-6f ? normalize(normalSum / normalWeight) : normalize(normalSum);
-                float into = dot(remaining, depenNormal);
-                if (into < 0) remaining = remaining - depenNormal * into;
-            }
-        }
-
-        // ---- resolveKinematicSweep :1658-1765 ----
-        {
-            F3 baseMove = toF(velocity) * dt;
-            float baseMoveLen = length(baseMove);
-            bool haveLast = false;
-            F3 lastSlideNormal{0, 0, 0};
-            const bool useAgents = (K.stages & SGE_STAGE_AGENTS) && selfSolid && K.agents.all != nullptr;
-            for (int it = 0; it < P.maxSlideIterations; ++it) {
-                float len = length(remaining);
-                if (len < 1e-6f) break;
-                SlideHit hit;
-                hit.aToi = 0; hit.aNormal = F3{0, 0, 0};
-                bool haveStatic = waveCapsuleCast(col, position, remaining, P.radius, P.halfHeight, true, false, 0.0f,
-                                                  P.collisionMask, hit.s, st);
-                if (haveStatic && hit.s.normal.y < P.minGroundDot && C.sideContactFrames > 0) {
-                    F3 cached;
-                    if (cachedNormal(C, hit.s.triIndex, cached)) {
-                        if (dot(cached, hit.s.normal) < 0) cached = -cached;
-                        hit.s.normal = cached;
-                    }
+                if (push <= 1e-6f) {
+                    stop = true;
+                } else {
+                    ms.position = ms.position + depenNormal * push;
+                    D3 dn = toD(depenNormal);
+                    D3 velocity = ms.velocity;
+                    double vInto = dot(velocity, dn);
+                    if (vInto < 0) velocity = velocity - dn * vInto;
+                    ms.velocity = velocity;
+                    ms.didResolve = 1;
+                    ms.normalSum = ms.normalSum + depenNormal * maxDepth;
+                    ms.normalWeight += maxDepth;
+                    ms.it += 1;
+                    if (ms.it >= 4) stop = true;
                 }
-                bool haveAgent = false;
-                if (useAgents)
-                    haveAgent = waveAgentBestHit(K.agents, position, remaining, len, baseMoveLen, dt, K.agents.selfOffset + e,
-                                                 selfRadius, P.halfHeight, K.agents.maxRadius, K.agents.maxSpeed, hit.aToi, hit.aNormal);
-                if (haveStatic || haveAgent) {
-                    if (haveStatic && haveAgent) { // HitSelector.selectBestHit :1382-1390
-                        float staticSkin = hit.s.normal.y >= P.minGroundDot ? P.groundSnapSkin : P.skinWidth;
-                        float staticStop = smax(hit.s.toi - staticSkin, 0.0f);
-                        float agentStop = smax(hit.aToi, 0.0f);
-                        hit.isStatic = staticStop <= agentStop;
-                    } else {
-                        hit.isStatic = haveStatic;
-                    }
-                    F3 hitNormal = hit.isStatic ? hit.s.normal : hit.aNormal;
-                    bool hasCachedSide = false;
-                    F3 cachedSide{0, 0, 0};
-                    if (hit.isStatic && hit.s.normal.y < P.minGroundDot && C.sideContactFrames > 0)
-                        hasCachedSide = cachedNormal(C, hit.s.triIndex, cachedSide);
-                    bool shouldBreak = resolveHit(remaining, len, hit, P, C, wasGrounded, wasGroundedNear, velocity, position,
-                                                  hasCachedSide, cachedSide);
-                    if (hit.isStatic && hit.s.normal.y < P.minGroundDot) cacheRecord(C, hit.s.triIndex, hit.s.normal, true);
-                    if (haveLast) {
-                        float dotN = dot(lastSlideNormal, hitNormal);
-                        if (fabsf(dotN) < 0.98f) {
-                            F3 axis = cross(lastSlideNormal, hitNormal);
-                            float axisLen = length(axis);
-                            if (axisLen > 1e-5f) {
-                                F3 axisN = axis / axisLen;
-                                remaining = axisN * dot(remaining, axisN);
-                            }
+            }
+            if (stop) {
+                if (ms.didResolve) { // applyPreSweepDepenetration :1651-1654
+                    F3 depenNormal = ms.normalWeight > 1e-6f ? normalize(ms.normalSum / ms.normalWeight) : normalize(ms.normalSum);
+                    float into = dot(ms.remaining, depenNormal);
+                    if (into < 0) ms.remaining = ms.remaining - depenNormal * into;
+                }
+                // resolveKinematicSweep prologue :1671-1673
+                F3 baseMove = toF(ms.velocity) * dt;
+                ms.baseMoveLen = length(baseMove);
+                ms.it = 0;
+                ms.phase = MP_SLIDE;
+            }
+        } else if (phase == MP_SLIDE) { // one iteration of resolveKinematicSweep :1674-1764
+            F3 remaining = ms.remaining, position = ms.position;
+            D3 velocity = ms.velocity;
+            const float len = length(remaining);
+            SlideHit hit;
+            hit.s = rec; hit.aToi = 0; hit.aNormal = F3{0, 0, 0}; hit.isStatic = true;
+            bool haveStatic = gotCast;
+            if (haveStatic && hit.s.normal.y < P.minGroundDot && C.sideContactFrames > 0) {
+                F3 cached;
+                if (cachedNormal(C, hit.s.triIndex, cached)) {
+                    if (dot(cached, hit.s.normal) < 0) cached = -cached;
+                    hit.s.normal = cached;
+                }
+            }
+            bool haveAgent = false;
+            if (useAgents) {
+                const float selfRadius = (hasAgent && (P.agentFlags & SGE_AGENT_RADIUS_OVERRIDE)) ? P.agentRadiusOverride : P.radius;
+                haveAgent = waveAgentBestHit(K.agents, position, remaining, len, ms.baseMoveLen, dt, K.agents.selfOffset + e,
+                                             selfRadius, P.halfHeight, K.agents.maxRadius, K.agents.maxSpeed, hit.aToi, hit.aNormal);
+            }
+            bool endSlide = false;
+            if (haveStatic || haveAgent) {
+                if (haveStatic && haveAgent) { // HitSelector.selectBestHit :1382-1390
+                    float staticSkin = hit.s.normal.y >= P.minGroundDot ? P.groundSnapSkin : P.skinWidth;
+                    float staticStop = smax(hit.s.toi - staticSkin, 0.0f);
+                    float agentStop = smax(hit.aToi, 0.0f);
+                    hit.isStatic = staticStop <= agentStop;
+                } else {
+                    hit.isStatic = haveStatic;
+                }
+                F3 hitNormal = hit.isStatic ? hit.s.normal : hit.aNormal;
+                bool hasCachedSide = false;
+                F3 cachedSide{0, 0, 0};
+                if (hit.isStatic && hit.s.normal.y < P.minGroundDot && C.sideContactFrames > 0)
+                    hasCachedSide = cachedNormal(C, hit.s.triIndex, cachedSide);
+                bool shouldBreak = resolveHit(remaining, len, hit, P, C, ms.wasGrounded != 0, ms.wasGroundedNear != 0, velocity,
+                                              position, hasCachedSide, cachedSide);
+                if (hit.isStatic && hit.s.normal.y < P.minGroundDot) cacheRecord(C, hit.s.triIndex, hit.s.normal, true);
+                if (ms.haveLast) {
+                    F3 last = ms.lastSlideNormal;
+                    float dotN = dot(last, hitNormal);
+                    if (fabsf(dotN) < 0.98f) {
+                        F3 axis = cross(last, hitNormal);
+                        float axisLen = length(axis);
+                        if (axisLen > 1e-5f) {
+                            F3 axisN = axis / axisLen;
+                            remaining = axisN * dot(remaining, axisN);
                         }
                     }
-                    lastSlideNormal = hitNormal;
-                    haveLast = true;
-                    if (shouldBreak) break;
-                } else {
-                    position = position + remaining;
-                    remaining = F3{0, 0, 0};
-                    break;
                 }
+                ms.lastSlideNormal = hitNormal;
+                ms.haveLast = 1;
+                endSlide = shouldBreak;
+            } else {
+                position = position + remaining;
+                remaining = F3{0, 0, 0};
+                endSlide = true;
             }
+            ms.remaining = remaining; ms.position = position; ms.velocity = velocity;
+            ms.it += 1;
+            if (endSlide) ms.phase = MP_GROUND_CENTER;
+        } else if (phase == MP_GROUND_CENTER) { // GroundProbe.resolve :844-853
+            ms.haveCenter = gotCast ? 1 : 0;
+            if (gotCast) ms.centerHit = rec;
+            ms.phase = MP_GROUND_FALL;
+        } else if (phase == MP_GROUND_FALL) { // :855-866
+            if (gotCast) ms.gDistance = rec.toi;
+            ms.phase = MP_GROUND_EVAL;
+        } else if (phase == MP_GROUND_SAMPLE) { // :906-921
+            const CastRec c = ms.centerHit;
+            float combineTol = smax(smax(P.groundSnapSkin, P.skinWidth), 0.05f);
+            if (gotCast && rec.toi <= c.toi + combineTol) {
+                if (dot(rec.triNormal, c.triNormal) > 0.98f) ms.gNormalSum = ms.gNormalSum + rec.triNormal;
+            }
+            ms.sampleK += 1;
+            if (ms.sampleK >= 4) ms.phase = MP_FINISH;
         }
-
-        // ---- resolveGroundContact :1767-1800: GroundProbe.resolve :826-943 ----
-        bool gGrounded = false, gNear = false, canSnap = false, nearGround = false, haveCenter = false;
-        F3 gNormal{0, 1, 0};
-        DevMaterial gMat{0.8f, 0.6f, 0};
-        int gTri = -1;
-        float gDistance = kFloatMax;
-        CastRec centerHit;
-        {
-            const F3 down{0, -1, 0};
-            const F3 snapDelta = down * P.snapDistance;
-            if (P.snapDistance > 0)
-                haveCenter = waveCapsuleCast(col, position, snapDelta, P.radius, P.halfHeight, false, true, P.minGroundDot,
-                                             P.collisionMask, centerHit, st);
-            if (P.fallProbeDistance > 0) {
-                CastRec fallHit;
-                if (waveCapsuleCast(col, position, down * P.fallProbeDistance, P.radius, P.halfHeight, false, true,
-                                    P.minGroundDot, P.collisionMask, fallHit, st))
-                    gDistance = fallHit.toi;
-            }
-            if (haveCenter && centerHit.toi <= P.snapDistance) {
-                const F3 prevNormal = ld3(C.groundNormal);
+        __syncthreads();
+        if (ms.phase == MP_GROUND_EVAL) { // :868-894 — decides whether the four offset casts are needed
+            const CastRec centerHit = ms.centerHit;
+            if (ms.haveCenter && centerHit.toi <= P.snapDistance) {
+                const F3 position = ms.position;
+                const D3 velocity = ms.velocity;
                 float baseCenterY = position.y - P.halfHeight;
                 float bottomY = baseCenterY - P.radius;
                 float groundTol = smax(P.skinWidth, P.groundSnapSkin);
                 bool validGroundPoint = centerHit.position.y <= bottomY + groundTol;
                 float groundNearThreshold = smax(P.groundSnapSkin, P.skinWidth);
-                nearGround = centerHit.toi <= groundNearThreshold;
-                gNear = nearGround;
-                gDistance = centerHit.toi;
+                bool nearGround = centerHit.toi <= groundNearThreshold;
                 bool groundGateVel = velocity.y <= 0;
                 double vInto = dot(velocity, toD(centerHit.normal));
                 bool groundGateSpeed = vInto >= -(double)P.groundSnapMaxSpeed;
                 bool groundGateToi = centerHit.toi <= P.groundSnapMaxToi;
-                canSnap = validGroundPoint && groundGateVel && (nearGround || groundGateSpeed || groundGateToi);
-                if (wasGroundedNear && centerHit.toi <= P.snapDistance) canSnap = validGroundPoint;
+                bool canSnap = validGroundPoint && groundGateVel && (nearGround || groundGateSpeed || groundGateToi);
+                if (ms.wasGroundedNear && centerHit.toi <= P.snapDistance) canSnap = validGroundPoint;
+                ms.nearGround = nearGround; ms.gNear = nearGround; ms.canSnap = canSnap;
+                ms.gDistance = centerHit.toi;
+                ms.phase = MP_FINISH;
                 if (validGroundPoint && (nearGround || canSnap)) {
-                    gGrounded = true;
-                    gMat = col.materials[centerHit.triIndex];
-                    gTri = centerHit.triIndex;
-                    F3 normalSum = centerHit.triNormal;
-                    if (centerHit.triNormal.y < 0.98f && (wasGroundedNear || nearGround)) {
-                        float offset = P.radius * 0.6f;
-                        float combineTol = smax(smax(P.groundSnapSkin, P.skinWidth), 0.05f);
-                        for (int k = 0; k < 4; ++k) {
-                            float ox = k == 0 ? offset : (k == 1 ? -offset : 0.0f);
-                            float oz = k == 2 ? offset : (k == 3 ? -offset : 0.0f);
-                            F3 samplePos = position + F3{ox, 0, oz};
-                            CastRec sHit;
-                            if (waveCapsuleCast(col, samplePos, snapDelta, P.radius, P.halfHeight, false, true, P.minGroundDot,
-                                                P.collisionMask, sHit, st) &&
-                                sHit.toi <= centerHit.toi + combineTol) {
-                                if (dot(sHit.triNormal, centerHit.triNormal) > 0.98f) normalSum = normalSum + sHit.triNormal;
-                            }
-                        }
-                    }
-                    float nLen = length(normalSum);
-                    gNormal = nLen > 1e-6f ? normalSum / nLen : centerHit.triNormal;
+                    ms.gGrounded = 1;
+                    ms.gNormalSum = centerHit.triNormal;
+                    if (centerHit.triNormal.y < 0.98f && (ms.wasGroundedNear || nearGround)) { ms.sampleK = 0; ms.phase = MP_GROUND_SAMPLE; }
                 }
-                if (gGrounded && wasGroundedNear) {
+            } else {
+                ms.haveCenter = 0; // guard failed: GroundProbeResult(hit: nil), canSnap false
+                ms.phase = MP_FINISH;
+            }
+            __syncthreads();
+        }
+        if (ms.phase == MP_FINISH) {
+            F3 position = ms.position;
+            D3 velocity = ms.velocity;
+            const CastRec centerHit = ms.centerHit;
+            const bool gGrounded = ms.gGrounded != 0;
+            F3 gNormal{0, 1, 0};
+            DevMaterial gMat{0.8f, 0.6f, 0};
+            int gTri = -1;
+            if (gGrounded) { // :890-937
+                gMat = col.materials[centerHit.triIndex];
+                gTri = centerHit.triIndex;
+                F3 normalSum = ms.gNormalSum;
+                float nLen = length(normalSum);
+                gNormal = nLen > 1e-6f ? normalSum / nLen : centerHit.triNormal;
+                if (ms.wasGroundedNear) {
+                    const F3 prevNormal = ld3(C.groundNormal);
                     float dotN = dot(prevNormal, gNormal);
                     if (dotN > 0.9f) {
                         const float blend = 0.2f;
                         gNormal = normalize(prevNormal * (1 - blend) + gNormal * blend);
                     }
                 }
-                if (gGrounded && gMat.flatten) gNormal = F3{0, 1, 0};
-            } else {
-                haveCenter = false; // guard failed: GroundProbeResult(hit: nil)
+                if (gMat.flatten) gNormal = F3{0, 1, 0};
             }
-        }
-        // GroundSnap.apply :945-963
-        if (canSnap && haveCenter) {
-            float rawMove = smax(centerHit.toi - P.groundSnapSkin, 0.0f);
-            float moveDist = rawMove;
-            if (nearGround && moveDist > P.groundSnapMaxStep) moveDist = P.groundSnapMaxStep;
-            position = position + F3{0, -1, 0} * moveDist;
-            D3 nD = toD(centerHit.normal);
-            double vIntoSnap = dot(velocity, nD);
-            if (vIntoSnap < 0) velocity = velocity - nD * vIntoSnap;
-        }
-        if (gGrounded) {
-            float normalUpDelta = gNormal.y - C.groundNormal[1];
-            if (gTri != C.groundTriangleIndex && normalUpDelta > 0.02f) C.groundTransitionFrames = 3;
-        }
-        // SlopeFriction.apply :965-1021
-        if (!gGrounded) {
-            C.flags &= ~(uint32_t)SGE_CTRL_GROUND_SLIDING;
-        } else {
-            F3 normal = normalize(gNormal);
-            if (normal.y > 0.98f) {
-                C.groundTransitionFrames = 0;
-                C.flags &= ~(uint32_t)SGE_CTRL_GROUND_SLIDING;
-            } else if (C.groundTransitionFrames > 0) {
-                C.groundTransitionFrames -= 1;
+            // GroundSnap.apply :945-963
+            if (ms.canSnap && ms.haveCenter) {
+                float rawMove = smax(centerHit.toi - P.groundSnapSkin, 0.0f);
+                float moveDist = rawMove;
+                if (ms.nearGround && moveDist > P.groundSnapMaxStep) moveDist = P.groundSnapMaxStep;
+                position = position + F3{0, -1, 0} * moveDist;
+                D3 nD = toD(centerHit.normal);
+                double vIntoSnap = dot(velocity, nD);
+                if (vIntoSnap < 0) velocity = velocity - nD * vIntoSnap;
+            }
+            if (gGrounded) { // resolveGroundContact :1787-1792
+                float normalUpDelta = gNormal.y - C.groundNormal[1];
+                if (gTri != C.groundTriangleIndex && normalUpDelta > 0.02f) C.groundTransitionFrames = 3;
+            }
+            // SlopeFriction.apply :965-1021
+            if (!gGrounded) {
                 C.flags &= ~(uint32_t)SGE_CTRL_GROUND_SLIDING;
             } else {
-                float gN = dot(gravity, normal);
-                F3 gTan = gravity - normal * gN;
-                float gTanLen = length(gTan);
-                if (gTanLen > 0.5f) {
-                    float gNMag = fabsf(gN);
-                    F3 gTanDir = gTan / gTanLen;
-                    D3 gTanDirD = toD(gTanDir), normalD = toD(normal);
-                    float stickLimit = gMat.muS * gNMag;
-                    bool enterSlide = gTanLen > stickLimit * 1.05f;
-                    bool exitSlide = gTanLen < stickLimit * 0.9f;
-                    bool sliding = (C.flags & SGE_CTRL_GROUND_SLIDING) != 0;
-                    if (sliding) { if (exitSlide) sliding = false; }
-                    else if (enterSlide) sliding = true;
-                    if (sliding) C.flags |= SGE_CTRL_GROUND_SLIDING; else C.flags &= ~(uint32_t)SGE_CTRL_GROUND_SLIDING;
-                    if (!sliding && gTanLen <= stickLimit) {
-                        D3 vTan = velocity - normalD * dot(velocity, normalD);
-                        double downhillSpeed = dot(vTan, gTanDirD);
-                        if (downhillSpeed > 0) velocity = velocity - gTanDirD * downhillSpeed;
-                    } else {
-                        float slideAccelMag = smax(gTanLen - gMat.muK * gNMag, 0.0f);
-                        if (slideAccelMag > 0) velocity = velocity + gTanDirD * (double)slideAccelMag * (double)dt;
+                F3 normal = normalize(gNormal);
+                if (normal.y > 0.98f) {
+                    C.groundTransitionFrames = 0;
+                    C.flags &= ~(uint32_t)SGE_CTRL_GROUND_SLIDING;
+                } else if (C.groundTransitionFrames > 0) {
+                    C.groundTransitionFrames -= 1;
+                    C.flags &= ~(uint32_t)SGE_CTRL_GROUND_SLIDING;
+                } else {
+                    float gN = dot(gravity, normal);
+                    F3 gTan = gravity - normal * gN;
+                    float gTanLen = length(gTan);
+                    if (gTanLen > 0.5f) {
+                        float gNMag = fabsf(gN);
+                        F3 gTanDir = gTan / gTanLen;
+                        D3 gTanDirD = toD(gTanDir), normalD = toD(normal);
+                        float stickLimit = gMat.muS * gNMag;
+                        bool enterSlide = gTanLen > stickLimit * 1.05f;
+                        bool exitSlide = gTanLen < stickLimit * 0.9f;
+                        bool sliding = (C.flags & SGE_CTRL_GROUND_SLIDING) != 0;
+                        if (sliding) { if (exitSlide) sliding = false; }
+                        else if (enterSlide) sliding = true;
+                        if (sliding) C.flags |= SGE_CTRL_GROUND_SLIDING; else C.flags &= ~(uint32_t)SGE_CTRL_GROUND_SLIDING;
+                        if (!sliding && gTanLen <= stickLimit) {
+                            D3 vTan = velocity - normalD * dot(velocity, normalD);
+                            double downhillSpeed = dot(vTan, gTanDirD);
+                            if (downhillSpeed > 0) velocity = velocity - gTanDirD * downhillSpeed;
+                        } else {
+                            float slideAccelMag = smax(gTanLen - gMat.muK * gNMag, 0.0f);
+                            if (slideAccelMag > 0) velocity = velocity + gTanDirD * (double)slideAccelMag * (double)dt;
+                        }
                     }
                 }
             }
+            // writeBack :1802-1821
+            D3 pd = toD(position);
+            body.position[0] = pd.x; body.position[1] = pd.y; body.position[2] = pd.z;
+            C.flags &= ~(uint32_t)(SGE_CTRL_GROUNDED | SGE_CTRL_GROUNDED_NEAR);
+            if (gGrounded) C.flags |= SGE_CTRL_GROUNDED;
+            if (ms.gNear) C.flags |= SGE_CTRL_GROUNDED_NEAR;
+            st3(C.groundNormal, gGrounded ? gNormal : F3{0, 1, 0});
+            C.groundDistance = ms.gDistance;
+            if (gGrounded) C.groundTriangleIndex = gTri;
+            ms.velocity = velocity;
+            ms.phase = MP_DONE;
+            __syncthreads();
         }
-        // writeBack :1802-1821
-        D3 pd = toD(position);
-        body.position[0] = pd.x; body.position[1] = pd.y; body.position[2] = pd.z;
-        C.flags &= ~(uint32_t)(SGE_CTRL_GROUNDED | SGE_CTRL_GROUNDED_NEAR);
-        if (gGrounded) C.flags |= SGE_CTRL_GROUNDED;
-        if (gNear) C.flags |= SGE_CTRL_GROUNDED_NEAR;
-        st3(C.groundNormal, gGrounded ? gNormal : F3{0, 1, 0});
-        C.groundDistance = gDistance;
-        if (gGrounded) C.groundTriangleIndex = gTri;
     }
 
-    if (lane == 0) {
+    {
+        D3 velocity = ms.velocity;
         body.linearVelocity[0] = velocity.x; body.linearVelocity[1] = velocity.y; body.linearVelocity[2] = velocity.z;
-        K.crowd.bodies[e] = body;
-        K.crowd.controllers[e] = C;
-        if (K.stats) {
-            atomicAdd(&K.stats[0], (unsigned long long)st.queries);
-            atomicAdd(&K.stats[1], (unsigned long long)st.candidates);
-            atomicAdd(&K.stats[3], (unsigned long long)st.overflow);
-        }
+    }
+    __syncthreads();
+    {
+        uint32_t* gb = reinterpret_cast<uint32_t*>(K.crowd.bodies + e);
+        uint32_t* gc = reinterpret_cast<uint32_t*>(K.crowd.controllers + e);
+        if (lane < 24) gb[lane] = reinterpret_cast<const uint32_t*>(&sBody)[lane];
+        if (lane < 32) gc[lane] = reinterpret_cast<const uint32_t*>(&sCtrl)[lane];
     }
     if (K.stats) {
         // evals are counted per lane; sum over the wave
         unsigned v = st.evals;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
-        if (lane == 0) atomicAdd(&K.stats[2], (unsigned long long)v);
+        if (lane == 0) {
+            atomicAdd(&K.stats[0], (unsigned long long)st.queries);
+            atomicAdd(&K.stats[1], (unsigned long long)st.candidates);
+            atomicAdd(&K.stats[2], (unsigned long long)v);
+            atomicAdd(&K.stats[3], (unsigned long long)st.overflow);
+        }
     }
 }
 
@@ -1098,7 +1199,7 @@ void launch_move(const MoveLaunch& L, hipStream_t s) {
 }
 
 // ---- batched single queries (the CollisionQuery facade) ---------------------
-__global__ __launch_bounds__(kWave) void cast_query_kernel(DevCollision col, const sge_capsule_query* q, int n,
+__global__ __launch_bounds__(kWave, 4) void cast_query_kernel(DevCollision col, const sge_capsule_query* q, int n,
                                                            sge_capsule_cast_hit* out, unsigned long long* stats) {
     const int i = blockIdx.x;
     WaveStats st{0, 0, 0, 0};
@@ -1127,7 +1228,7 @@ __global__ __launch_bounds__(kWave) void cast_query_kernel(DevCollision col, con
     }
 }
 
-__global__ __launch_bounds__(kWave) void overlap_query_kernel(DevCollision col, const sge_capsule_query* q, int n, int maxHits,
+__global__ __launch_bounds__(kWave, 4) void overlap_query_kernel(DevCollision col, const sge_capsule_query* q, int n, int maxHits,
                                                               sge_capsule_overlap_hit* out, int32_t* counts,
                                                               unsigned long long* stats) {
     const int i = blockIdx.x;
