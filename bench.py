@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--chars", type=int, default=10000, help="characters per GPU")
     ap.add_argument("--workload", choices=["ccd", "lbs", "agents"], default="ccd")
     ap.add_argument("--layout", choices=["packed", "padded16"], default="packed")
+    ap.add_argument("--overlap", action="store_true", help="skin(n) on a second stream, overlapping move(n+1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-chars", type=int, default=384)
     ap.add_argument("--cpu-sample-steps", type=int, default=8)
@@ -69,6 +70,7 @@ def main():
     # ---- world: replicated per GPU ------------------------------------------------
     eng = sge.CharacterEngine(local_rank)
     eng.set_option(abi.OPT_SKIN_LAYOUT, abi.LAYOUT_PADDED16 if args.layout == "padded16" else abi.LAYOUT_PACKED)
+    eng.set_option(abi.OPT_OVERLAP_SKIN, 1 if args.overlap else 0)
     ybot = sge.assets.YBotAssets()
     sge.crowd.upload_character_assets(eng, ybot)  # 22 x 10 vertices on 64 bones = 14,080
     terrain = sge.crowd.upload_terrain(eng)       # 224 x 160 x 2 = 71,680 triangles
@@ -147,7 +149,7 @@ def main():
                          "agents": "configs[4]-style: configs[2] + character-vs-character sweeps, RCCL all-gather of capsule state"}[args.workload],
             "characters_per_gpu": args.chars, "characters_total": n_total, "bones": B, "vertices_per_character": V,
             "static_triangles": int(terrain["indices"].size // 3), "dt": 1.0 / 60.0, "sharding": f"by-character x{world}",
-            "skin_layout": args.layout, "settle_steps": SETTLE_STEPS if mode == "ccd" else 0, "seed": 1234,
+            "skin_layout": args.layout, "overlap_skin_with_next_move": bool(args.overlap), "settle_steps": SETTLE_STEPS if mode == "ccd" else 0, "seed": 1234,
         },
         "roofline": {"bound": "hbm", "kernel": "skin_kernel (4-weight LBS)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -158,6 +160,8 @@ def main():
         "ccd": {"bvh_queries_per_char_step": stats.queries / max(count * args.steps, 1),
                 "candidates_per_query": stats.candidates / max(stats.queries, 1),
                 "distance_evals_per_query": stats.sweepIterations / max(stats.queries, 1),
+                "traversal_steps_per_query": stats.traversalSteps / max(stats.queries, 1),
+                "sweep_trips_per_query": stats.sweepTrips / max(stats.queries, 1),
                 "queries_per_s": stats.queries / max(prof.move_ms * 1e-3, 1e-9), "overflow": int(stats.overflow)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

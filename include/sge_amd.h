@@ -224,7 +224,9 @@ int sge_synchronize(sge_context* ctx);
 enum {
     SGE_OPT_STORE_POSE_DEBUG = 1, /* also keep PoseComponent.local/.model per character */
     SGE_OPT_SKIN_LAYOUT = 2,      /* SGE_LAYOUT_* for the skinned output streams */
-    SGE_OPT_PROFILE = 3           /* 1: bracket every kernel with HIP events */
+    SGE_OPT_PROFILE = 3,          /* 1: bracket every kernel with HIP events */
+    SGE_OPT_OVERLAP_SKIN = 4      /* 1: run the skin stage on a second stream so that it overlaps the next
+                                     step's move stage (ignored on a caller-provided stream) */
 };
 enum {
     SGE_LAYOUT_PACKED = 0,  /* positions/normals float[3] (12 B), tangents float[4] */
@@ -495,6 +497,8 @@ typedef struct sge_move_stats {
     uint64_t candidates;       /* capsuleCandidateCount */
     uint64_t sweepIterations;  /* capsuleSweepIterations */
     uint64_t overflow;         /* traversal-stack or candidate overflows (must stay 0) */
+    uint64_t traversalSteps;   /* wave-wide node-expansion steps */
+    uint64_t sweepTrips;       /* wave-wide trips of the sweep loop (one distance evaluation per active lane each) */
 } sge_move_stats;
 int sge_move_stats_read(sge_context* ctx, sge_move_stats* out, int reset);
 

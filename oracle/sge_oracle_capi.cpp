@@ -311,6 +311,8 @@ int sgeo_move_stats_read(sgeo_world* h, sge_move_stats* out, int reset) {
     out->candidates = (uint64_t)h->stats.candidates;
     out->sweepIterations = (uint64_t)h->stats.iterations;
     out->overflow = 0;
+    out->traversalSteps = 0;
+    out->sweepTrips = 0;
     if (reset) h->stats = QueryStats();
     return SGE_OK;
 }

@@ -46,6 +46,10 @@ using namespace sge;
 struct sge_context {
     int device = 0;
     hipStream_t ownStream = nullptr, stream = nullptr;
+    // LBS of step n overlaps move/CCD of step n+1: skinning runs on its own stream, ordered by two events
+    hipStream_t skinStream = nullptr;
+    hipEvent_t evPoseDone = nullptr, evSkinDone = nullptr;
+    bool skinPending = false, overlapSkin = false, customStream = false;
     // options
     bool storePoseDebug = false, profile = false;
     int skinLayout = SGE_LAYOUT_PACKED;
@@ -103,14 +107,27 @@ int drainEvents(Events& ev) {
 }
 
 struct Bracket {
-    sge_context* c; Events* ev; hipEvent_t a = nullptr, b = nullptr;
-    Bracket(sge_context* ctx, Events* e) : c(ctx), ev(e) {
-        if (c->profile) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, c->stream); }
+    sge_context* c; Events* ev; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    Bracket(sge_context* ctx, Events* e, hipStream_t stream = nullptr) : c(ctx), ev(e), s(stream ? stream : ctx->stream) {
+        if (c->profile) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
     }
     ~Bracket() {
-        if (c->profile) { (void)hipEventRecord(b, c->stream); ev->pending.emplace_back(a, b); }
+        if (c->profile) { (void)hipEventRecord(b, s); ev->pending.emplace_back(a, b); }
     }
 };
+
+// Everything enqueued so far on either stream has completed.
+int syncAll(sge_context* c) {
+    SGE_HIP(hipStreamSynchronize(c->stream));
+    if (c->skinStream) SGE_HIP(hipStreamSynchronize(c->skinStream));
+    c->skinPending = false;
+    return SGE_OK;
+}
+// The main stream must not touch palettes / skinned outputs while a skin launch is in flight.
+int joinSkin(sge_context* c) {
+    if (c->skinPending) { SGE_HIP(hipStreamWaitEvent(c->stream, c->evSkinDone, 0)); c->skinPending = false; }
+    return SGE_OK;
+}
 
 int refreshInvBind(sge_context* c, const float* meshInvBind, int meshInvBindCount) {
     // Systems.swift:2523: re-bind only when the mesh carries invBindModel of matching count
@@ -256,6 +273,9 @@ sge_context* sge_context_create(int device_index) {
     c->device = device_index;
     if (hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
     c->stream = c->ownStream;
+    if (hipStreamCreateWithFlags(&c->skinStream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evPoseDone, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evSkinDone, hipEventDisableTiming) != hipSuccess) { set_error("stream/event creation failed"); delete c; return nullptr; }
     if (c->dStats.alloc(64) != SGE_OK || hipMemsetAsync(c->dStats.p, 0, 64, c->stream) != hipSuccess) { delete c; return nullptr; }
     return c;
 }
@@ -263,7 +283,7 @@ sge_context* sge_context_create(int device_index) {
 void sge_context_destroy(sge_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)syncAll(c);
     drainEvents(c->evMove); drainEvents(c->evPose); drainEvents(c->evSkin); drainEvents(c->evAgents);
     DevBuf* bufs[] = {&c->dParent, &c->dDepth, &c->dLeanChain, &c->dBindLocal, &c->dInvBind, &c->dRestT, &c->dRawRestT, &c->dPreRot,
                       &c->dCoeffs, &c->dCoeffCount, &c->dBonePresent, &c->dMeshPos, &c->dMeshNrm, &c->dMeshTan, &c->dMeshIdx, &c->dMeshWgt,
@@ -271,21 +291,25 @@ void sge_context_destroy(sge_context* c) {
                       &c->dPalettes, &c->dPoseModel, &c->dPoseLocal, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
                       &c->dCellCursor, &c->dAgentMinMax, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats};
     for (DevBuf* b : bufs) b->release();
+    if (c->evPoseDone) (void)hipEventDestroy(c->evPoseDone);
+    if (c->evSkinDone) (void)hipEventDestroy(c->evSkinDone);
+    if (c->skinStream) (void)hipStreamDestroy(c->skinStream);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
 }
 
 int sge_context_set_stream(sge_context* c, void* hip_stream) {
     if (!c) return SGE_ERR_INVALID;
-    SGE_HIP(hipStreamSynchronize(c->stream));
+    int rc = syncAll(c);
+    if (rc != SGE_OK) return rc;
     c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->ownStream;
+    c->customStream = hip_stream != nullptr; // on a caller's stream everything stays in that stream's order
     return SGE_OK;
 }
 
 int sge_synchronize(sge_context* c) {
     if (!c) return SGE_ERR_INVALID;
-    SGE_HIP(hipStreamSynchronize(c->stream));
-    return SGE_OK;
+    return syncAll(c);
 }
 
 int sge_context_set_option(sge_context* c, int option, int value) {
@@ -297,6 +321,7 @@ int sge_context_set_option(sge_context* c, int option, int value) {
         c->skinLayout = value;
         break;
     case SGE_OPT_PROFILE: c->profile = value != 0; break;
+    case SGE_OPT_OVERLAP_SKIN: { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; c->overlapSkin = value != 0; break; }
     default: set_error("unknown option"); return SGE_ERR_INVALID;
     }
     return SGE_OK;
@@ -304,6 +329,7 @@ int sge_context_set_option(sge_context* c, int option, int value) {
 
 // ---- skeleton ----------------------------------------------------------------
 int sge_skeleton_upload(sge_context* c, const sge_skeleton_desc* d) {
+    if (c) { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; }
     if (!c || !d || d->boneCount <= 0 || d->boneCount > SGE_MAX_BONES || !d->parent || !d->bindLocal || !d->invBindModel ||
         !d->restTranslation || !d->rawRestTranslation || !d->preRotationDegrees) {
         set_error("sge_skeleton_upload: bad argument");
@@ -376,6 +402,7 @@ int sge_skeleton_upload(sge_context* c, const sge_skeleton_desc* d) {
 
 // ---- motion profiles -----------------------------------------------------------
 int sge_motion_profiles_upload(sge_context* c, const sge_motion_profile_desc* p, int32_t count) {
+    if (c) { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; }
     if (!c || !p || count <= 0 || count > SGE_MAX_PROFILES) { set_error("sge_motion_profiles_upload: bad argument"); return SGE_ERR_INVALID; }
     if (c->boneCount == 0) { set_error("upload the skeleton first"); return SGE_ERR_STATE; }
     const int B = c->boneCount;
@@ -419,6 +446,7 @@ int sge_motion_profiles_upload(sge_context* c, const sge_motion_profile_desc* p,
 
 // ---- skinned mesh ----------------------------------------------------------------
 int sge_skinned_mesh_upload(sge_context* c, const sge_skinned_mesh_desc* d) {
+    if (c) { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; }
     if (!c || !d || d->vertexCount <= 0 || !d->positions || !d->normals || !d->tangents || !d->boneIndices || !d->boneWeights) {
         set_error("sge_skinned_mesh_upload: bad argument");
         return SGE_ERR_INVALID;
@@ -459,6 +487,7 @@ int sge_skinning_encode(sge_context* c, void* d_outPositions, void* d_outNormals
                         const sge_skinning_job* jobs, int32_t job_count) {
     if (!c || !d_outPositions || !d_outNormals || !d_outTangents || (job_count > 0 && !jobs)) { set_error("sge_skinning_encode: bad argument"); return SGE_ERR_INVALID; }
     (void)hipSetDevice(c->device);
+    { int rcj = joinSkin(c); if (rcj != SGE_OK) return rcj; }
     for (int j = 0; j < job_count; ++j) { // RTSkinningEncoder.swift:37-54
         const sge_skinning_job& J = jobs[j];
         if (J.vertexCount <= 0) continue;
@@ -475,6 +504,7 @@ int sge_skinning_encode(sge_context* c, void* d_outPositions, void* d_outNormals
 
 // ---- collision world ---------------------------------------------------------------
 int sge_collision_rebuild_static(sge_context* c, const sge_static_mesh_entity* ents, int32_t count) {
+    if (c) { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; }
     if (!c || count < 0 || (count > 0 && !ents)) { set_error("sge_collision_rebuild_static: bad argument"); return SGE_ERR_INVALID; }
     for (int e = 0; e < count; ++e) {
         if (!ents[e].positions || !ents[e].indices || ents[e].vertexCount < 0 || ents[e].indexCount < 0) { set_error("bad entity"); return SGE_ERR_INVALID; }
@@ -576,7 +606,7 @@ int sge_capsule_overlap_all_batch(sge_context* c, const sge_capsule_query* q, in
 int sge_characters_resize(sge_context* c, int32_t count) {
     if (!c || count < 0) { set_error("sge_characters_resize: bad argument"); return SGE_ERR_INVALID; }
     (void)hipSetDevice(c->device);
-    SGE_HIP(hipStreamSynchronize(c->stream));
+    { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; }
     const size_t N = (size_t)count, B = (size_t)c->boneCount;
     int rc;
 #define SGE_ZALLOC(buf, bytes) if ((rc = (buf).alloc(bytes)) != SGE_OK) return rc; if ((bytes) > 0) SGE_HIP(hipMemsetAsync((buf).p, 0, (bytes), c->stream));
@@ -644,6 +674,7 @@ int sge_palettes_download(sge_context* c, int32_t first, int32_t count, float* p
     if ((model || local) && !c->crowd.poseModel) { set_error("model/local need SGE_OPT_STORE_POSE_DEBUG set before sge_characters_resize"); return SGE_ERR_STATE; }
     (void)hipSetDevice(c->device);
     const size_t B = (size_t)c->boneCount, off = (size_t)first * B * 16, n = (size_t)count * B * 64;
+    { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; }
     if (palette) SGE_HIP(hipMemcpyAsync(palette, c->dPalettes.as<float>() + off, n, hipMemcpyDeviceToHost, c->stream));
     if (model) SGE_HIP(hipMemcpyAsync(model, c->dPoseModel.as<float>() + off, n, hipMemcpyDeviceToHost, c->stream));
     if (local) SGE_HIP(hipMemcpyAsync(local, c->dPoseLocal.as<float>() + off, n, hipMemcpyDeviceToHost, c->stream));
@@ -657,6 +688,7 @@ int sge_skinned_download(sge_context* c, int64_t first_vertex, int64_t vertex_co
     (void)hipSetDevice(c->device);
     const bool padded = c->outLayoutAllocated == SGE_LAYOUT_PADDED16;
     const size_t n = (size_t)vertex_count, f = (size_t)first_vertex;
+    { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; }
     hipStream_t s = c->stream;
     if (!padded) {
         if (positions) SGE_HIP(hipMemcpyAsync(positions, c->dOutPos.as<float>() + f * 3, n * 12, hipMemcpyDeviceToHost, s));
@@ -696,18 +728,35 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
     if (st & (SGE_STAGE_LOCOMOTION | SGE_STAGE_ACTION | SGE_STAGE_POSE | SGE_STAGE_WRITEBACK)) {
         if ((st & SGE_STAGE_POSE) && (c->boneCount == 0 || c->prof.count == 0)) { set_error("pose stage needs a skeleton and motion profiles"); return SGE_ERR_STATE; }
         PoseLaunch L{c->crowd, c->sk, c->prof, d->dt, st, first, count};
+        if (st & SGE_STAGE_POSE) { int rcj = joinSkin(c); if (rcj != SGE_OK) return rcj; } // palettes are about to be rewritten
         Bracket br(c, &c->evPose);
         launch_pose(L, c->stream);
     }
     if (st & SGE_STAGE_SKIN) {
         if (c->mesh.vertexCount == 0) { set_error("skin stage needs a skinned mesh"); return SGE_ERR_STATE; }
-        if (c->outLayoutAllocated != c->skinLayout) { int rc = allocCrowdOutputs(c); if (rc != SGE_OK) return rc; }
+        if (c->outLayoutAllocated != c->skinLayout) {
+            int rc = syncAll(c);
+            if (rc != SGE_OK || (rc = allocCrowdOutputs(c)) != SGE_OK) return rc;
+        }
         // one RTSkinningJob per character, dstBaseVertex = running vertex offset (RTGeometryCache.swift:266-315)
         SkinLaunch L{c->mesh.positions, c->mesh.normals, c->mesh.tangents, c->mesh.boneIndices, c->mesh.boneWeights,
                      c->crowd.palettes + (size_t)first * c->boneCount * 16, c->boneCount, c->mesh.vertexCount, count,
                      (long long)first * c->mesh.vertexCount, SGE_LAYOUT_PACKED, c->skinLayout, c->dOutPos.p, c->dOutNrm.p, c->dOutTan.p};
-        Bracket br(c, &c->evSkin);
-        launch_skin(L, c->stream);
+        hipStream_t ss = c->stream;
+        const bool overlap = c->overlapSkin && !c->customStream;
+        if (overlap) {
+            // skin(n) on its own stream after pose(n); move(n+1) may start on the main stream meanwhile
+            int rcj = joinSkin(c);
+            if (rcj != SGE_OK) return rcj;
+            SGE_HIP(hipEventRecord(c->evPoseDone, c->stream));
+            SGE_HIP(hipStreamWaitEvent(c->skinStream, c->evPoseDone, 0));
+            ss = c->skinStream;
+        }
+        {
+            Bracket br(c, &c->evSkin, ss);
+            launch_skin(L, ss);
+        }
+        if (overlap) { SGE_HIP(hipEventRecord(c->evSkinDone, c->skinStream)); c->skinPending = true; }
     }
     SGE_HIP(hipGetLastError());
     return SGE_OK;
@@ -749,11 +798,12 @@ int sge_profile_read(sge_context* c, sge_stage_times* out, int reset) {
 int sge_move_stats_read(sge_context* c, sge_move_stats* out, int reset) {
     if (!c || !out) return SGE_ERR_INVALID;
     (void)hipSetDevice(c->device);
-    unsigned long long h[4];
+    unsigned long long h[6];
     SGE_HIP(hipMemcpyAsync(h, c->dStats.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     SGE_HIP(hipStreamSynchronize(c->stream));
     out->queries = h[0]; out->candidates = h[1]; out->sweepIterations = h[2]; out->overflow = h[3];
-    if (reset) { SGE_HIP(hipMemsetAsync(c->dStats.p, 0, 32, c->stream)); SGE_HIP(hipStreamSynchronize(c->stream)); }
+    out->traversalSteps = h[4]; out->sweepTrips = h[5];
+    if (reset) { SGE_HIP(hipMemsetAsync(c->dStats.p, 0, 64, c->stream)); SGE_HIP(hipStreamSynchronize(c->stream)); }
     return SGE_OK;
 }
 

@@ -51,7 +51,7 @@ struct WaveShared {
     OverlapRec ovlTmp[SGE_MAX_OVERLAP_HITS];
 };
 
-struct WaveStats { unsigned int queries, candidates, evals, overflow; };
+struct WaveStats { unsigned int queries, candidates, evals, overflow, steps, trips; };
 
 // One instance per 64-thread workgroup (= per character / per query).
 __shared__ WaveShared sh;
@@ -199,6 +199,7 @@ __device__ __forceinline__ bool boxDisjoint(F3 bmin, F3 bmax, F3 minP, F3 maxP) 
 __device__ __forceinline__ void expandNodes(const DevCollision& col, F3 minP, F3 maxP, uint32_t mask,
                                             int& stackSize, int& candCount, WaveStats& st) {
     const int lane = laneId();
+    st.steps += 1;
     int n = stackSize > kStackSoft ? 1 : (stackSize < kWave ? stackSize : kWave);
     int myNode = lane < n ? sh.stack[stackSize - 1 - lane] : -1;
     stackSize -= n;
@@ -309,6 +310,7 @@ __device__ __forceinline__ bool waveCapsuleCast(const DevCollision& col, F3 from
         unsigned long long myKey = ~0ull;
 
         while (__any(phase != PH_DONE)) {
+            st.trips += 1;
             if (phase == PH_MARCH) {
                 // loop head of :1303-1307 — iteration budget, then `if t > maxDistance return nil`
                 if (iter >= maxIter || t > len || lastSafeT > bestToi) phase = PH_DONE;
@@ -799,7 +801,7 @@ enum { MP_DEPEN = 0, MP_SLIDE = 1, MP_GROUND_CENTER = 2, MP_GROUND_FALL = 3, MP_
 __global__ __launch_bounds__(kWave, 4) void move_kernel(MoveLaunch K) {
     const int e = K.first + blockIdx.x;
     const int lane = laneId();
-    WaveStats st{0, 0, 0, 0};
+    WaveStats st{0, 0, 0, 0, 0, 0};
     const DevCollision& col = K.col;
     {   // 288 B of state: lanes copy dwords
         const uint32_t* gb = reinterpret_cast<const uint32_t*>(K.crowd.bodies + e);
@@ -1189,6 +1191,8 @@ __global__ __launch_bounds__(kWave, 4) void move_kernel(MoveLaunch K) {
             atomicAdd(&K.stats[1], (unsigned long long)st.candidates);
             atomicAdd(&K.stats[2], (unsigned long long)v);
             atomicAdd(&K.stats[3], (unsigned long long)st.overflow);
+            atomicAdd(&K.stats[4], (unsigned long long)st.steps);
+            atomicAdd(&K.stats[5], (unsigned long long)st.trips);
         }
     }
 }
@@ -1202,7 +1206,7 @@ void launch_move(const MoveLaunch& L, hipStream_t s) {
 __global__ __launch_bounds__(kWave, 4) void cast_query_kernel(DevCollision col, const sge_capsule_query* q, int n,
                                                            sge_capsule_cast_hit* out, unsigned long long* stats) {
     const int i = blockIdx.x;
-    WaveStats st{0, 0, 0, 0};
+    WaveStats st{0, 0, 0, 0, 0, 0};
     sge_capsule_query Q = q[i];
     CastRec r;
     bool got = waveCapsuleCast(col, F3{Q.from[0], Q.from[1], Q.from[2]}, F3{Q.delta[0], Q.delta[1], Q.delta[2]}, Q.radius,
@@ -1233,7 +1237,7 @@ __global__ __launch_bounds__(kWave, 4) void overlap_query_kernel(DevCollision co
                                                               unsigned long long* stats) {
     const int i = blockIdx.x;
     const int lane = laneId();
-    WaveStats st{0, 0, 0, 0};
+    WaveStats st{0, 0, 0, 0, 0, 0};
     sge_capsule_query Q = q[i];
     int cnt = waveCapsuleOverlapAll(col, F3{Q.from[0], Q.from[1], Q.from[2]}, Q.radius, Q.halfHeight, maxHits, Q.mask, st);
     if (lane < maxHits) {
