@@ -1,0 +1,130 @@
+"""CPU tests of the C-ABI boundary: the HIP library loads without a GPU, exports exactly the symbols
+include/sge_amd.h declares, agrees with the ctypes mirror on every struct size, refuses to run without
+a device (no CPU fallback), and its host-side helpers match the oracle's."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "sge_amd.h")
+
+
+@pytest.fixture(scope="module")
+def lib(sge):
+    import __graft_entry__
+    __graft_entry__.build()
+    return sge.abi.load_library()
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sge_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_ctypes_mirror_agree(sge):
+    names = declared_functions()
+    assert len(names) >= 30
+    assert names == sorted(sge.abi.PROTOTYPES), set(names) ^ set(sge.abi.PROTOTYPES)
+
+
+def test_library_exports_every_declared_symbol(sge, lib):
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+    out = subprocess.check_output(["nm", "-D", "--defined-only", sge.abi.library_path()], text=True)
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert set(declared_functions()) <= exported
+    assert lib.sge_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header(sge, tmp_path):
+    """Compile a tiny C program against the header and compare sizeof() with the ctypes mirror."""
+    names = {"sge_body_state": sge.abi.BodyState, "sge_controller_params": sge.abi.ControllerParams,
+             "sge_controller_state": sge.abi.ControllerState, "sge_move_intent": sge.abi.MoveIntent,
+             "sge_locomotion_state": sge.abi.LocomotionState, "sge_action_state": sge.abi.ActionState,
+             "sge_skeleton_desc": sge.abi.SkeletonDesc, "sge_motion_profile_desc": sge.abi.MotionProfileDesc,
+             "sge_skinned_mesh_desc": sge.abi.SkinnedMeshDesc, "sge_skinning_job": sge.abi.SkinningJob,
+             "sge_static_mesh_entity": sge.abi.StaticMeshEntity, "sge_bvh_node": sge.abi.BVHNode,
+             "sge_capsule_query": sge.abi.CapsuleQuery, "sge_capsule_cast_hit": sge.abi.CapsuleCastHit,
+             "sge_capsule_overlap_hit": sge.abi.CapsuleOverlapHit, "sge_tick_desc": sge.abi.TickDesc,
+             "sge_agent_state": sge.abi.AgentState, "sge_stage_times": sge.abi.StageTimes,
+             "sge_move_stats": sge.abi.MoveStats, "sge_surface_material": sge.abi.SurfaceMaterial}
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "sge_amd.h"\nint main(void){' +
+                   "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    for line in subprocess.check_output([str(exe)], text=True).splitlines():
+        n, sz = line.split()
+        assert C.sizeof(names[n]) == int(sz), n
+
+
+def test_no_cpu_fallback(sge, lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    assert not lib.sge_context_create(0)
+    assert b"no HIP device" in lib.sge_last_error() or b"fallback" in lib.sge_last_error()
+    with pytest.raises(sge.SgeError):
+        sge.CharacterEngine(0)
+    # entry points reject a NULL context instead of computing anything
+    d = sge.abi.TickDesc()
+    assert lib.sge_tick(None, C.byref(d)) != 0
+    assert lib.sge_characters_resize(None, 4) != 0
+
+
+def test_host_helpers_match_oracle(sge, ybot, lib):
+    """sge_skeleton_build / sge_mesh_tangents_compute are pure host code in the product library."""
+    ora = ob.load_oracle()
+    B = ybot.bone_count
+    outs = []
+    for fn in (lib.sge_skeleton_build, ora.sgeo_skeleton_build):
+        rest, bind, inv, fix = (np.zeros((B, 3), np.float32), np.zeros((B, 16), np.float32),
+                                np.zeros((B, 16), np.float32), np.zeros(16, np.float32))
+        rc = fn(B, sge.abi.ptr(ybot.parent), sge.abi.ptr(ybot.translations), sge.abi.ptr(ybot.pre_rotation_degrees),
+                sge.abi.ptr(ybot.root_fix_degrees), C.c_float(ybot.unit_scale), int(ybot.zero_root),
+                sge.abi.ptr(rest), sge.abi.ptr(bind), sge.abi.ptr(inv), sge.abi.ptr(fix))
+        assert rc == 0
+        outs.append((rest, bind, inv, fix))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    # invalid skeleton: child before parent
+    bad = ybot.parent.copy()
+    bad[1] = 5
+    assert lib.sge_skeleton_build(B, sge.abi.ptr(bad), sge.abi.ptr(ybot.translations), sge.abi.ptr(ybot.pre_rotation_degrees),
+                                  sge.abi.ptr(ybot.root_fix_degrees), C.c_float(1.0), 1, sge.abi.ptr(outs[0][0]),
+                                  sge.abi.ptr(outs[0][1]), sge.abi.ptr(outs[0][2]), sge.abi.ptr(outs[0][3])) != 0
+    rng = np.random.default_rng(0)
+    V = 300
+    pos = rng.normal(size=(V, 3)).astype(np.float32)
+    nrm = rng.normal(size=(V, 3)).astype(np.float32)
+    uv = rng.uniform(size=(V, 2)).astype(np.float32)
+    idx = rng.integers(0, V, 999).astype(np.uint32)
+    t = [np.zeros((V, 4), np.float32), np.zeros((V, 4), np.float32)]
+    for k, fn in enumerate((lib.sge_mesh_tangents_compute, ora.sgeo_mesh_tangents_compute)):
+        assert fn(V, sge.abi.ptr(pos), sge.abi.ptr(nrm), sge.abi.ptr(uv), None, sge.abi.ptr(idx), idx.size, sge.abi.ptr(t[k])) == 0
+    assert np.array_equal(t[0], t[1])
+
+
+def test_assets_and_synthetic_meshes(sge, ybot):
+    assert ybot.profile_names == ["Idle", "Walking", "Running", "FallingIdle", "StandingDodgeBackward"]
+    for p in ybot.profiles:
+        assert p["order"] == 4 and p["bonePresent"].sum() == 52
+        cc = p["coeffCount"]
+        assert set(np.unique(cc)) <= {9, 255}
+        assert (cc != 255).sum() == 159  # 52 bones, 159 channels
+    pos, idx = sge.assets.make_synthetic_static_mesh()
+    assert idx.size // 3 == 71680 and idx.max() < pos.shape[0]
+    e1 = pos[idx[1::3]] - pos[idx[0::3]]
+    e2 = pos[idx[2::3]] - pos[idx[0::3]]
+    assert (np.cross(e1, e2)[:, 1] > 0).all()  # +Y facing
+    off = sge.assets.crowd_phase_offsets(5, 0.7)
+    assert off[0] == 0 and np.all((off >= 0) & (off < 0.7))
+    assert sge.parallel.shard_range(10, 0, 3) == (0, 3) and sge.parallel.shard_range(10, 2, 3) == (6, 4)
+    assert sum(sge.parallel.shard_range(250000, r, 8)[1] for r in range(8)) == 250000

@@ -232,3 +232,50 @@ def test_config1_single_ybot_settles(sge, engines):
         ys.append(gpu.download(what=("bodies",))["bodies"]["position"][0, 1])
     assert abs(ys[-1] - (-3 + 2.5 + 0.05)) < 2e-3, ys[-1]
     assert abs(ys[-1] - ys[-20]) < 1e-6
+
+
+def test_character_vs_character_sweeps(sge, engines):
+    """config 5 on one GPU: the all-gathered capsule snapshot (world size 1 here) is binned into the XZ grid
+    and swept; the oracle loops over all pairs like the reference (Systems.swift:1069)."""
+    import torch
+
+    gpu, cpu = engines
+    n = 160
+
+    class Cap:
+        def resize(self, k):
+            pass
+
+        def upload(self, **kw):
+            self.kw = kw
+
+    for e in engines:
+        ybot, terrain, _ = build_scene(sge, e, 1, terrain_cells=(40, 30), rings=3, segments=3)
+        cap = Cap()
+        sge.crowd.spawn_crowd(cap, ybot, n, terrain, seed=9, mode="ccd", agents=True)
+        cap.kw["bodies"]["position"][:, 0] *= 0.35
+        cap.kw["bodies"]["position"][:, 2] *= 0.35
+        cap.kw["params"]["agentFlags"][::7] = sge.abi.AGENT_PRESENT  # some non-solid agents
+        cap.kw["params"]["agentFlags"][3::11] |= sge.abi.AGENT_RADIUS_OVERRIDE
+        cap.kw["params"]["agentRadiusOverride"][:] = 1.1
+        e.resize(n)
+        e.upload(**cap.kw)
+    ex = sge.parallel.AgentExchange(gpu, n, 0, 1, torch.device("cuda", 0), None)
+    stages = sge.abi.STAGE_ALL
+    hits = 0
+    for s in range(60):
+        ex.step(stages=stages)
+        cpu.tick(stages=stages | sge.abi.STAGE_AGENTS)
+        if s % 10 == 9:
+            gpu.synchronize()
+            compare_states(sge, gpu, cpu, n)
+    free = ob.oracle_engine()
+    build_scene(sge, free, 1, terrain_cells=(40, 30), rings=3, segments=3)
+    free.resize(n)
+    free.upload(**cap.kw)
+    for s in range(60):
+        free.tick(stages=stages)
+    a = free.download(what=("bodies",))["bodies"]["position"]
+    b = cpu.download(what=("bodies",))["bodies"]["position"]
+    assert np.abs(a - b).max() > 1e-3, "the scene must exercise capsule-capsule hits"
+    free.close()
