@@ -1,0 +1,178 @@
+// Header-only C++ host mirror of the reference's Swift surfaces for this path, forwarding to the
+// C ABI of include/sge_amd.h.  The reference is compiled Swift with no toolchain in this image, so
+// the host side above the ABI is C++ (and a ctypes/numpy driver for tests); names, argument meaning
+// and the nil/optional error convention follow the Swift originals so that call sites read alike:
+//
+//   sge::CollisionQuery            Game/CollisionQuery.swift:54-160
+//   sge::RTSkinningEncoder         Game/RTSkinningEncoder.swift:10-57 (+ RTSkinningJob, RTGeometryCache.swift:43-52)
+//   sge::KinematicMoveStopSystem   Game/Systems.swift:1402-1415, 1823-1902  (FixedStepSystem, Systems.swift:15-17)
+//   sge::PoseStackSystem           Game/ProceduralPoseSystem.swift:10-13
+//   sge::LocomotionProfileSystem   Game/Systems.swift:276-279
+//   sge::ActionAnimationSystem     Game/Systems.swift:472-475
+//
+// `World` here is the crowd owned by one GPU context: the reference's per-entity dictionary stores
+// (World.swift:64-75) become the context's resident arrays, so `fixedUpdate(world, dt)` is one batched call.
+#pragma once
+#include <array>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/sge_amd.h"
+
+namespace sge {
+
+struct float3 { float x, y, z; };
+
+class Error : public std::runtime_error {
+public:
+    explicit Error(const std::string& what) : std::runtime_error(what + ": " + sge_last_error()) {}
+};
+inline void check(int rc, const char* what) { if (rc != SGE_OK) throw Error(what); }
+
+// The crowd resident on one GPU.
+class World {
+public:
+    // Mirrors the reference's failable initialisers: returns nullptr when no gfx950 device exists.
+    static std::unique_ptr<World> make(int deviceIndex = 0) {
+        sge_context* c = sge_context_create(deviceIndex);
+        if (!c) return nullptr;
+        return std::unique_ptr<World>(new World(c));
+    }
+    ~World() { sge_context_destroy(ctx_); }
+    World(const World&) = delete;
+    World& operator=(const World&) = delete;
+
+    sge_context* context() const { return ctx_; }
+    void uploadSkeleton(const sge_skeleton_desc& d) { check(sge_skeleton_upload(ctx_, &d), "sge_skeleton_upload"); boneCount_ = d.boneCount; }
+    void uploadMotionProfiles(const std::vector<sge_motion_profile_desc>& p) { check(sge_motion_profiles_upload(ctx_, p.data(), (int32_t)p.size()), "sge_motion_profiles_upload"); }
+    void uploadSkinnedMesh(const sge_skinned_mesh_desc& d) { check(sge_skinned_mesh_upload(ctx_, &d), "sge_skinned_mesh_upload"); vertexCount_ = d.vertexCount; }
+    void resize(int32_t n) { check(sge_characters_resize(ctx_, n), "sge_characters_resize"); count_ = n; }
+    void upload(int32_t first, int32_t count, const sge_body_state* b, const sge_controller_params* p,
+                const sge_controller_state* c, const sge_move_intent* i, const sge_locomotion_state* l,
+                const sge_action_state* a) { check(sge_characters_upload(ctx_, first, count, b, p, c, i, l, a), "sge_characters_upload"); }
+    void download(int32_t first, int32_t count, sge_body_state* b, sge_controller_params* p, sge_controller_state* c,
+                  sge_move_intent* i, sge_locomotion_state* l, sge_action_state* a) { check(sge_characters_download(ctx_, first, count, b, p, c, i, l, a), "sge_characters_download"); }
+    void tick(float dt, uint32_t stages, float3 gravity = {0, -98.0f, 0}) {
+        sge_tick_desc d{dt, {gravity.x, gravity.y, gravity.z}, stages, 0, 0, 0};
+        check(sge_tick(ctx_, &d), "sge_tick");
+    }
+    void synchronize() { check(sge_synchronize(ctx_), "sge_synchronize"); }
+    int32_t count() const { return count_; }
+    int32_t boneCount() const { return boneCount_; }
+    int32_t vertexCount() const { return vertexCount_; }
+
+private:
+    explicit World(sge_context* c) : ctx_(c) {}
+    sge_context* ctx_;
+    int32_t count_ = 0, boneCount_ = 0, vertexCount_ = 0;
+};
+
+// ---- FixedStepSystem conformers (Systems.swift:15-17) ------------------------------------------
+struct FixedStepSystem {
+    virtual ~FixedStepSystem() = default;
+    virtual void fixedUpdate(World& world, float dt) = 0;
+};
+
+// PhysicsIntentSystem + GravitySystem + KinematicMoveStopSystem in the reference's order
+// (DemoScene.swift:62-68); init(gravity:) as Systems.swift:1407.
+class KinematicMoveStopSystem : public FixedStepSystem {
+public:
+    explicit KinematicMoveStopSystem(float3 gravity = {0, -98.0f, 0}, bool applyIntentAndGravity = true)
+        : gravity_(gravity), pre_(applyIntentAndGravity) {}
+    void fixedUpdate(World& world, float dt) override {
+        world.tick(dt, (pre_ ? (SGE_STAGE_INTENT | SGE_STAGE_GRAVITY) : 0u) | SGE_STAGE_MOVE, gravity_);
+    }
+private:
+    float3 gravity_;
+    bool pre_;
+};
+struct LocomotionProfileSystem : FixedStepSystem {
+    void fixedUpdate(World& world, float dt) override { world.tick(dt, SGE_STAGE_LOCOMOTION); }
+};
+struct ActionAnimationSystem : FixedStepSystem {
+    void fixedUpdate(World& world, float dt) override { world.tick(dt, SGE_STAGE_ACTION); }
+};
+struct PoseStackSystem : FixedStepSystem {
+    void fixedUpdate(World& world, float dt) override { world.tick(dt, SGE_STAGE_POSE); }
+};
+
+// ---- CollisionQuery (CollisionQuery.swift:54-160) ------------------------------------------------
+struct CapsuleCastHit { float toi; float3 position, normal, triangleNormal; int triangleIndex; sge_surface_material material; };
+struct CapsuleOverlapHit { float depth; float3 position, normal, triangleNormal; int triangleIndex; sge_surface_material material; };
+
+class CollisionQuery {
+public:
+    // init(world:activeEntityIDs:) — builds the static triangle set + BVH from the collidable entities
+    CollisionQuery(World& world, const std::vector<sge_static_mesh_entity>& collidables) : world_(world) {
+        check(sge_collision_rebuild_static(world.context(), collidables.data(), (int32_t)collidables.size()), "sge_collision_rebuild_static");
+    }
+    std::optional<CapsuleCastHit> capsuleCast(float3 from, float3 delta, float radius, float halfHeight, uint32_t mask = 0xFFFFFFFFu) {
+        return cast(from, delta, radius, halfHeight, SGE_CAST, 0.0f, mask);
+    }
+    std::optional<CapsuleCastHit> capsuleCastBlocking(float3 from, float3 delta, float radius, float halfHeight, uint32_t mask = 0xFFFFFFFFu) {
+        return cast(from, delta, radius, halfHeight, SGE_CAST_BLOCKING, 0.0f, mask);
+    }
+    std::optional<CapsuleCastHit> capsuleCastGround(float3 from, float3 delta, float radius, float halfHeight, float minNormalY, uint32_t mask = 0xFFFFFFFFu) {
+        return cast(from, delta, radius, halfHeight, SGE_CAST_GROUND, minNormalY, mask);
+    }
+    std::vector<CapsuleOverlapHit> capsuleOverlapAll(float3 from, float radius, float halfHeight, int maxHits = 8, uint32_t mask = 0xFFFFFFFFu) {
+        maxHits = maxHits < 1 ? 1 : (maxHits > SGE_MAX_OVERLAP_HITS ? SGE_MAX_OVERLAP_HITS : maxHits); // max(1, maxHits), :157
+        sge_capsule_query q{{from.x, from.y, from.z}, {0, 0, 0}, radius, halfHeight, 0.0f, mask, SGE_CAST};
+        std::array<sge_capsule_overlap_hit, SGE_MAX_OVERLAP_HITS> out{};
+        int32_t n = 0;
+        check(sge_capsule_overlap_all_batch(world_.context(), &q, 1, maxHits, out.data(), &n), "sge_capsule_overlap_all_batch");
+        std::vector<CapsuleOverlapHit> hits;
+        for (int k = 0; k < n; ++k)
+            hits.push_back({out[k].depth, {out[k].position[0], out[k].position[1], out[k].position[2]},
+                            {out[k].normal[0], out[k].normal[1], out[k].normal[2]},
+                            {out[k].triangleNormal[0], out[k].triangleNormal[1], out[k].triangleNormal[2]},
+                            out[k].triangleIndex, out[k].material});
+        return hits;
+    }
+    // batched forms for callers that have many probes per frame
+    void capsuleCastBatch(const std::vector<sge_capsule_query>& q, std::vector<sge_capsule_cast_hit>& out) {
+        out.resize(q.size());
+        check(sge_capsule_cast_batch(world_.context(), q.data(), (int32_t)q.size(), out.data()), "sge_capsule_cast_batch");
+    }
+
+private:
+    std::optional<CapsuleCastHit> cast(float3 from, float3 delta, float radius, float halfHeight, uint32_t mode, float minNormalY, uint32_t mask) {
+        sge_capsule_query q{{from.x, from.y, from.z}, {delta.x, delta.y, delta.z}, radius, halfHeight, minNormalY, mask, mode};
+        sge_capsule_cast_hit h{};
+        check(sge_capsule_cast_batch(world_.context(), &q, 1, &h), "sge_capsule_cast_batch");
+        if (!h.hit) return std::nullopt; // Swift nil
+        return CapsuleCastHit{h.toi, {h.position[0], h.position[1], h.position[2]}, {h.normal[0], h.normal[1], h.normal[2]},
+                              {h.triangleNormal[0], h.triangleNormal[1], h.triangleNormal[2]}, h.triangleIndex, h.material};
+    }
+    World& world_;
+};
+
+// ---- RTSkinningEncoder (RTSkinningEncoder.swift:10-57) ----------------------------------------------
+using RTSkinningJob = sge_skinning_job; // sourcePositions ... paletteBuffer as device pointers, vertexCount, dstBaseVertex
+
+class RTSkinningEncoder {
+public:
+    // init?(device:) — nil when the kernel is unavailable (here: no context)
+    static std::optional<RTSkinningEncoder> make(World* world) {
+        if (!world) return std::nullopt;
+        return RTSkinningEncoder(*world);
+    }
+    // encode(commandBuffer:outputBuffer:outputNormalBuffer:outputTangentBuffer:jobs:) — asynchronous on the
+    // context's stream (the command buffer); returns without work when jobs is empty (:32-35)
+    void encode(void* outputBuffer, void* outputNormalBuffer, void* outputTangentBuffer, const std::vector<RTSkinningJob>& jobs,
+                int outLayout = SGE_LAYOUT_PADDED16) {
+        if (jobs.empty()) return;
+        check(sge_skinning_encode(world_->context(), outputBuffer, outputNormalBuffer, outputTangentBuffer, outLayout, jobs.data(),
+                                  (int32_t)jobs.size()), "sge_skinning_encode");
+    }
+    // the crowd path: one job per character over the shared source mesh, palettes from the pose stage
+    void encodeCrowd(float dt = 0.0f) { world_->tick(dt, SGE_STAGE_SKIN); }
+
+private:
+    explicit RTSkinningEncoder(World& w) : world_(&w) {}
+    World* world_;
+};
+
+} // namespace sge
