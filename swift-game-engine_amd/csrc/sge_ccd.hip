@@ -38,6 +38,8 @@ constexpr int kWave = 64;
 constexpr int kStackCap = 1024;
 constexpr int kStackSoft = 768;   // above this, pop one node at a time (growth <= tree depth)
 constexpr int kCandCap = 512;
+constexpr int kItemCap = 512;
+constexpr int kMaxRays = 4;
 
 struct OverlapRec { float depth; F3 position, normal, triNormal; int triIndex, rank; };
 struct CastRec { float toi; F3 position, normal, triNormal; int triIndex; };
@@ -46,12 +48,28 @@ struct WaveShared {
     int stack[kStackCap];
     int cand[kCandCap];
     CastRec laneCast[kWave]; // each lane's accepted hit of the current batch
-    CastRec bestCast;
+    int items[kItemCap];     // (ray << 28) | slot work items of a multi-ray cast
+    // up to kMaxRays casts that share radius/halfHeight/filters run as ONE traversal + shared sweep batches
+    int rayCount;
+    F3 rayFrom[kMaxRays], rayDelta[kMaxRays], rayDir[kMaxRays], rayMin[kMaxRays], rayMax[kMaxRays];
+    float rayLen[kMaxRays];
+    int rayMaxIter[kMaxRays], rayValid[kMaxRays];
+    unsigned long long rayKey[kMaxRays]; // (toi bits << 32) | visit rank of the best accepted hit so far
+    CastRec rayRec[kMaxRays];
     OverlapRec ovl[SGE_MAX_OVERLAP_HITS];
     OverlapRec ovlTmp[SGE_MAX_OVERLAP_HITS];
 };
 
 struct WaveStats { unsigned int queries, candidates, evals, overflow, steps, trips; };
+#ifdef SGE_CCD_TIMING
+// diagnostic build only: shader-clock cycles per wave spent in traversal / sweep / everything
+__device__ unsigned long long g_cycTraverse, g_cycSweep, g_cycTotal;
+#define SGE_T0() long long _t0 = (long long)__builtin_amdgcn_s_memtime()
+#define SGE_T1(acc) acc += (long long)__builtin_amdgcn_s_memtime() - _t0
+#else
+#define SGE_T0()
+#define SGE_T1(acc)
+#endif
 
 // One instance per 64-thread workgroup (= per character / per query).
 __shared__ WaveShared sh;
@@ -263,52 +281,105 @@ __device__ __forceinline__ Tri loadTri(const DevCollision& col, int slot) {
 // ---------------------------------------------------------------------------
 enum { PH_MARCH = 0, PH_REFINE = 1, PH_FINAL = 2, PH_DONE = 3 };
 
-__device__ __forceinline__ bool waveCapsuleCast(const DevCollision& col, F3 from, F3 delta, float radius,
-                                             float halfHeight, bool blockingOnly, bool hasMinNormalY, float minNormalY,
-                                             uint32_t mask, CastRec& out, WaveStats& st) {
+// Casts sh.rayFrom/rayDelta[0..rayCount) (same capsule, same filters) in one pass. Each ray is an
+// independent capsuleCastCombined call of the reference; a work item is a (ray, triangle) pair whose
+// triangle AABB overlaps THAT ray's swept box, so every ray sees exactly its own candidate set.
+// Results: sh.rayKey[r] != initial  <=>  hit, record in sh.rayRec[r].
+__device__ __forceinline__ void waveCastRays(const DevCollision& col, float radius, float halfHeight, bool blockingOnly,
+                                             bool hasMinNormalY, float minNormalY, uint32_t mask, WaveStats& st) {
     const int lane = laneId();
-    float len = length(delta);
-    if (len < 1e-6f) return false;       // :987-988
-    if (col.root < 0) return false;      // :1020
-    st.queries += 1;
-    F3 dir = delta / len;
-    F3 up{0, 1, 0};
-    F3 a0 = from + up * halfHeight, b0 = from - up * halfHeight;
-    F3 a1 = a0 + delta, b1 = b0 + delta;
-    F3 minP = vmin(vmin(a0, b0), vmin(a1, b1));
-    F3 maxP = vmax(vmax(a0, b0), vmax(a1, b1));
-    F3 ext{radius, radius, radius};
-    minP = minP - ext; maxP = maxP + ext;
+    const int R = sh.rayCount;
+    // per-ray setup (:1021-1035), lanes 0..R-1 in parallel
+    if (lane < R) {
+        F3 from = sh.rayFrom[lane], delta = sh.rayDelta[lane];
+        float len = length(delta);
+        bool valid = !(len < 1e-6f) && col.root >= 0; // :987-988, :1020
+        F3 dir = delta / len;
+        F3 up{0, 1, 0};
+        F3 a0 = from + up * halfHeight, b0 = from - up * halfHeight;
+        F3 a1 = a0 + delta, b1 = b0 + delta;
+        F3 minP = vmin(vmin(a0, b0), vmin(a1, b1));
+        F3 maxP = vmax(vmax(a0, b0), vmax(a1, b1));
+        F3 ext{radius, radius, radius};
+        sh.rayMin[lane] = minP - ext; sh.rayMax[lane] = maxP + ext;
+        sh.rayDir[lane] = dir; sh.rayLen[lane] = len; sh.rayValid[lane] = valid ? 1 : 0;
+        const float minAdv = smax(radius * 0.02f, 1e-4f);
+        int maxIter = (int)ceilf(len / minAdv) + 1; // :1296
+        sh.rayMaxIter[lane] = maxIter < 256 ? maxIter : 256;
+        // a hit must have toi < len (:1084 with bestT = len): start the key at (len, +inf rank)
+        sh.rayKey[lane] = ((unsigned long long)__float_as_uint(len) << 32) | 0xffffffffull;
+    }
+    __syncthreads();
+    // union box of the valid rays drives the traversal
+    F3 minP{kFloatMax, kFloatMax, kFloatMax}, maxP{-kFloatMax, -kFloatMax, -kFloatMax};
+    int nValid = 0;
+    for (int r = 0; r < R; ++r) {
+        if (!sh.rayValid[r]) continue;
+        minP = vmin(minP, sh.rayMin[r]); maxP = vmax(maxP, sh.rayMax[r]);
+        nValid += 1;
+    }
+    if (nValid == 0) return;
+    st.queries += nValid;
 
-    // sweep constants (:1295-1297)
-    const float minAdvance = smax(radius * 0.02f, 1e-4f);
-    int maxIter = (int)ceilf(len / minAdvance) + 1;
-    maxIter = maxIter < 256 ? maxIter : 256;
+    const float minAdvance = smax(radius * 0.02f, 1e-4f); // :1295
     const float contactEps = 1e-5f;
-
-    unsigned long long bestKey = ~0ull; // (toi bits << 32) | rank, over accepted hits with toi < len
-    float bestToi = len;                // prune bound: a hit must have toi < bestToi (or tie with lower rank)
-    int stackSize = 1, candCount = 0;
+    long long cycTrav = 0, cycSweep = 0; (void)cycTrav; (void)cycSweep;
+    int stackSize = 1, candCount = 0, itemCount = 0;
     if (lane == 0) sh.stack[0] = col.root;
     __syncthreads();
 
     while (true) {
+        // 1. traverse until a batch of candidates is ready
+        { SGE_T0();
         while (stackSize > 0 && candCount < kWave) expandNodes(col, minP, maxP, mask, stackSize, candCount, st);
-        if (candCount == 0) break;
-        int n = candCount < kWave ? candCount : kWave;
-        candCount -= n;
-        st.candidates += n;
-        bool active = lane < n;
+        SGE_T1(cycTrav); }
+        // 2. turn up to 64 candidates into (ray, slot) work items
+        if (candCount > 0 && itemCount <= kItemCap - kWave * kMaxRays) {
+            int n = candCount < kWave ? candCount : kWave;
+            candCount -= n;
+            st.candidates += n;
+            int slot = -1;
+            F3 bmin{0, 0, 0}, bmax{0, 0, 0};
+            if (lane < n) {
+                slot = sh.cand[candCount + lane];
+                const float4* tp = reinterpret_cast<const float4*>(col.tris + slot);
+                float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                F3 v0{t0.x, t0.y, t0.z}, v1{t0.w, t1.x, t1.y}, v2{t1.z, t1.w, t2.x};
+                bmin = vmin(v0, vmin(v1, v2)); bmax = vmax(v0, vmax(v1, v2));
+            }
+            for (int r = 0; r < R; ++r) {
+                bool c = slot >= 0 && sh.rayValid[r] && !boxDisjoint(bmin, bmax, sh.rayMin[r], sh.rayMax[r]);
+                unsigned long long mc = __ballot(c);
+                if (c) sh.items[itemCount + prefixCount(mc)] = (r << 28) | slot;
+                itemCount += __popcll(mc);
+            }
+            __syncthreads();
+        }
+        if (itemCount == 0) { if (candCount == 0 && stackSize == 0) break; else continue; }
+        if (itemCount < kWave && (candCount > 0 || stackSize > 0) && itemCount <= kItemCap - kWave * kMaxRays) continue; // fill the batch
+        // 3. sweep one batch of work items
+        int n = itemCount < kWave ? itemCount : kWave;
+        itemCount -= n;
+        const bool active = lane < n;
+        int myRay = 0;
         Tri tri;
         tri.v0 = tri.v1 = tri.v2 = F3{0, 0, 0}; tri.triIndex = -1; tri.rank = 0x7fffffff;
-        if (active) tri = loadTri(col, sh.cand[candCount + lane]);
+        if (active) {
+            int it = sh.items[itemCount + lane];
+            myRay = (unsigned)it >> 28;
+            tri = loadTri(col, it & 0x0fffffff);
+        }
+        const F3 from = sh.rayFrom[myRay], dir = sh.rayDir[myRay];
+        const float len = sh.rayLen[myRay];
+        const int maxIter = sh.rayMaxIter[myRay];
+        float bestToi = __uint_as_float((unsigned)(sh.rayKey[myRay] >> 32));
         F3 triNormal = normalize(cross(tri.v1 - tri.v0, tri.v2 - tri.v0));
 
         int phase = active ? PH_MARCH : PH_DONE;
         float t = 0, lastSafeT = 0, lo = 0, hi = 0, tEval = 0;
         int iter = 0, refineK = 0;
         unsigned long long myKey = ~0ull;
-
+        SGE_T0();
         while (__any(phase != PH_DONE)) {
             st.trips += 1;
             if (phase == PH_MARCH) {
@@ -319,6 +390,7 @@ __device__ __forceinline__ bool waveCapsuleCast(const DevCollision& col, F3 from
                 if (lo > bestToi) phase = PH_DONE;
                 else tEval = 0.5f * (lo + hi);
             }
+            bool finished = false;
             if (phase != PH_DONE) {
                 st.evals += 1;
                 F3 center = from + dir * tEval;
@@ -352,33 +424,38 @@ __device__ __forceinline__ bool waveCapsuleCast(const DevCollision& col, F3 from
                     phase = PH_DONE;
                     // acceptance filters of capsuleCastBVH :1084-1097 (toi < len; blocking; minNormalY)
                     bool ok = tHit < len;
-                    if (ok && blockingOnly) ok = !(dot(delta, nrm) >= 0) && !(dot(delta, triN) >= 0);
+                    if (ok && blockingOnly) {
+                        F3 delta = sh.rayDelta[myRay];
+                        ok = !(dot(delta, nrm) >= 0) && !(dot(delta, triN) >= 0);
+                    }
                     if (ok && hasMinNormalY) ok = !(triN.y < minNormalY);
                     if (ok) {
                         sh.laneCast[lane] = CastRec{tHit, triP, nrm, triN, tri.triIndex};
                         myKey = ((unsigned long long)__float_as_uint(tHit) << 32) | (unsigned)tri.rank;
+                        atomicMin(&sh.rayKey[myRay], myKey);
+                        finished = true;
                     }
                 }
             }
-            // tighten the prune bound as soon as any lane has an accepted hit
-            unsigned long long got = __ballot(myKey != ~0ull && __uint_as_float((unsigned)(myKey >> 32)) < bestToi);
-            if (got) {
-                unsigned long long k = waveMinU64(myKey);
-                bestToi = smin(bestToi, __uint_as_float((unsigned)(k >> 32)));
+            // tighten every lane's prune bound as soon as any lane has published an accepted hit
+            if (__any(finished)) {
+                __syncthreads();
+                bestToi = __uint_as_float((unsigned)(sh.rayKey[myRay] >> 32));
             }
         }
-        unsigned long long k = waveMinU64(myKey);
-        if (k < bestKey) {
-            bestKey = k;
-            if (myKey == k) sh.bestCast = sh.laneCast[lane];
-        }
+        SGE_T1(cycSweep);
         __syncthreads();
+        if (myKey != ~0ull && sh.rayKey[myRay] == myKey) sh.rayRec[myRay] = sh.laneCast[lane];
+        __syncthreads();
+        if (itemCount == 0 && candCount == 0 && stackSize == 0) break;
     }
-    if (bestKey == ~0ull) return false;
-    out = sh.bestCast;
-    __syncthreads();
-    return true;
+#ifdef SGE_CCD_TIMING
+    if (lane == 0) { atomicAdd(&g_cycTraverse, (unsigned long long)cycTrav); atomicAdd(&g_cycSweep, (unsigned long long)cycSweep); }
+#endif
 }
+
+// one capsuleCastCombined (CollisionQuery.swift:980-1009)
+__device__ __forceinline__ bool rayHit(int r) { return (unsigned)(sh.rayKey[r] & 0xffffffffull) != 0xffffffffu; }
 
 // ---------------------------------------------------------------------------
 // capsuleOverlapAll over the static set (CollisionQuery.swift:852-882, 1201-1283):
@@ -792,17 +869,313 @@ struct MoveState {
     CastRec centerHit; int haveCenter; float gDistance; F3 gNormalSum; int sampleK;
     int nearGround, canSnap, gGrounded, gNear;
     int wasGrounded, wasGroundedNear;
+    // constants of the launch + the agent sweep result of this slide iteration
+    float dt; F3 gravity; const DevMaterial* materials;
+    int aHave; float aToi; F3 aNormal;
 };
 __shared__ MoveState ms;
 
-enum { MP_DEPEN = 0, MP_SLIDE = 1, MP_GROUND_CENTER = 2, MP_GROUND_FALL = 3, MP_GROUND_EVAL = 4, MP_GROUND_SAMPLE = 5,
+enum { MP_DEPEN = 0, MP_SLIDE = 1, MP_GROUND_CENTER = 2, MP_GROUND_EVAL = 4, MP_GROUND_SAMPLE = 5,
        MP_FINISH = 6, MP_DONE = 7 };
 
+// ---- consume steps of the per-character state machine. They work on the LDS-resident state only and are
+// deliberately NOT inlined: the kernel body then holds just the two query loops within its register budget. ----
+__device__ __noinline__ void consumeDepen(int nOverlap) { // DepenetrationResolver.resolve :734-808, one iteration
+    sge_body_state& body = sBody; (void)body;
+    const sge_controller_params& P = sParams; (void)P;
+    sge_controller_state& C = sCtrl; (void)C;
+    const float dt = ms.dt; (void)dt;
+    bool stop = nOverlap == 0;
+    if (!stop) {
+        const int n = nOverlap;
+        // stable sort by depth descending: deepest and second deepest (first occurrence wins ties)
+        int i0 = 0;
+        for (int k = 1; k < n; ++k) if (sh.ovl[k].depth > sh.ovl[i0].depth) i0 = k;
+        int i1 = -1;
+        for (int k = 0; k < n; ++k) {
+            if (k == i0) continue;
+            if (i1 < 0 || sh.ovl[k].depth > sh.ovl[i1].depth) i1 = k;
+        }
+        OverlapRec deepest = sh.ovl[i0];
+        OverlapRec second = i1 >= 0 ? sh.ovl[i1] : deepest;
+        __syncthreads();
+        const float slop = smax(P.skinWidth * 0.5f, 0.001f);
+        bool sideContact = deepest.normal.y < P.minGroundDot;
+        int useCount = sideContact ? 1 : (n < 2 ? n : 2);
+        float maxDepth = deepest.depth;
+        F3 frameNormal{0, 0, 0};
+        for (int k = 0; k < useCount; ++k) {
+            const OverlapRec& hit = k == 0 ? deepest : second;
+            maxDepth = smax(maxDepth, hit.depth);
+            F3 nn = hit.normal, cached;
+            if (cachedNormal(C, hit.triIndex, cached)) nn = cached;
+            frameNormal = frameNormal + nn * hit.depth;
+            cacheRecord(C, hit.triIndex, nn, hit.normal.y < P.minGroundDot);
+        }
+        float frameNormalLen = length(frameNormal);
+        F3 depenNormal = frameNormalLen > 1e-6f ? frameNormal / frameNormalLen : frameNormal;
+        float push = sideContact ? smax(maxDepth, 0.0f) : smax(maxDepth + slop, 0.0f);
+        if (sideContact) push = smin(push, P.skinWidth);
+        if (push <= 1e-6f) {
+            stop = true;
+        } else {
+            ms.position = ms.position + depenNormal * push;
+            D3 dn = toD(depenNormal);
+            D3 velocity = ms.velocity;
+            double vInto = dot(velocity, dn);
+            if (vInto < 0) velocity = velocity - dn * vInto;
+            ms.velocity = velocity;
+            ms.didResolve = 1;
+            ms.normalSum = ms.normalSum + depenNormal * maxDepth;
+            ms.normalWeight += maxDepth;
+            ms.it += 1;
+            if (ms.it >= 4) stop = true;
+        }
+    }
+    if (stop) {
+        if (ms.didResolve) { // applyPreSweepDepenetration :1651-1654
+            F3 depenNormal = ms.normalWeight > 1e-6f ? normalize(ms.normalSum / ms.normalWeight) : normalize(ms.normalSum);
+            float into = dot(ms.remaining, depenNormal);
+            if (into < 0) ms.remaining = ms.remaining - depenNormal * into;
+        }
+        // resolveKinematicSweep prologue :1671-1673
+        F3 baseMove = toF(ms.velocity) * dt;
+        ms.baseMoveLen = length(baseMove);
+        ms.it = 0;
+        ms.phase = MP_SLIDE;
+    }
+}
+
+__device__ __noinline__ void consumeSlide() { // one iteration of resolveKinematicSweep :1674-1764
+    sge_body_state& body = sBody; (void)body;
+    const sge_controller_params& P = sParams; (void)P;
+    sge_controller_state& C = sCtrl; (void)C;
+    const float dt = ms.dt; (void)dt;
+    F3 remaining = ms.remaining, position = ms.position;
+    D3 velocity = ms.velocity;
+    const float len = length(remaining);
+    SlideHit hit;
+    hit.s = sh.rayRec[0]; hit.aToi = 0; hit.aNormal = F3{0, 0, 0}; hit.isStatic = true;
+    bool haveStatic = rayHit(0);
+    if (haveStatic && hit.s.normal.y < P.minGroundDot && C.sideContactFrames > 0) {
+        F3 cached;
+        if (cachedNormal(C, hit.s.triIndex, cached)) {
+            if (dot(cached, hit.s.normal) < 0) cached = -cached;
+            hit.s.normal = cached;
+        }
+    }
+    const bool haveAgent = ms.aHave != 0;
+    if (haveAgent) { hit.aToi = ms.aToi; hit.aNormal = ms.aNormal; }
+    bool endSlide = false;
+    if (haveStatic || haveAgent) {
+        if (haveStatic && haveAgent) { // HitSelector.selectBestHit :1382-1390
+            float staticSkin = hit.s.normal.y >= P.minGroundDot ? P.groundSnapSkin : P.skinWidth;
+            float staticStop = smax(hit.s.toi - staticSkin, 0.0f);
+            float agentStop = smax(hit.aToi, 0.0f);
+            hit.isStatic = staticStop <= agentStop;
+        } else {
+            hit.isStatic = haveStatic;
+        }
+        F3 hitNormal = hit.isStatic ? hit.s.normal : hit.aNormal;
+        bool hasCachedSide = false;
+        F3 cachedSide{0, 0, 0};
+        if (hit.isStatic && hit.s.normal.y < P.minGroundDot && C.sideContactFrames > 0)
+            hasCachedSide = cachedNormal(C, hit.s.triIndex, cachedSide);
+        bool shouldBreak = resolveHit(remaining, len, hit, P, C, ms.wasGrounded != 0, ms.wasGroundedNear != 0, velocity,
+                                      position, hasCachedSide, cachedSide);
+        if (hit.isStatic && hit.s.normal.y < P.minGroundDot) cacheRecord(C, hit.s.triIndex, hit.s.normal, true);
+        if (ms.haveLast) {
+            F3 last = ms.lastSlideNormal;
+            float dotN = dot(last, hitNormal);
+            if (fabsf(dotN) < 0.98f) {
+                F3 axis = cross(last, hitNormal);
+                float axisLen = length(axis);
+                if (axisLen > 1e-5f) {
+                    F3 axisN = axis / axisLen;
+                    remaining = axisN * dot(remaining, axisN);
+                }
+            }
+        }
+        ms.lastSlideNormal = hitNormal;
+        ms.haveLast = 1;
+        endSlide = shouldBreak;
+    } else {
+        position = position + remaining;
+        remaining = F3{0, 0, 0};
+        endSlide = true;
+    }
+    ms.remaining = remaining; ms.position = position; ms.velocity = velocity;
+    ms.it += 1;
+    if (endSlide) ms.phase = MP_GROUND_CENTER;
+}
+
+__device__ __noinline__ void consumeGroundCenter() { // GroundProbe.resolve :844-866
+    sge_body_state& body = sBody; (void)body;
+    const sge_controller_params& P = sParams; (void)P;
+    sge_controller_state& C = sCtrl; (void)C;
+    const float dt = ms.dt; (void)dt;
+    ms.haveCenter = rayHit(0) ? 1 : 0;
+    if (rayHit(0)) ms.centerHit = sh.rayRec[0];
+    if (rayHit(1)) ms.gDistance = sh.rayRec[1].toi;
+    ms.phase = MP_GROUND_EVAL;
+}
+
+__device__ __noinline__ void consumeGroundSample() { // :906-921, in the reference's sample order
+    sge_body_state& body = sBody; (void)body;
+    const sge_controller_params& P = sParams; (void)P;
+    sge_controller_state& C = sCtrl; (void)C;
+    const float dt = ms.dt; (void)dt;
+    const CastRec c = ms.centerHit;
+    float combineTol = smax(smax(P.groundSnapSkin, P.skinWidth), 0.05f);
+    F3 normalSum = ms.gNormalSum;
+    for (int k = 0; k < 4; ++k) {
+        if (rayHit(k) && sh.rayRec[k].toi <= c.toi + combineTol) {
+            if (dot(sh.rayRec[k].triNormal, c.triNormal) > 0.98f) normalSum = normalSum + sh.rayRec[k].triNormal;
+        }
+    }
+    ms.gNormalSum = normalSum;
+    ms.phase = MP_FINISH;
+}
+
+__device__ __noinline__ void groundEval() { // :868-894 — decides whether the four offset casts are needed
+    sge_body_state& body = sBody; (void)body;
+    const sge_controller_params& P = sParams; (void)P;
+    sge_controller_state& C = sCtrl; (void)C;
+    const float dt = ms.dt; (void)dt;
+    const CastRec centerHit = ms.centerHit;
+    if (ms.haveCenter && centerHit.toi <= P.snapDistance) {
+        const F3 position = ms.position;
+        const D3 velocity = ms.velocity;
+        float baseCenterY = position.y - P.halfHeight;
+        float bottomY = baseCenterY - P.radius;
+        float groundTol = smax(P.skinWidth, P.groundSnapSkin);
+        bool validGroundPoint = centerHit.position.y <= bottomY + groundTol;
+        float groundNearThreshold = smax(P.groundSnapSkin, P.skinWidth);
+        bool nearGround = centerHit.toi <= groundNearThreshold;
+        bool groundGateVel = velocity.y <= 0;
+        double vInto = dot(velocity, toD(centerHit.normal));
+        bool groundGateSpeed = vInto >= -(double)P.groundSnapMaxSpeed;
+        bool groundGateToi = centerHit.toi <= P.groundSnapMaxToi;
+        bool canSnap = validGroundPoint && groundGateVel && (nearGround || groundGateSpeed || groundGateToi);
+        if (ms.wasGroundedNear && centerHit.toi <= P.snapDistance) canSnap = validGroundPoint;
+        ms.nearGround = nearGround; ms.gNear = nearGround; ms.canSnap = canSnap;
+        ms.gDistance = centerHit.toi;
+        ms.phase = MP_FINISH;
+        if (validGroundPoint && (nearGround || canSnap)) {
+            ms.gGrounded = 1;
+            ms.gNormalSum = centerHit.triNormal;
+            if (centerHit.triNormal.y < 0.98f && (ms.wasGroundedNear || nearGround)) { ms.sampleK = 0; ms.phase = MP_GROUND_SAMPLE; }
+        }
+    } else {
+        ms.haveCenter = 0; // guard failed: GroundProbeResult(hit: nil), canSnap false
+        ms.phase = MP_FINISH;
+    }
+    __syncthreads();
+}
+
+__device__ __noinline__ void finishStep() { // ground state, GroundSnap, SlopeFriction, writeBack
+    sge_body_state& body = sBody; (void)body;
+    const sge_controller_params& P = sParams; (void)P;
+    sge_controller_state& C = sCtrl; (void)C;
+    const float dt = ms.dt; (void)dt;
+    const F3 gravity = ms.gravity;
+    F3 position = ms.position;
+    D3 velocity = ms.velocity;
+    const CastRec centerHit = ms.centerHit;
+    const bool gGrounded = ms.gGrounded != 0;
+    F3 gNormal{0, 1, 0};
+    DevMaterial gMat{0.8f, 0.6f, 0};
+    int gTri = -1;
+    if (gGrounded) { // :890-937
+        gMat = ms.materials[centerHit.triIndex];
+        gTri = centerHit.triIndex;
+        F3 normalSum = ms.gNormalSum;
+        float nLen = length(normalSum);
+        gNormal = nLen > 1e-6f ? normalSum / nLen : centerHit.triNormal;
+        if (ms.wasGroundedNear) {
+            const F3 prevNormal = ld3(C.groundNormal);
+            float dotN = dot(prevNormal, gNormal);
+            if (dotN > 0.9f) {
+                const float blend = 0.2f;
+                gNormal = normalize(prevNormal * (1 - blend) + gNormal * blend);
+            }
+        }
+        if (gMat.flatten) gNormal = F3{0, 1, 0};
+    }
+    // GroundSnap.apply :945-963
+    if (ms.canSnap && ms.haveCenter) {
+        float rawMove = smax(centerHit.toi - P.groundSnapSkin, 0.0f);
+        float moveDist = rawMove;
+        if (ms.nearGround && moveDist > P.groundSnapMaxStep) moveDist = P.groundSnapMaxStep;
+        position = position + F3{0, -1, 0} * moveDist;
+        D3 nD = toD(centerHit.normal);
+        double vIntoSnap = dot(velocity, nD);
+        if (vIntoSnap < 0) velocity = velocity - nD * vIntoSnap;
+    }
+    if (gGrounded) { // resolveGroundContact :1787-1792
+        float normalUpDelta = gNormal.y - C.groundNormal[1];
+        if (gTri != C.groundTriangleIndex && normalUpDelta > 0.02f) C.groundTransitionFrames = 3;
+    }
+    // SlopeFriction.apply :965-1021
+    if (!gGrounded) {
+        C.flags &= ~(uint32_t)SGE_CTRL_GROUND_SLIDING;
+    } else {
+        F3 normal = normalize(gNormal);
+        if (normal.y > 0.98f) {
+            C.groundTransitionFrames = 0;
+            C.flags &= ~(uint32_t)SGE_CTRL_GROUND_SLIDING;
+        } else if (C.groundTransitionFrames > 0) {
+            C.groundTransitionFrames -= 1;
+            C.flags &= ~(uint32_t)SGE_CTRL_GROUND_SLIDING;
+        } else {
+            float gN = dot(gravity, normal);
+            F3 gTan = gravity - normal * gN;
+            float gTanLen = length(gTan);
+            if (gTanLen > 0.5f) {
+                float gNMag = fabsf(gN);
+                F3 gTanDir = gTan / gTanLen;
+                D3 gTanDirD = toD(gTanDir), normalD = toD(normal);
+                float stickLimit = gMat.muS * gNMag;
+                bool enterSlide = gTanLen > stickLimit * 1.05f;
+                bool exitSlide = gTanLen < stickLimit * 0.9f;
+                bool sliding = (C.flags & SGE_CTRL_GROUND_SLIDING) != 0;
+                if (sliding) { if (exitSlide) sliding = false; }
+                else if (enterSlide) sliding = true;
+                if (sliding) C.flags |= SGE_CTRL_GROUND_SLIDING; else C.flags &= ~(uint32_t)SGE_CTRL_GROUND_SLIDING;
+                if (!sliding && gTanLen <= stickLimit) {
+                    D3 vTan = velocity - normalD * dot(velocity, normalD);
+                    double downhillSpeed = dot(vTan, gTanDirD);
+                    if (downhillSpeed > 0) velocity = velocity - gTanDirD * downhillSpeed;
+                } else {
+                    float slideAccelMag = smax(gTanLen - gMat.muK * gNMag, 0.0f);
+                    if (slideAccelMag > 0) velocity = velocity + gTanDirD * (double)slideAccelMag * (double)dt;
+                }
+            }
+        }
+    }
+    // writeBack :1802-1821
+    D3 pd = toD(position);
+    body.position[0] = pd.x; body.position[1] = pd.y; body.position[2] = pd.z;
+    C.flags &= ~(uint32_t)(SGE_CTRL_GROUNDED | SGE_CTRL_GROUNDED_NEAR);
+    if (gGrounded) C.flags |= SGE_CTRL_GROUNDED;
+    if (ms.gNear) C.flags |= SGE_CTRL_GROUNDED_NEAR;
+    st3(C.groundNormal, gGrounded ? gNormal : F3{0, 1, 0});
+    C.groundDistance = ms.gDistance;
+    if (gGrounded) C.groundTriangleIndex = gTri;
+    ms.velocity = velocity;
+    ms.phase = MP_DONE;
+    __syncthreads();
+}
+
+template <bool AGENTS>
 __global__ __launch_bounds__(kWave, 4) void move_kernel(MoveLaunch K) {
     const int e = K.first + blockIdx.x;
     const int lane = laneId();
     WaveStats st{0, 0, 0, 0, 0, 0};
     const DevCollision& col = K.col;
+#ifdef SGE_CCD_TIMING
+    const long long tStart = (long long)__builtin_amdgcn_s_memtime();
+#endif
     {   // 288 B of state: lanes copy dwords
         const uint32_t* gb = reinterpret_cast<const uint32_t*>(K.crowd.bodies + e);
         const uint32_t* gp = reinterpret_cast<const uint32_t*>(K.crowd.params + e);
@@ -849,11 +1222,12 @@ __global__ __launch_bounds__(kWave, 4) void move_kernel(MoveLaunch K) {
     }
     ms.position = toF(D3{body.position[0], body.position[1], body.position[2]});
     ms.phase = MP_DONE;
+    ms.dt = dt; ms.gravity = gravity; ms.materials = col.materials; ms.aHave = 0; ms.aToi = 0; ms.aNormal = F3{0, 0, 0};
 
     const bool doMove = (K.stages & SGE_STAGE_MOVE) && body.bodyType != SGE_BODY_STATIC;
     const bool hasAgent = (P.agentFlags & SGE_AGENT_PRESENT) != 0;
     const bool selfSolid = hasAgent && (P.agentFlags & SGE_AGENT_SOLID);
-    const bool useAgents = (K.stages & SGE_STAGE_AGENTS) && selfSolid && K.agents.all != nullptr;
+    const bool useAgents = AGENTS && (K.stages & SGE_STAGE_AGENTS) && selfSolid && K.agents.all != nullptr;
     if (doMove) {
         cacheDecay(C);
         ms.wasGrounded = (C.flags & SGE_CTRL_GROUNDED) != 0;
@@ -880,294 +1254,58 @@ __global__ __launch_bounds__(kWave, 4) void move_kernel(MoveLaunch K) {
         const int phase = ms.phase;
         // ---------------- 1. which query does this phase need? ----------------
         bool doOverlap = false, doCast = false, blocking = false;
-        F3 qFrom = ms.position, qDelta{0, 0, 0};
         if (phase == MP_DEPEN) {
             doOverlap = true;
         } else if (phase == MP_SLIDE) {
             // head of the slide loop :1674-1676
             float len = length(ms.remaining);
             if (ms.it >= P.maxSlideIterations || len < 1e-6f) { ms.phase = MP_GROUND_CENTER; __syncthreads(); continue; }
-            doCast = true; blocking = true; qDelta = ms.remaining;
+            doCast = true; blocking = true;
+            sh.rayCount = 1; sh.rayFrom[0] = ms.position; sh.rayDelta[0] = ms.remaining;
         } else if (phase == MP_GROUND_CENTER) {
-            if (!(P.snapDistance > 0)) { ms.haveCenter = 0; ms.phase = MP_GROUND_FALL; __syncthreads(); continue; }
-            doCast = true; qDelta = F3{0, -1, 0} * P.snapDistance;
-        } else if (phase == MP_GROUND_FALL) {
-            if (!(P.fallProbeDistance > 0)) { ms.phase = MP_GROUND_EVAL; __syncthreads(); continue; }
-            doCast = true; qDelta = F3{0, -1, 0} * P.fallProbeDistance;
+            // GroundProbe's snap cast (:844-853) and fall probe (:855-866) share origin, capsule and filters:
+            // two rays of one pass. A disabled probe becomes a zero-length ray (= nil, like :987-988).
+            doCast = true;
+            sh.rayCount = 2;
+            sh.rayFrom[0] = ms.position; sh.rayFrom[1] = ms.position;
+            sh.rayDelta[0] = P.snapDistance > 0 ? F3{0, -1, 0} * P.snapDistance : F3{0, 0, 0};
+            sh.rayDelta[1] = P.fallProbeDistance > 0 ? F3{0, -1, 0} * P.fallProbeDistance : F3{0, 0, 0};
         } else if (phase == MP_GROUND_SAMPLE) {
-            const int k = ms.sampleK;
-            float offset = P.radius * 0.6f;
-            float ox = k == 0 ? offset : (k == 1 ? -offset : 0.0f);
-            float oz = k == 2 ? offset : (k == 3 ? -offset : 0.0f);
-            qFrom = ms.position + F3{ox, 0, oz};
-            doCast = true; qDelta = F3{0, -1, 0} * P.snapDistance;
-        }
-        // ---------------- 2. the query ----------------
-        int nOverlap = 0;
-        bool gotCast = false;
-        CastRec rec;
-        rec.toi = 0; rec.position = rec.normal = rec.triNormal = F3{0, 0, 0}; rec.triIndex = -1;
-        if (doOverlap) nOverlap = waveCapsuleOverlapAll(col, qFrom, P.radius, P.halfHeight, 8, P.collisionMask, st);
-        if (doCast) gotCast = waveCapsuleCast(col, qFrom, qDelta, P.radius, P.halfHeight, blocking, !blocking, P.minGroundDot,
-                                              P.collisionMask, rec, st);
-        // ---------------- 3. consume ----------------
-        if (phase == MP_DEPEN) { // DepenetrationResolver.resolve :734-808, one iteration
-            bool stop = nOverlap == 0;
-            if (!stop) {
-                const int n = nOverlap;
-                // stable sort by depth descending: deepest and second deepest (first occurrence wins ties)
-                int i0 = 0;
-                for (int k = 1; k < n; ++k) if (sh.ovl[k].depth > sh.ovl[i0].depth) i0 = k;
-                int i1 = -1;
-                for (int k = 0; k < n; ++k) {
-                    if (k == i0) continue;
-                    if (i1 < 0 || sh.ovl[k].depth > sh.ovl[i1].depth) i1 = k;
-                }
-                OverlapRec deepest = sh.ovl[i0];
-                OverlapRec second = i1 >= 0 ? sh.ovl[i1] : deepest;
-                __syncthreads();
-                const float slop = smax(P.skinWidth * 0.5f, 0.001f);
-                bool sideContact = deepest.normal.y < P.minGroundDot;
-                int useCount = sideContact ? 1 : (n < 2 ? n : 2);
-                float maxDepth = deepest.depth;
-                F3 frameNormal{0, 0, 0};
-                for (int k = 0; k < useCount; ++k) {
-                    const OverlapRec& hit = k == 0 ? deepest : second;
-                    maxDepth = smax(maxDepth, hit.depth);
-                    F3 nn = hit.normal, cached;
-                    if (cachedNormal(C, hit.triIndex, cached)) nn = cached;
-                    frameNormal = frameNormal + nn * hit.depth;
-                    cacheRecord(C, hit.triIndex, nn, hit.normal.y < P.minGroundDot);
-                }
-                float frameNormalLen = length(frameNormal);
-                F3 depenNormal = frameNormalLen > 1e-6f ? frameNormal / frameNormalLen : frameNormal;
-                float push = sideContact ? smax(maxDepth, 0.0f) : smax(maxDepth + slop, 0.0f);
-                if (sideContact) push = smin(push, P.skinWidth);
-                if (push <= 1e-6f) {
-                    stop = true;
-                } else {
-                    ms.position = ms.position + depenNormal * push;
-                    D3 dn = toD(depenNormal);
-                    D3 velocity = ms.velocity;
-                    double vInto = dot(velocity, dn);
-                    if (vInto < 0) velocity = velocity - dn * vInto;
-                    ms.velocity = velocity;
-                    ms.didResolve = 1;
-                    ms.normalSum = ms.normalSum + depenNormal * maxDepth;
-                    ms.normalWeight += maxDepth;
-                    ms.it += 1;
-                    if (ms.it >= 4) stop = true;
-                }
+            // the four offset casts of :898-921, one pass
+            doCast = true;
+            sh.rayCount = 4;
+            const float offset = P.radius * 0.6f;
+            const F3 snapDelta = F3{0, -1, 0} * P.snapDistance;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float ox = k == 0 ? offset : (k == 1 ? -offset : 0.0f);
+                float oz = k == 2 ? offset : (k == 3 ? -offset : 0.0f);
+                sh.rayFrom[k] = ms.position + F3{ox, 0, oz};
+                sh.rayDelta[k] = snapDelta;
             }
-            if (stop) {
-                if (ms.didResolve) { // applyPreSweepDepenetration :1651-1654
-                    F3 depenNormal = ms.normalWeight > 1e-6f ? normalize(ms.normalSum / ms.normalWeight) : normalize(ms.normalSum);
-                    float into = dot(ms.remaining, depenNormal);
-                    if (into < 0) ms.remaining = ms.remaining - depenNormal * into;
-                }
-                // resolveKinematicSweep prologue :1671-1673
-                F3 baseMove = toF(ms.velocity) * dt;
-                ms.baseMoveLen = length(baseMove);
-                ms.it = 0;
-                ms.phase = MP_SLIDE;
-            }
-        } else if (phase == MP_SLIDE) { // one iteration of resolveKinematicSweep :1674-1764
-            F3 remaining = ms.remaining, position = ms.position;
-            D3 velocity = ms.velocity;
-            const float len = length(remaining);
-            SlideHit hit;
-            hit.s = rec; hit.aToi = 0; hit.aNormal = F3{0, 0, 0}; hit.isStatic = true;
-            bool haveStatic = gotCast;
-            if (haveStatic && hit.s.normal.y < P.minGroundDot && C.sideContactFrames > 0) {
-                F3 cached;
-                if (cachedNormal(C, hit.s.triIndex, cached)) {
-                    if (dot(cached, hit.s.normal) < 0) cached = -cached;
-                    hit.s.normal = cached;
-                }
-            }
-            bool haveAgent = false;
-            if (useAgents) {
-                const float selfRadius = (hasAgent && (P.agentFlags & SGE_AGENT_RADIUS_OVERRIDE)) ? P.agentRadiusOverride : P.radius;
-                haveAgent = waveAgentBestHit(K.agents, position, remaining, len, ms.baseMoveLen, dt, K.agents.selfOffset + e,
-                                             selfRadius, P.halfHeight, K.agents.maxRadius, K.agents.maxSpeed, hit.aToi, hit.aNormal);
-            }
-            bool endSlide = false;
-            if (haveStatic || haveAgent) {
-                if (haveStatic && haveAgent) { // HitSelector.selectBestHit :1382-1390
-                    float staticSkin = hit.s.normal.y >= P.minGroundDot ? P.groundSnapSkin : P.skinWidth;
-                    float staticStop = smax(hit.s.toi - staticSkin, 0.0f);
-                    float agentStop = smax(hit.aToi, 0.0f);
-                    hit.isStatic = staticStop <= agentStop;
-                } else {
-                    hit.isStatic = haveStatic;
-                }
-                F3 hitNormal = hit.isStatic ? hit.s.normal : hit.aNormal;
-                bool hasCachedSide = false;
-                F3 cachedSide{0, 0, 0};
-                if (hit.isStatic && hit.s.normal.y < P.minGroundDot && C.sideContactFrames > 0)
-                    hasCachedSide = cachedNormal(C, hit.s.triIndex, cachedSide);
-                bool shouldBreak = resolveHit(remaining, len, hit, P, C, ms.wasGrounded != 0, ms.wasGroundedNear != 0, velocity,
-                                              position, hasCachedSide, cachedSide);
-                if (hit.isStatic && hit.s.normal.y < P.minGroundDot) cacheRecord(C, hit.s.triIndex, hit.s.normal, true);
-                if (ms.haveLast) {
-                    F3 last = ms.lastSlideNormal;
-                    float dotN = dot(last, hitNormal);
-                    if (fabsf(dotN) < 0.98f) {
-                        F3 axis = cross(last, hitNormal);
-                        float axisLen = length(axis);
-                        if (axisLen > 1e-5f) {
-                            F3 axisN = axis / axisLen;
-                            remaining = axisN * dot(remaining, axisN);
-                        }
-                    }
-                }
-                ms.lastSlideNormal = hitNormal;
-                ms.haveLast = 1;
-                endSlide = shouldBreak;
-            } else {
-                position = position + remaining;
-                remaining = F3{0, 0, 0};
-                endSlide = true;
-            }
-            ms.remaining = remaining; ms.position = position; ms.velocity = velocity;
-            ms.it += 1;
-            if (endSlide) ms.phase = MP_GROUND_CENTER;
-        } else if (phase == MP_GROUND_CENTER) { // GroundProbe.resolve :844-853
-            ms.haveCenter = gotCast ? 1 : 0;
-            if (gotCast) ms.centerHit = rec;
-            ms.phase = MP_GROUND_FALL;
-        } else if (phase == MP_GROUND_FALL) { // :855-866
-            if (gotCast) ms.gDistance = rec.toi;
-            ms.phase = MP_GROUND_EVAL;
-        } else if (phase == MP_GROUND_SAMPLE) { // :906-921
-            const CastRec c = ms.centerHit;
-            float combineTol = smax(smax(P.groundSnapSkin, P.skinWidth), 0.05f);
-            if (gotCast && rec.toi <= c.toi + combineTol) {
-                if (dot(rec.triNormal, c.triNormal) > 0.98f) ms.gNormalSum = ms.gNormalSum + rec.triNormal;
-            }
-            ms.sampleK += 1;
-            if (ms.sampleK >= 4) ms.phase = MP_FINISH;
         }
         __syncthreads();
-        if (ms.phase == MP_GROUND_EVAL) { // :868-894 — decides whether the four offset casts are needed
-            const CastRec centerHit = ms.centerHit;
-            if (ms.haveCenter && centerHit.toi <= P.snapDistance) {
-                const F3 position = ms.position;
-                const D3 velocity = ms.velocity;
-                float baseCenterY = position.y - P.halfHeight;
-                float bottomY = baseCenterY - P.radius;
-                float groundTol = smax(P.skinWidth, P.groundSnapSkin);
-                bool validGroundPoint = centerHit.position.y <= bottomY + groundTol;
-                float groundNearThreshold = smax(P.groundSnapSkin, P.skinWidth);
-                bool nearGround = centerHit.toi <= groundNearThreshold;
-                bool groundGateVel = velocity.y <= 0;
-                double vInto = dot(velocity, toD(centerHit.normal));
-                bool groundGateSpeed = vInto >= -(double)P.groundSnapMaxSpeed;
-                bool groundGateToi = centerHit.toi <= P.groundSnapMaxToi;
-                bool canSnap = validGroundPoint && groundGateVel && (nearGround || groundGateSpeed || groundGateToi);
-                if (ms.wasGroundedNear && centerHit.toi <= P.snapDistance) canSnap = validGroundPoint;
-                ms.nearGround = nearGround; ms.gNear = nearGround; ms.canSnap = canSnap;
-                ms.gDistance = centerHit.toi;
-                ms.phase = MP_FINISH;
-                if (validGroundPoint && (nearGround || canSnap)) {
-                    ms.gGrounded = 1;
-                    ms.gNormalSum = centerHit.triNormal;
-                    if (centerHit.triNormal.y < 0.98f && (ms.wasGroundedNear || nearGround)) { ms.sampleK = 0; ms.phase = MP_GROUND_SAMPLE; }
-                }
-            } else {
-                ms.haveCenter = 0; // guard failed: GroundProbeResult(hit: nil), canSnap false
-                ms.phase = MP_FINISH;
+        // ---------------- 2. the query ----------------
+        int nOverlap = 0;
+        if (doOverlap) nOverlap = waveCapsuleOverlapAll(col, ms.position, P.radius, P.halfHeight, 8, P.collisionMask, st);
+        if (doCast) waveCastRays(col, P.radius, P.halfHeight, blocking, !blocking, P.minGroundDot, P.collisionMask, st);
+        // ---------------- 3. consume ----------------
+        if (phase == MP_DEPEN) consumeDepen(nOverlap);
+        else if (phase == MP_SLIDE) {
+            if (AGENTS && useAgents) { // AgentSweepSolver.bestHit :1053-1091 (independent of the static hit)
+                const F3 remaining = ms.remaining;
+                const float selfRadius = (hasAgent && (P.agentFlags & SGE_AGENT_RADIUS_OVERRIDE)) ? P.agentRadiusOverride : P.radius;
+                float aToi = 0; F3 aNormal{0, 0, 0};
+                bool have = waveAgentBestHit(K.agents, ms.position, remaining, length(remaining), ms.baseMoveLen, dt, K.agents.selfOffset + e,
+                                             selfRadius, P.halfHeight, K.agents.maxRadius, K.agents.maxSpeed, aToi, aNormal);
+                ms.aHave = have ? 1 : 0; ms.aToi = aToi; ms.aNormal = aNormal;
             }
-            __syncthreads();
-        }
-        if (ms.phase == MP_FINISH) {
-            F3 position = ms.position;
-            D3 velocity = ms.velocity;
-            const CastRec centerHit = ms.centerHit;
-            const bool gGrounded = ms.gGrounded != 0;
-            F3 gNormal{0, 1, 0};
-            DevMaterial gMat{0.8f, 0.6f, 0};
-            int gTri = -1;
-            if (gGrounded) { // :890-937
-                gMat = col.materials[centerHit.triIndex];
-                gTri = centerHit.triIndex;
-                F3 normalSum = ms.gNormalSum;
-                float nLen = length(normalSum);
-                gNormal = nLen > 1e-6f ? normalSum / nLen : centerHit.triNormal;
-                if (ms.wasGroundedNear) {
-                    const F3 prevNormal = ld3(C.groundNormal);
-                    float dotN = dot(prevNormal, gNormal);
-                    if (dotN > 0.9f) {
-                        const float blend = 0.2f;
-                        gNormal = normalize(prevNormal * (1 - blend) + gNormal * blend);
-                    }
-                }
-                if (gMat.flatten) gNormal = F3{0, 1, 0};
-            }
-            // GroundSnap.apply :945-963
-            if (ms.canSnap && ms.haveCenter) {
-                float rawMove = smax(centerHit.toi - P.groundSnapSkin, 0.0f);
-                float moveDist = rawMove;
-                if (ms.nearGround && moveDist > P.groundSnapMaxStep) moveDist = P.groundSnapMaxStep;
-                position = position + F3{0, -1, 0} * moveDist;
-                D3 nD = toD(centerHit.normal);
-                double vIntoSnap = dot(velocity, nD);
-                if (vIntoSnap < 0) velocity = velocity - nD * vIntoSnap;
-            }
-            if (gGrounded) { // resolveGroundContact :1787-1792
-                float normalUpDelta = gNormal.y - C.groundNormal[1];
-                if (gTri != C.groundTriangleIndex && normalUpDelta > 0.02f) C.groundTransitionFrames = 3;
-            }
-            // SlopeFriction.apply :965-1021
-            if (!gGrounded) {
-                C.flags &= ~(uint32_t)SGE_CTRL_GROUND_SLIDING;
-            } else {
-                F3 normal = normalize(gNormal);
-                if (normal.y > 0.98f) {
-                    C.groundTransitionFrames = 0;
-                    C.flags &= ~(uint32_t)SGE_CTRL_GROUND_SLIDING;
-                } else if (C.groundTransitionFrames > 0) {
-                    C.groundTransitionFrames -= 1;
-                    C.flags &= ~(uint32_t)SGE_CTRL_GROUND_SLIDING;
-                } else {
-                    float gN = dot(gravity, normal);
-                    F3 gTan = gravity - normal * gN;
-                    float gTanLen = length(gTan);
-                    if (gTanLen > 0.5f) {
-                        float gNMag = fabsf(gN);
-                        F3 gTanDir = gTan / gTanLen;
-                        D3 gTanDirD = toD(gTanDir), normalD = toD(normal);
-                        float stickLimit = gMat.muS * gNMag;
-                        bool enterSlide = gTanLen > stickLimit * 1.05f;
-                        bool exitSlide = gTanLen < stickLimit * 0.9f;
-                        bool sliding = (C.flags & SGE_CTRL_GROUND_SLIDING) != 0;
-                        if (sliding) { if (exitSlide) sliding = false; }
-                        else if (enterSlide) sliding = true;
-                        if (sliding) C.flags |= SGE_CTRL_GROUND_SLIDING; else C.flags &= ~(uint32_t)SGE_CTRL_GROUND_SLIDING;
-                        if (!sliding && gTanLen <= stickLimit) {
-                            D3 vTan = velocity - normalD * dot(velocity, normalD);
-                            double downhillSpeed = dot(vTan, gTanDirD);
-                            if (downhillSpeed > 0) velocity = velocity - gTanDirD * downhillSpeed;
-                        } else {
-                            float slideAccelMag = smax(gTanLen - gMat.muK * gNMag, 0.0f);
-                            if (slideAccelMag > 0) velocity = velocity + gTanDirD * (double)slideAccelMag * (double)dt;
-                        }
-                    }
-                }
-            }
-            // writeBack :1802-1821
-            D3 pd = toD(position);
-            body.position[0] = pd.x; body.position[1] = pd.y; body.position[2] = pd.z;
-            C.flags &= ~(uint32_t)(SGE_CTRL_GROUNDED | SGE_CTRL_GROUNDED_NEAR);
-            if (gGrounded) C.flags |= SGE_CTRL_GROUNDED;
-            if (ms.gNear) C.flags |= SGE_CTRL_GROUNDED_NEAR;
-            st3(C.groundNormal, gGrounded ? gNormal : F3{0, 1, 0});
-            C.groundDistance = ms.gDistance;
-            if (gGrounded) C.groundTriangleIndex = gTri;
-            ms.velocity = velocity;
-            ms.phase = MP_DONE;
-            __syncthreads();
-        }
+            consumeSlide();
+        } else if (phase == MP_GROUND_CENTER) consumeGroundCenter();
+        else if (phase == MP_GROUND_SAMPLE) consumeGroundSample();
+        __syncthreads();
+        if (ms.phase == MP_GROUND_EVAL) { groundEval(); __syncthreads(); }
+        if (ms.phase == MP_FINISH) { finishStep(); __syncthreads(); }
     }
 
     {
@@ -1181,6 +1319,11 @@ __global__ __launch_bounds__(kWave, 4) void move_kernel(MoveLaunch K) {
         if (lane < 24) gb[lane] = reinterpret_cast<const uint32_t*>(&sBody)[lane];
         if (lane < 32) gc[lane] = reinterpret_cast<const uint32_t*>(&sCtrl)[lane];
     }
+#ifdef SGE_CCD_TIMING
+    if (lane == 0) {
+        atomicAdd(&g_cycTotal, (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - tStart));
+    }
+#endif
     if (K.stats) {
         // evals are counted per lane; sum over the wave
         unsigned v = st.evals;
@@ -1189,17 +1332,23 @@ __global__ __launch_bounds__(kWave, 4) void move_kernel(MoveLaunch K) {
         if (lane == 0) {
             atomicAdd(&K.stats[0], (unsigned long long)st.queries);
             atomicAdd(&K.stats[1], (unsigned long long)st.candidates);
-            atomicAdd(&K.stats[2], (unsigned long long)v);
             atomicAdd(&K.stats[3], (unsigned long long)st.overflow);
+#ifdef SGE_CCD_TIMING
+            // diagnostic build: the three counters below carry cycle sums instead
+            K.stats[2] = g_cycTotal; K.stats[4] = g_cycTraverse; K.stats[5] = g_cycSweep;
+#else
+            atomicAdd(&K.stats[2], (unsigned long long)v);
             atomicAdd(&K.stats[4], (unsigned long long)st.steps);
             atomicAdd(&K.stats[5], (unsigned long long)st.trips);
+#endif
         }
     }
 }
 
 void launch_move(const MoveLaunch& L, hipStream_t s) {
     if (L.count <= 0) return;
-    hipLaunchKernelGGL(move_kernel, dim3(L.count), dim3(kWave), 0, s, L);
+    if ((L.stages & SGE_STAGE_AGENTS) && L.agents.all) hipLaunchKernelGGL(move_kernel<true>, dim3(L.count), dim3(kWave), 0, s, L);
+    else hipLaunchKernelGGL(move_kernel<false>, dim3(L.count), dim3(kWave), 0, s, L);
 }
 
 // ---- batched single queries (the CollisionQuery facade) ---------------------
@@ -1208,9 +1357,13 @@ __global__ __launch_bounds__(kWave, 4) void cast_query_kernel(DevCollision col, 
     const int i = blockIdx.x;
     WaveStats st{0, 0, 0, 0, 0, 0};
     sge_capsule_query Q = q[i];
-    CastRec r;
-    bool got = waveCapsuleCast(col, F3{Q.from[0], Q.from[1], Q.from[2]}, F3{Q.delta[0], Q.delta[1], Q.delta[2]}, Q.radius,
-                               Q.halfHeight, Q.mode == SGE_CAST_BLOCKING, Q.mode == SGE_CAST_GROUND, Q.minNormalY, Q.mask, r, st);
+    sh.rayCount = 1;
+    sh.rayFrom[0] = F3{Q.from[0], Q.from[1], Q.from[2]};
+    sh.rayDelta[0] = F3{Q.delta[0], Q.delta[1], Q.delta[2]};
+    __syncthreads();
+    waveCastRays(col, Q.radius, Q.halfHeight, Q.mode == SGE_CAST_BLOCKING, Q.mode == SGE_CAST_GROUND, Q.minNormalY, Q.mask, st);
+    const bool got = rayHit(0);
+    const CastRec r = sh.rayRec[0];
     if (laneId() == 0) {
         sge_capsule_cast_hit h;
         h.hit = got ? 1 : 0;
