@@ -67,7 +67,7 @@ struct sge_context {
     // collision
     HostCollision hostCol;
     DevCollision col{};
-    DevBuf dNodes, dTris, dMaterials;
+    DevBuf dNodes, dWide, dTris, dMaterials;
     // crowd
     DevCrowd crowd{};
     DevBuf dBodies, dParams, dCtrl, dIntents, dLoco, dActions, dPalettes, dPoseModel, dPoseLocal;
@@ -287,7 +287,7 @@ void sge_context_destroy(sge_context* c) {
     drainEvents(c->evMove); drainEvents(c->evPose); drainEvents(c->evSkin); drainEvents(c->evAgents);
     DevBuf* bufs[] = {&c->dParent, &c->dDepth, &c->dLeanChain, &c->dBindLocal, &c->dInvBind, &c->dRestT, &c->dRawRestT, &c->dPreRot,
                       &c->dCoeffs, &c->dCoeffCount, &c->dBonePresent, &c->dMeshPos, &c->dMeshNrm, &c->dMeshTan, &c->dMeshIdx, &c->dMeshWgt,
-                      &c->dNodes, &c->dTris, &c->dMaterials, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
+                      &c->dNodes, &c->dWide, &c->dTris, &c->dMaterials, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
                       &c->dPalettes, &c->dPoseModel, &c->dPoseLocal, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
                       &c->dCellCursor, &c->dAgentMinMax, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats};
     for (DevBuf* b : bufs) b->release();
@@ -534,10 +534,12 @@ int sge_collision_rebuild_static(sge_context* c, const sge_static_mesh_entity* e
     (void)hipSetDevice(c->device);
     int rc;
     if ((rc = upload(c->dNodes, nodes.data(), nodes.size() * sizeof(DevNode), c->stream)) != SGE_OK) return rc;
+    if ((rc = upload(c->dWide, hc.wide.data(), hc.wide.size() * sizeof(DevNode), c->stream)) != SGE_OK) return rc;
     if ((rc = upload(c->dTris, tris.data(), tris.size() * sizeof(DevTri), c->stream)) != SGE_OK) return rc;
     if ((rc = upload(c->dMaterials, mats.data(), mats.size() * sizeof(DevMaterial), c->stream)) != SGE_OK) return rc;
     SGE_HIP(hipStreamSynchronize(c->stream));
-    c->col = DevCollision{(int)nodes.size(), T, hc.root, c->dNodes.as<DevNode>(), c->dTris.as<DevTri>(), c->dMaterials.as<DevMaterial>()};
+    c->col = DevCollision{(int)nodes.size(), T, hc.root, c->dWide.as<DevNode>(), (int)(hc.wide.size() / kWideWidth),
+                          c->dNodes.as<DevNode>(), c->dTris.as<DevTri>(), c->dMaterials.as<DevMaterial>()};
     return SGE_OK;
 }
 

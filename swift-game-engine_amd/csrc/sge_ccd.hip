@@ -36,8 +36,8 @@ namespace sge {
 
 constexpr int kWave = 64;
 constexpr int kStackCap = 1024;
-constexpr int kStackSoft = 768;   // above this, pop one node at a time (growth <= tree depth)
 constexpr int kCandCap = 512;
+constexpr int kRangeCap = 128;
 constexpr int kItemCap = 512;
 constexpr int kMaxRays = 4;
 
@@ -47,6 +47,7 @@ struct CastRec { float toi; F3 position, normal, triNormal; int triIndex; };
 struct WaveShared {
     int stack[kStackCap];
     int cand[kCandCap];
+    int ranges[kRangeCap];   // pending (firstSlot << 7 | count) triangle ranges of the wide BVH
     CastRec laneCast[kWave]; // each lane's accepted hit of the current batch
     int items[kItemCap];     // (ray << 28) | slot work items of a multi-ray cast
     // up to kMaxRays casts that share radius/halfHeight/filters run as ONE traversal + shared sweep batches
@@ -214,39 +215,20 @@ __device__ __forceinline__ bool boxDisjoint(F3 bmin, F3 bmax, F3 minP, F3 maxP) 
     return bmax.x < minP.x || bmin.x > maxP.x || bmax.y < minP.y || bmin.y > maxP.y || bmax.z < minP.z || bmin.z > maxP.z;
 }
 
+// One traversal step over the wide BVH (DevCollision::wide): either scan one pending triangle range
+// (<= 64 triangles, one per lane, coalesced 48-B records) into the candidate list, or pop one wide node and
+// test its 64 entries (one per lane, one coalesced 2-KB load). Ranges are consumed before the next pop, so
+// at most 64 of them are ever pending.
 __device__ __forceinline__ void expandNodes(const DevCollision& col, F3 minP, F3 maxP, uint32_t mask,
-                                            int& stackSize, int& candCount, WaveStats& st) {
+                                            int& stackSize, int& rangeCount, int& candCount, WaveStats& st) {
     const int lane = laneId();
     st.steps += 1;
-    int n = stackSize > kStackSoft ? 1 : (stackSize < kWave ? stackSize : kWave);
-    int myNode = lane < n ? sh.stack[stackSize - 1 - lane] : -1;
-    stackSize -= n;
-    __syncthreads();
-    bool overlap = false;
-    int a = 0, b = 0;
-    if (myNode >= 0) {
-        const float4* np = reinterpret_cast<const float4*>(col.nodes + myNode);
-        float4 n0 = np[0], n1 = np[1];
-        overlap = !boxDisjoint(F3{n0.x, n0.y, n0.z}, F3{n0.w, n1.x, n1.y}, minP, maxP);
-        a = __float_as_int(n1.z);
-        b = __float_as_int(n1.w);
-    }
-    const bool leaf = a < 0;
-    const bool pushI = overlap && !leaf;
-    unsigned long long m = __ballot(pushI);
-    int tot = __popcll(m);
-    if (stackSize + 2 * tot > kStackCap) { st.overflow += 1; }
-    else if (pushI) {
-        int pre = prefixCount(m);
-        sh.stack[stackSize + 2 * pre] = a;
-        sh.stack[stackSize + 2 * pre + 1] = b;
-    }
-    if (stackSize + 2 * tot <= kStackCap) stackSize += 2 * tot;
-    const int firstSlot = ~a;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        bool c = overlap && leaf && k < b;
-        int slot = firstSlot + k;
+    if (rangeCount > 0) {
+        rangeCount -= 1;
+        const int packed = sh.ranges[rangeCount]; // (firstSlot << 7) | count, count in 1..64
+        const int first = packed >> 7, cnt = packed & 127;
+        bool c = lane < cnt;
+        const int slot = first + lane;
         if (c) {
             const float4* tp = reinterpret_cast<const float4*>(col.tris + slot);
             float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
@@ -261,6 +243,25 @@ __device__ __forceinline__ void expandNodes(const DevCollision& col, F3 minP, F3
             if (c) sh.cand[candCount + prefixCount(mc)] = slot;
             candCount += totc;
         }
+        __syncthreads();
+        return;
+    }
+    stackSize -= 1;
+    const int w = sh.stack[stackSize];
+    __syncthreads();
+    const float4* np = reinterpret_cast<const float4*>(col.wide + (size_t)w * kWideWidth + lane);
+    float4 n0 = np[0], n1 = np[1];
+    const bool overlap = !boxDisjoint(F3{n0.x, n0.y, n0.z}, F3{n0.w, n1.x, n1.y}, minP, maxP);
+    const int a = __float_as_int(n1.z), b = __float_as_int(n1.w);
+    const bool isRange = b > 0;
+    const unsigned long long mi = __ballot(overlap && !isRange), mr = __ballot(overlap && isRange);
+    const int ti = __popcll(mi), tr = __popcll(mr);
+    if (stackSize + ti > kStackCap || rangeCount + tr > kRangeCap) { st.overflow += 1; }
+    else {
+        if (overlap && !isRange) sh.stack[stackSize + prefixCount(mi)] = a;
+        if (overlap && isRange) sh.ranges[rangeCount + prefixCount(mr)] = ((~a) << 7) | b;
+        stackSize += ti;
+        rangeCount += tr;
     }
     __syncthreads();
 }
@@ -324,14 +325,14 @@ __device__ __forceinline__ void waveCastRays(const DevCollision& col, float radi
     const float minAdvance = smax(radius * 0.02f, 1e-4f); // :1295
     const float contactEps = 1e-5f;
     long long cycTrav = 0, cycSweep = 0; (void)cycTrav; (void)cycSweep;
-    int stackSize = 1, candCount = 0, itemCount = 0;
-    if (lane == 0) sh.stack[0] = col.root;
+    int stackSize = 1, rangeCount = 0, candCount = 0, itemCount = 0;
+    if (lane == 0) sh.stack[0] = 0;
     __syncthreads();
 
     while (true) {
         // 1. traverse until a batch of candidates is ready
         { SGE_T0();
-        while (stackSize > 0 && candCount < kWave) expandNodes(col, minP, maxP, mask, stackSize, candCount, st);
+        while ((stackSize > 0 || rangeCount > 0) && candCount < kWave) expandNodes(col, minP, maxP, mask, stackSize, rangeCount, candCount, st);
         SGE_T1(cycTrav); }
         // 2. turn up to 64 candidates into (ray, slot) work items
         if (candCount > 0 && itemCount <= kItemCap - kWave * kMaxRays) {
@@ -355,8 +356,8 @@ __device__ __forceinline__ void waveCastRays(const DevCollision& col, float radi
             }
             __syncthreads();
         }
-        if (itemCount == 0) { if (candCount == 0 && stackSize == 0) break; else continue; }
-        if (itemCount < kWave && (candCount > 0 || stackSize > 0) && itemCount <= kItemCap - kWave * kMaxRays) continue; // fill the batch
+        if (itemCount == 0) { if (candCount == 0 && stackSize == 0 && rangeCount == 0) break; else continue; }
+        if (itemCount < kWave && (candCount > 0 || stackSize > 0 || rangeCount > 0) && itemCount <= kItemCap - kWave * kMaxRays) continue; // fill the batch
         // 3. sweep one batch of work items
         int n = itemCount < kWave ? itemCount : kWave;
         itemCount -= n;
@@ -447,7 +448,7 @@ __device__ __forceinline__ void waveCastRays(const DevCollision& col, float radi
         __syncthreads();
         if (myKey != ~0ull && sh.rayKey[myRay] == myKey) sh.rayRec[myRay] = sh.laneCast[lane];
         __syncthreads();
-        if (itemCount == 0 && candCount == 0 && stackSize == 0) break;
+        if (itemCount == 0 && candCount == 0 && stackSize == 0 && rangeCount == 0) break;
     }
 #ifdef SGE_CCD_TIMING
     if (lane == 0) { atomicAdd(&g_cycTraverse, (unsigned long long)cycTrav); atomicAdd(&g_cycSweep, (unsigned long long)cycSweep); }
@@ -472,11 +473,11 @@ __device__ __forceinline__ int waveCapsuleOverlapAll(const DevCollision& col, F3
     F3 ext{radius, radius, radius};
     minP = minP - ext; maxP = maxP + ext;
     int count = 0; // entries in sh.ovl, sorted by rank
-    int stackSize = 1, candCount = 0;
-    if (lane == 0) sh.stack[0] = col.root;
+    int stackSize = 1, rangeCount = 0, candCount = 0;
+    if (lane == 0) sh.stack[0] = 0;
     __syncthreads();
     while (true) {
-        while (stackSize > 0 && candCount < kWave) expandNodes(col, minP, maxP, mask, stackSize, candCount, st);
+        while ((stackSize > 0 || rangeCount > 0) && candCount < kWave) expandNodes(col, minP, maxP, mask, stackSize, rangeCount, candCount, st);
         if (candCount == 0) break;
         int n = candCount < kWave ? candCount : kWave;
         candCount -= n;
@@ -1168,7 +1169,7 @@ __device__ __noinline__ void finishStep() { // ground state, GroundSnap, SlopeFr
 }
 
 template <bool AGENTS>
-__global__ __launch_bounds__(kWave, 4) void move_kernel(MoveLaunch K) {
+__global__ __launch_bounds__(kWave, 2) void move_kernel(MoveLaunch K) {
     const int e = K.first + blockIdx.x;
     const int lane = laneId();
     WaveStats st{0, 0, 0, 0, 0, 0};
@@ -1352,7 +1353,7 @@ void launch_move(const MoveLaunch& L, hipStream_t s) {
 }
 
 // ---- batched single queries (the CollisionQuery facade) ---------------------
-__global__ __launch_bounds__(kWave, 4) void cast_query_kernel(DevCollision col, const sge_capsule_query* q, int n,
+__global__ __launch_bounds__(kWave, 3) void cast_query_kernel(DevCollision col, const sge_capsule_query* q, int n,
                                                            sge_capsule_cast_hit* out, unsigned long long* stats) {
     const int i = blockIdx.x;
     WaveStats st{0, 0, 0, 0, 0, 0};
@@ -1385,7 +1386,7 @@ __global__ __launch_bounds__(kWave, 4) void cast_query_kernel(DevCollision col, 
     }
 }
 
-__global__ __launch_bounds__(kWave, 4) void overlap_query_kernel(DevCollision col, const sge_capsule_query* q, int n, int maxHits,
+__global__ __launch_bounds__(kWave, 3) void overlap_query_kernel(DevCollision col, const sge_capsule_query* q, int n, int maxHits,
                                                               sge_capsule_overlap_hit* out, int32_t* counts,
                                                               unsigned long long* stats) {
     const int i = blockIdx.x;

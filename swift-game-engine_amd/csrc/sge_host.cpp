@@ -180,6 +180,56 @@ void HostCollision::rebuild(const sge_static_mesh_entity* ents, int count) {
             stack.push_back(n.right);
         }
     }
+    buildWide();
+}
+
+// Treelet cut of the binary BVH (see DevCollision): starting from a binary node, repeatedly open the frontier
+// entry with the most triangles until kWideWidth entries exist or every entry holds <= kWideWidth triangles.
+// Subtree triangle ranges are contiguous in triOrder because BVH.build partitions in place
+// (left = [start, mid), right = [mid, end), CollisionQuery.swift:655-663).
+void HostCollision::buildWide() {
+    wide.clear();
+    if (root < 0) return;
+    const int N = (int)nodes.size();
+    std::vector<int> cnt(N), lo(N);
+    for (int i = N - 1; i >= 0; --i) { // children follow their parent (pre-order), so a reverse sweep is post-order
+        const HostBVHNode& n = nodes[i];
+        if (n.left < 0) { cnt[i] = n.count; lo[i] = n.start; }
+        else { cnt[i] = cnt[n.left] + cnt[n.right]; lo[i] = std::min(lo[n.left], lo[n.right]); }
+    }
+    struct Job { int binary, wideIndex; };
+    std::vector<Job> jobs{{root, 0}};
+    wide.resize(kWideWidth);
+    for (size_t q = 0; q < jobs.size(); ++q) {
+        std::vector<int> frontier{jobs[q].binary};
+        while ((int)frontier.size() < kWideWidth) {
+            int best = -1;
+            for (int k = 0; k < (int)frontier.size(); ++k) {
+                int b = frontier[k];
+                if (nodes[b].left >= 0 && cnt[b] > kWideWidth && (best < 0 || cnt[b] > cnt[frontier[best]])) best = k;
+            }
+            if (best < 0) break;
+            int b = frontier[best];
+            frontier[best] = nodes[b].left;
+            frontier.push_back(nodes[b].right);
+        }
+        for (int k = 0; k < kWideWidth; ++k) {
+            DevNode d{kFloatMax, kFloatMax, kFloatMax, -kFloatMax, -kFloatMax, -kFloatMax, 0, 0};
+            if (k < (int)frontier.size()) {
+                int b = frontier[k];
+                const HostBVHNode& n = nodes[b];
+                d = DevNode{n.mn[0], n.mn[1], n.mn[2], n.mx[0], n.mx[1], n.mx[2], 0, 0};
+                if (cnt[b] <= kWideWidth) { d.a = ~lo[b]; d.b = cnt[b]; }
+                else {
+                    int w = (int)(wide.size() / kWideWidth);
+                    wide.resize(wide.size() + kWideWidth);
+                    jobs.push_back({b, w});
+                    d.a = w; d.b = 0;
+                }
+            }
+            wide[(size_t)jobs[q].wideIndex * kWideWidth + k] = d;
+        }
+    }
 }
 
 } // namespace sge

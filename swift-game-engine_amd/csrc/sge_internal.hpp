@@ -68,8 +68,16 @@ struct DevProfiles {
     const uint8_t* bonePresent; // [P][B]
 };
 
+// Wide BVH the kernels traverse: every wide node is kWideWidth consecutive DevNode entries (2 KB) — a treelet cut
+// out of the reference's binary tree. Entry: bounds of one binary subtree + either a = index of the child wide
+// node (b = 0) or a = ~firstSlot, b = triangle count (<= kWideWidth) of a contiguous slot range. Unused entries
+// carry an inverted box. One wavefront tests a whole wide node per step, one entry per lane.
+constexpr int kWideWidth = 64;
+
 struct DevCollision {
     int nodeCount, triCount, root;
+    const DevNode* wide;            // [wideCount][kWideWidth]; wide node 0 is the root (root < 0: empty world)
+    int wideCount;
     const DevNode* nodes;
     const DevTri* tris;             // slot order
     const DevMaterial* materials;   // by triIndex
@@ -120,7 +128,9 @@ struct HostCollision {
     std::vector<int> triOrder, triLeaf, rank; // rank[tri]
     int root = -1;
     int maxDepth = 0;
+    std::vector<DevNode> wide;      // flattened wide nodes, kWideWidth entries each
     void rebuild(const sge_static_mesh_entity* ents, int count);
+    void buildWide();
 };
 
 // ---- kernel launchers ----------------------------------------------------- //
