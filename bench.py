@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--workload", choices=["ccd", "lbs", "agents"], default="ccd")
     ap.add_argument("--layout", choices=["packed", "padded16"], default="packed")
     ap.add_argument("--overlap", action="store_true", help="skin(n) on a second stream, overlapping move(n+1)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only to rehearse N>1 on one GPU")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-chars", type=int, default=384)
     ap.add_argument("--cpu-sample-steps", type=int, default=8)
@@ -56,12 +58,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
 
     import __graft_entry__
     sge = __graft_entry__.build()
@@ -114,7 +121,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

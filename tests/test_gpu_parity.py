@@ -279,3 +279,67 @@ def test_character_vs_character_sweeps(sge, engines):
     b = cpu.download(what=("bodies",))["bodies"]["position"]
     assert np.abs(a - b).max() > 1e-3, "the scene must exercise capsule-capsule hits"
     free.close()
+
+
+def test_full_size_properties(sge):
+    """BASELINE.json configs[2] at full size (10k clones x 14,080 vertices vs 71,680 triangles), checked through
+    size-independent properties: characters are independent, so an oracle run over a RANDOM SUBSET of the crowd
+    must reproduce the GPU's result for those indices bit for bit; clones that start identical stay identical;
+    nobody tunnels through the terrain; two runs give identical checksums."""
+    gpu = sge.CharacterEngine(0)
+    cpu = ob.oracle_engine()
+    ybot = sge.assets.YBotAssets()
+    n = 10000
+    steps = 40
+    sge.crowd.upload_character_assets(gpu, ybot)
+    terrain = sge.crowd.upload_terrain(gpu)
+    assert gpu.vertex_count == 14080 and gpu.collision_counts()[1] == 71680
+    state0 = sge.crowd.spawn_crowd(gpu, ybot, n, terrain)
+    # make characters 1 and 2 exact clones of character 0
+    for k in state0:
+        state0[k][1] = state0[k][0]
+        state0[k][2] = state0[k][0]
+    gpu.upload(**state0)
+
+    def run():
+        gpu.upload(**state0)
+        for _ in range(steps):
+            gpu.tick()
+        gpu.synchronize()
+        d = gpu.download(what=("bodies", "controllers", "locomotion"))
+        p, nrm, tan = gpu.skinned(0, 3 * gpu.vertex_count)
+        # checksum of checksums over the whole skinned output, computed from strided samples to bound PCIe time
+        samples = [gpu.skinned(i * gpu.vertex_count, 256)[0].view(np.uint32).sum(dtype=np.uint64) for i in range(0, n, 97)]
+        return d, (p, nrm, tan), np.asarray(samples)
+
+    d1, (p, nrm, tan), chk1 = run()
+    d2, _, chk2 = run()
+    assert np.array_equal(chk1, chk2)                                   # deterministic
+    assert_struct_equal(d1["bodies"], d2["bodies"], "bodies(run1 vs run2)")
+    V = gpu.vertex_count
+    assert np.array_equal(p[:V], p[V:2 * V]) and np.array_equal(p[:V], p[2 * V:3 * V])   # clones stay identical
+    assert np.array_equal(tan[:V], tan[V:2 * V])
+    assert np.isfinite(p).all() and np.allclose(np.linalg.norm(nrm, axis=1), 1, atol=1e-5)
+    # nobody fell through: capsule bottom above the terrain surface (minus contact skin)
+    pos = d1["bodies"]["position"]
+    ground = sge.assets.terrain_height(pos[:, 0], pos[:, 2], *terrain["half"])
+    assert ((pos[:, 1] - 2.5) - ground > -0.35).all()
+    assert gpu.move_stats().overflow == 0
+    # subset parity against the oracle
+    rng = np.random.default_rng(0)
+    pick = np.sort(rng.choice(n, 96, replace=False))
+    sge.crowd.upload_character_assets(cpu, ybot)
+    cpu.rebuild_static([{"positions": terrain["positions"], "indices": terrain["indices"]}])
+    cpu.resize(len(pick))
+    cpu.upload(**{k: v[pick] for k, v in state0.items()})
+    for _ in range(steps):
+        cpu.tick()
+    c = cpu.download(what=("bodies", "controllers", "locomotion"))
+    assert_struct_equal(d1["bodies"][pick], c["bodies"], "bodies(subset)")
+    assert_struct_equal(d1["controllers"][pick], c["controllers"], "controllers(subset)")
+    assert np.array_equal(d1["locomotion"]["state"][pick], c["locomotion"]["state"])
+    gp = gpu.skinned(int(pick[5]) * V, V)[0]
+    cp = cpu.skinned(5 * V, V)[0]
+    assert np.abs(gp - cp).max() <= REL * np.abs(cp).max()
+    gpu.close()
+    cpu.close()
