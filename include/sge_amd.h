@@ -415,6 +415,11 @@ int sge_capsule_cast_batch(sge_context* ctx, const sge_capsule_query* queries, i
 int sge_capsule_overlap_all_batch(sge_context* ctx, const sge_capsule_query* queries, int32_t count,
                                   int32_t max_hits, sge_capsule_overlap_hit* out, int32_t* out_counts);
 
+/* CollisionQuery.capsuleOverlap (CollisionQuery.swift:137-146, 830-850, 1119-1199), batched: the deepest
+ * overlapping triangle (first in visit order among equal depths); out_found[i] = 0 means nil. Synchronous. */
+int sge_capsule_overlap_batch(sge_context* ctx, const sge_capsule_query* queries, int32_t count,
+                              sge_capsule_overlap_hit* out, int32_t* out_found);
+
 /* ------------------------------------------------------------------------- */
 /* Characters + the batched fixed step                                        */
 /* ------------------------------------------------------------------------- */

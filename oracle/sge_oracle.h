@@ -72,6 +72,7 @@ struct CollisionQuery {
                              bool hasMinNormalY, float minNormalY, uint32_t mask, CapsuleCastHit& out) const;
     int capsuleOverlapAll(V3 from, float radius, float halfHeight, int maxHits, uint32_t mask,
                           CapsuleOverlapHit* out) const;
+    bool capsuleOverlap(V3 from, float radius, float halfHeight, uint32_t mask, CapsuleOverlapHit& out) const;
 };
 
 struct AgentSweepState { int entity; V3 position, velocity; float radius, halfHeight; };

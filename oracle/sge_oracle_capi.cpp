@@ -157,6 +157,25 @@ int sgeo_capsule_overlap_all_batch(sgeo_world* h, const sge_capsule_query* q, in
     return SGE_OK;
 }
 
+int sgeo_capsule_overlap_batch(sgeo_world* h, const sge_capsule_query* q, int32_t count, sge_capsule_overlap_hit* out,
+                               int32_t* outFound) {
+    for (int i = 0; i < count; ++i) {
+        CapsuleOverlapHit hit;
+        bool got = h->w.query.capsuleOverlap(V3{q[i].from[0], q[i].from[1], q[i].from[2]}, q[i].radius, q[i].halfHeight, q[i].mask, hit);
+        sge_capsule_overlap_hit& o = out[i];
+        std::memset(&o, 0, sizeof(o));
+        outFound[i] = got ? 1 : 0;
+        if (!got) { o.triangleIndex = -1; continue; }
+        o.depth = hit.depth;
+        o.position[0] = hit.position.x; o.position[1] = hit.position.y; o.position[2] = hit.position.z;
+        o.normal[0] = hit.normal.x; o.normal[1] = hit.normal.y; o.normal[2] = hit.normal.z;
+        o.triangleNormal[0] = hit.triangleNormal.x; o.triangleNormal[1] = hit.triangleNormal.y; o.triangleNormal[2] = hit.triangleNormal.z;
+        o.triangleIndex = hit.triangleIndex;
+        o.material = hit.material;
+    }
+    return SGE_OK;
+}
+
 int sgeo_characters_resize(sgeo_world* h, int32_t n) {
     World& w = h->w;
     int B = w.skeleton.boneCount, V = w.mesh.vertexCount;

@@ -429,4 +429,51 @@ int CollisionQuery::capsuleOverlapAll(V3 from, float radius, float halfHeight, i
     return n;
 }
 
+// :830-850 + :1119-1199 (static set): the deepest overlap; `depth <= bestDepth` keeps the first visited on ties
+bool CollisionQuery::capsuleOverlap(V3 from, float radius, float halfHeight, uint32_t mask, CapsuleOverlapHit& best) const {
+    const TriangleMeshSet& set = staticSet;
+    if (!set.hasBVH || set.bvh.root < 0) return false;
+    const BVH& bvh = set.bvh;
+    V3 up = V3{0, 1, 0};
+    V3 a0 = from + up * halfHeight, b0 = from - up * halfHeight;
+    V3 minP = vmin(a0, b0), maxP = vmax(a0, b0);
+    V3 ext = V3{radius, radius, radius};
+    minP -= ext; maxP += ext;
+    bool have = false;
+    float bestDepth = 0;
+    std::vector<int> stack;
+    stack.push_back(bvh.root);
+    while (!stack.empty()) {
+        int nodeIndex = stack.back(); stack.pop_back();
+        const BVHNode& node = bvh.nodes[nodeIndex];
+        if (aabbDisjoint(node.bounds, minP, maxP)) continue;
+        if (node.left < 0) {
+            for (int i = node.start; i < node.start + node.count; ++i) {
+                int triIndex = bvh.triOrder[i];
+                if ((set.triangleLayers[triIndex] & mask) == 0) continue;
+                if (aabbDisjoint(set.triangleAABBs[triIndex], minP, maxP)) continue;
+                int base = triIndex * 3;
+                if (base + 2 >= (int)set.indices.size()) continue;
+                V3 v0 = set.positions[set.indices[base]], v1 = set.positions[set.indices[base + 1]], v2 = set.positions[set.indices[base + 2]];
+                V3 segPoint, triPoint;
+                float dist = segmentTriangleDistance(from, halfHeight, v0, v1, v2, segPoint, triPoint);
+                if (dist >= radius) continue;
+                float depth = radius - dist;
+                if (depth <= bestDepth) continue;
+                V3 triNormal = normalize(cross(v1 - v0, v2 - v0));
+                V3 nn = dist < 1e-6f ? triNormal : normalize(segPoint - triPoint);
+                V3 triN = triNormal;
+                if (dot(triN, nn) < 0) triN = -triN;
+                bestDepth = depth;
+                best = CapsuleOverlapHit{depth, triPoint, nn, triN, triIndex, set.triangleMaterials[triIndex]};
+                have = true;
+            }
+        } else {
+            stack.push_back(node.left);
+            stack.push_back(node.right);
+        }
+    }
+    return have;
+}
+
 } // namespace sgeo

@@ -220,6 +220,7 @@ PROTOTYPES = {
     "sge_collision_copy": (C.c_int, [VP, VP, VP, VP, VP, VP, VP]),
     "sge_capsule_cast_batch": (C.c_int, [VP, VP, i32, VP]),
     "sge_capsule_overlap_all_batch": (C.c_int, [VP, VP, i32, i32, VP, VP]),
+    "sge_capsule_overlap_batch": (C.c_int, [VP, VP, i32, VP, VP]),
     "sge_characters_resize": (C.c_int, [VP, i32]),
     "sge_characters_upload": (C.c_int, [VP, i32, i32, VP, VP, VP, VP, VP, VP]),
     "sge_characters_download": (C.c_int, [VP, i32, i32, VP, VP, VP, VP, VP, VP]),

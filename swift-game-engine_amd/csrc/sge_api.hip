@@ -604,6 +604,24 @@ int sge_capsule_overlap_all_batch(sge_context* c, const sge_capsule_query* q, in
     return SGE_OK;
 }
 
+int sge_capsule_overlap_batch(sge_context* c, const sge_capsule_query* q, int32_t count, sge_capsule_overlap_hit* out,
+                              int32_t* out_found) {
+    if (!c || count < 0 || (count > 0 && (!q || !out || !out_found))) { set_error("sge_capsule_overlap_batch: bad argument"); return SGE_ERR_INVALID; }
+    if (count == 0) return SGE_OK;
+    (void)hipSetDevice(c->device);
+    int rc;
+    if ((rc = upload(c->dQueries, q, (size_t)count * sizeof(*q), c->stream)) != SGE_OK) return rc;
+    if ((rc = c->dOverlapOut.alloc((size_t)count * sizeof(*out))) != SGE_OK) return rc;
+    if ((rc = c->dCounts.alloc((size_t)count * 4)) != SGE_OK) return rc;
+    launch_overlap_deepest_queries(c->col, c->dQueries.as<sge_capsule_query>(), count, c->dOverlapOut.as<sge_capsule_overlap_hit>(),
+                                   c->dCounts.as<int32_t>(), c->dStats.as<unsigned long long>(), c->stream);
+    SGE_HIP(hipGetLastError());
+    SGE_HIP(hipMemcpyAsync(out, c->dOverlapOut.p, (size_t)count * sizeof(*out), hipMemcpyDeviceToHost, c->stream));
+    SGE_HIP(hipMemcpyAsync(out_found, c->dCounts.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
+    SGE_HIP(hipStreamSynchronize(c->stream));
+    return SGE_OK;
+}
+
 // ---- characters ----------------------------------------------------------------------
 int sge_characters_resize(sge_context* c, int32_t count) {
     if (!c || count < 0) { set_error("sge_characters_resize: bad argument"); return SGE_ERR_INVALID; }

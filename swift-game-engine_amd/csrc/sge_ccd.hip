@@ -1419,6 +1419,79 @@ __global__ __launch_bounds__(kWave, 3) void overlap_query_kernel(DevCollision co
     }
 }
 
+// CollisionQuery.capsuleOverlap (:1119-1199): deepest hit, first visited wins equal depths
+__global__ __launch_bounds__(kWave, 3) void overlap_deepest_kernel(DevCollision col, const sge_capsule_query* q, int n,
+                                                                   sge_capsule_overlap_hit* out, int32_t* found,
+                                                                   unsigned long long* stats) {
+    const int i = blockIdx.x;
+    const int lane = laneId();
+    WaveStats st{0, 0, 0, 0, 0, 0};
+    const sge_capsule_query Q = q[i];
+    const F3 from{Q.from[0], Q.from[1], Q.from[2]};
+    unsigned long long bestKey = ~0ull; // (~depth bits << 32) | rank: deeper first, then earlier visit
+    if (col.root >= 0) {
+        F3 up{0, 1, 0};
+        F3 a0 = from + up * Q.halfHeight, b0 = from - up * Q.halfHeight;
+        F3 ext{Q.radius, Q.radius, Q.radius};
+        F3 minP = vmin(a0, b0) - ext, maxP = vmax(a0, b0) + ext;
+        int stackSize = 1, rangeCount = 0, candCount = 0;
+        if (lane == 0) sh.stack[0] = 0;
+        __syncthreads();
+        while (true) {
+            while ((stackSize > 0 || rangeCount > 0) && candCount < kWave) expandNodes(col, minP, maxP, Q.mask, stackSize, rangeCount, candCount, st);
+            if (candCount == 0) break;
+            int nb = candCount < kWave ? candCount : kWave;
+            candCount -= nb;
+            unsigned long long key = ~0ull;
+            OverlapRec rec;
+            rec.depth = 0; rec.position = rec.normal = rec.triNormal = F3{0, 0, 0}; rec.triIndex = -1; rec.rank = 0x7fffffff;
+            if (lane < nb) {
+                Tri tri = loadTri(col, sh.cand[candCount + lane]);
+                F3 segP, triP;
+                float dist = segmentTriangleDistance(from, Q.halfHeight, tri.v0, tri.v1, tri.v2, segP, triP);
+                float depth = Q.radius - dist;
+                if (!(dist >= Q.radius) && !(depth <= 0.0f)) { // :1170-1172 with bestDepth starting at 0
+                    F3 triNormal = normalize(cross(tri.v1 - tri.v0, tri.v2 - tri.v0));
+                    F3 nn = dist < 1e-6f ? triNormal : normalize(segP - triP);
+                    F3 triN = triNormal;
+                    if (dot(triN, nn) < 0) triN = -triN;
+                    rec.depth = depth; rec.position = triP; rec.normal = nn; rec.triNormal = triN; rec.triIndex = tri.triIndex; rec.rank = tri.rank;
+                    key = ((unsigned long long)(~__float_as_uint(depth)) << 32) | (unsigned)tri.rank;
+                }
+            }
+            unsigned long long k = waveMinU64(key);
+            if (k < bestKey) {
+                bestKey = k;
+                if (key == k) sh.ovl[0] = rec;
+            }
+            __syncthreads();
+        }
+    }
+    if (lane == 0) {
+        sge_capsule_overlap_hit h;
+        const bool got = bestKey != ~0ull;
+        found[i] = got ? 1 : 0;
+        OverlapRec r = sh.ovl[0];
+        F3 z{0, 0, 0};
+        F3 p = got ? r.position : z, nn = got ? r.normal : z, tn = got ? r.triNormal : z;
+        h.depth = got ? r.depth : 0;
+        h.position[0] = p.x; h.position[1] = p.y; h.position[2] = p.z;
+        h.normal[0] = nn.x; h.normal[1] = nn.y; h.normal[2] = nn.z;
+        h.triangleNormal[0] = tn.x; h.triangleNormal[1] = tn.y; h.triangleNormal[2] = tn.z;
+        h.triangleIndex = got ? r.triIndex : -1;
+        DevMaterial m = got ? col.materials[r.triIndex] : DevMaterial{0, 0, 0};
+        h.material.muS = m.muS; h.material.muK = m.muK; h.material.flattenGround = m.flatten;
+        out[i] = h;
+        if (stats) atomicAdd(&stats[3], (unsigned long long)st.overflow);
+    }
+}
+
+void launch_overlap_deepest_queries(const DevCollision& col, const sge_capsule_query* d_q, int n,
+                                    sge_capsule_overlap_hit* d_out, int32_t* d_found, unsigned long long* stats, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(overlap_deepest_kernel, dim3(n), dim3(kWave), 0, s, col, d_q, n, d_out, d_found, stats);
+}
+
 void launch_cast_queries(const DevCollision& col, const sge_capsule_query* d_q, int n, sge_capsule_cast_hit* d_out,
                          unsigned long long* stats, hipStream_t s) {
     if (n <= 0) return;

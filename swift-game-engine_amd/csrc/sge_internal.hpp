@@ -144,6 +144,8 @@ void launch_cast_queries(const DevCollision& col, const sge_capsule_query* d_q, 
                          unsigned long long* stats, hipStream_t s);
 void launch_overlap_queries(const DevCollision& col, const sge_capsule_query* d_q, int n, int maxHits,
                             sge_capsule_overlap_hit* d_out, int32_t* d_counts, unsigned long long* stats, hipStream_t s);
+void launch_overlap_deepest_queries(const DevCollision& col, const sge_capsule_query* d_q, int n,
+                                    sge_capsule_overlap_hit* d_out, int32_t* d_found, unsigned long long* stats, hipStream_t s);
 
 struct PoseLaunch {
     DevCrowd crowd; DevSkeleton sk; DevProfiles prof;

@@ -212,6 +212,14 @@ class CharacterEngine:
         self._call("capsule_overlap_all_batch", ptr(q), q.shape[0], int(max_hits), ptr(out), ptr(counts))
         return out, counts
 
+    def capsule_overlap(self, queries):
+        """CollisionQuery.capsuleOverlap: deepest hit per query (found flag 0 = nil)."""
+        q = np.ascontiguousarray(queries, abi.query_dtype)
+        out = np.zeros(q.shape[0], abi.overlap_hit_dtype)
+        found = np.zeros(q.shape[0], np.int32)
+        self._call("capsule_overlap_batch", ptr(q), q.shape[0], ptr(out), ptr(found))
+        return out, found
+
     # -- characters -------------------------------------------------------- #
     def resize(self, n):
         self._call("characters_resize", int(n))

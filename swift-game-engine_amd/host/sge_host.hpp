@@ -117,6 +117,15 @@ public:
     std::optional<CapsuleCastHit> capsuleCastGround(float3 from, float3 delta, float radius, float halfHeight, float minNormalY, uint32_t mask = 0xFFFFFFFFu) {
         return cast(from, delta, radius, halfHeight, SGE_CAST_GROUND, minNormalY, mask);
     }
+    std::optional<CapsuleOverlapHit> capsuleOverlap(float3 from, float radius, float halfHeight, uint32_t mask = 0xFFFFFFFFu) {
+        sge_capsule_query q{{from.x, from.y, from.z}, {0, 0, 0}, radius, halfHeight, 0.0f, mask, SGE_CAST};
+        sge_capsule_overlap_hit h{};
+        int32_t found = 0;
+        check(sge_capsule_overlap_batch(world_.context(), &q, 1, &h, &found), "sge_capsule_overlap_batch");
+        if (!found) return std::nullopt;
+        return CapsuleOverlapHit{h.depth, {h.position[0], h.position[1], h.position[2]}, {h.normal[0], h.normal[1], h.normal[2]},
+                                 {h.triangleNormal[0], h.triangleNormal[1], h.triangleNormal[2]}, h.triangleIndex, h.material};
+    }
     std::vector<CapsuleOverlapHit> capsuleOverlapAll(float3 from, float radius, float halfHeight, int maxHits = 8, uint32_t mask = 0xFFFFFFFFu) {
         maxHits = maxHits < 1 ? 1 : (maxHits > SGE_MAX_OVERLAP_HITS ? SGE_MAX_OVERLAP_HITS : maxHits); // max(1, maxHits), :157
         sge_capsule_query q{{from.x, from.y, from.z}, {0, 0, 0}, radius, halfHeight, 0.0f, mask, SGE_CAST};

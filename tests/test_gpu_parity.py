@@ -103,6 +103,10 @@ def test_queries_bit_exact_on_terrain(sge, engines):
     co, cc = cpu.capsule_overlap_all(q2, 8)
     assert cc.max() == 8 and np.array_equal(gc, cc)
     assert_struct_equal(go, co, "overlap")
+    gd, gf = gpu.capsule_overlap(q2)
+    cd, cf = cpu.capsule_overlap(q2)
+    assert cf.sum() > n // 2 and np.array_equal(gf, cf)
+    assert_struct_equal(gd, cd, "overlap-deepest")
     for mh in (1, 3):
         go, gc = gpu.capsule_overlap_all(q2[:200], mh)
         co, cc = cpu.capsule_overlap_all(q2[:200], mh)

@@ -124,6 +124,8 @@ def test_capsule_vs_plane_analytic(sge, cpu):
     # overlap depth = r - dist
     o, c = cpu.capsule_overlap_all(sge.make_queries([[0, -3 + 2.5 - 0.4, 0]]), 8)
     assert c[0] == 2 and np.allclose(o["depth"][0, :2], 0.4, atol=1e-5)
+    d, f = cpu.capsule_overlap(sge.make_queries([[0, -3 + 2.5 - 0.4, 0], [0, 5, 0]]))
+    assert f.tolist() == [1, 0] and abs(d["depth"][0] - 0.4) < 1e-5 and d["triangleIndex"][0] == o["triangleIndex"][0, 0]
     # layer mask
     qm = sge.make_queries(origin, np.tile([[0, -200.0, 0]], (len(hs), 1)), mask=2)
     assert not cpu.capsule_cast(qm)["hit"].any()
