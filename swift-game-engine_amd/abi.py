@@ -237,7 +237,8 @@ LIB_NAME = "libsge_amd.so"
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+    # SGE_AMD_LIB selects another build of the SAME HIP library (e.g. a diagnostic -DSGE_CCD_TIMING build)
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("SGE_AMD_LIB", LIB_NAME))
 
 
 def bind(lib, prefix="sge_", names=None):

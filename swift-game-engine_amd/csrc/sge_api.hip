@@ -70,7 +70,7 @@ struct sge_context {
     DevBuf dNodes, dWide, dTris, dMaterials;
     // crowd
     DevCrowd crowd{};
-    DevBuf dBodies, dParams, dCtrl, dIntents, dLoco, dActions, dPalettes, dPoseModel, dPoseLocal;
+    DevBuf dBodies, dParams, dCtrl, dIntents, dLoco, dActions, dPalettes, dPoseModel, dPoseLocal, dMoveScratch;
     DevBuf dOutPos, dOutNrm, dOutTan;
     int outLayoutAllocated = -1;
     // agents
@@ -276,7 +276,7 @@ sge_context* sge_context_create(int device_index) {
     if (hipStreamCreateWithFlags(&c->skinStream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->evPoseDone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evSkinDone, hipEventDisableTiming) != hipSuccess) { set_error("stream/event creation failed"); delete c; return nullptr; }
-    if (c->dStats.alloc(64) != SGE_OK || hipMemsetAsync(c->dStats.p, 0, 64, c->stream) != hipSuccess) { delete c; return nullptr; }
+    if (c->dStats.alloc((size_t)kStatShards * 64) != SGE_OK || hipMemsetAsync(c->dStats.p, 0, (size_t)kStatShards * 64, c->stream) != hipSuccess) { delete c; return nullptr; }
     return c;
 }
 
@@ -288,7 +288,7 @@ void sge_context_destroy(sge_context* c) {
     DevBuf* bufs[] = {&c->dParent, &c->dDepth, &c->dLeanChain, &c->dBindLocal, &c->dInvBind, &c->dRestT, &c->dRawRestT, &c->dPreRot,
                       &c->dCoeffs, &c->dCoeffCount, &c->dBonePresent, &c->dMeshPos, &c->dMeshNrm, &c->dMeshTan, &c->dMeshIdx, &c->dMeshWgt,
                       &c->dNodes, &c->dWide, &c->dTris, &c->dMaterials, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
-                      &c->dPalettes, &c->dPoseModel, &c->dPoseLocal, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
+                      &c->dPalettes, &c->dPoseModel, &c->dPoseLocal, &c->dMoveScratch, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
                       &c->dCellCursor, &c->dAgentMinMax, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats};
     for (DevBuf* b : bufs) b->release();
     if (c->evPoseDone) (void)hipEventDestroy(c->evPoseDone);
@@ -637,6 +637,7 @@ int sge_characters_resize(sge_context* c, int32_t count) {
     SGE_ZALLOC(c->dLoco, N * sizeof(sge_locomotion_state));
     SGE_ZALLOC(c->dActions, N * sizeof(sge_action_state));
     SGE_ZALLOC(c->dPalettes, N * B * 64);
+    SGE_ZALLOC(c->dMoveScratch, N * (size_t)kMoveScratchBytes);
     if (c->storePoseDebug) { SGE_ZALLOC(c->dPoseModel, N * B * 64); SGE_ZALLOC(c->dPoseLocal, N * B * 64); }
 #undef SGE_ZALLOC
     c->crowd = DevCrowd{count, c->dBodies.as<sge_body_state>(), c->dParams.as<sge_controller_params>(),
@@ -740,7 +741,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
             if (rc != SGE_OK) return rc;
         }
         MoveLaunch L{c->crowd, c->col, c->agents, d->dt, d->gravity[0], d->gravity[1], d->gravity[2], st, first, count,
-                     c->dStats.as<unsigned long long>()};
+                     c->dStats.as<unsigned long long>(), c->dMoveScratch.p};
         if (!(st & SGE_STAGE_AGENTS) || c->agents.nx == 0) L.agents.all = nullptr;
         Bracket br(c, &c->evMove);
         launch_move(L, c->stream);
@@ -818,12 +819,15 @@ int sge_profile_read(sge_context* c, sge_stage_times* out, int reset) {
 int sge_move_stats_read(sge_context* c, sge_move_stats* out, int reset) {
     if (!c || !out) return SGE_ERR_INVALID;
     (void)hipSetDevice(c->device);
-    unsigned long long h[6];
-    SGE_HIP(hipMemcpyAsync(h, c->dStats.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    std::vector<unsigned long long> shards((size_t)kStatShards * 8);
+    SGE_HIP(hipMemcpyAsync(shards.data(), c->dStats.p, shards.size() * 8, hipMemcpyDeviceToHost, c->stream));
     SGE_HIP(hipStreamSynchronize(c->stream));
+    unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
+    for (int sdx = 0; sdx < kStatShards; ++sdx)
+        for (int k = 0; k < 6; ++k) h[k] += shards[(size_t)sdx * 8 + k];
     out->queries = h[0]; out->candidates = h[1]; out->sweepIterations = h[2]; out->overflow = h[3];
     out->traversalSteps = h[4]; out->sweepTrips = h[5];
-    if (reset) { SGE_HIP(hipMemsetAsync(c->dStats.p, 0, 64, c->stream)); SGE_HIP(hipStreamSynchronize(c->stream)); }
+    if (reset) { SGE_HIP(hipMemsetAsync(c->dStats.p, 0, (size_t)kStatShards * 64, c->stream)); SGE_HIP(hipStreamSynchronize(c->stream)); }
     return SGE_OK;
 }
 

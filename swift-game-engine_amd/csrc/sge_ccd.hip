@@ -35,7 +35,7 @@
 namespace sge {
 
 constexpr int kWave = 64;
-constexpr int kStackCap = 1024;
+constexpr int kStackCap = 256;   // wide nodes pending (each pop adds <= 64)
 constexpr int kCandCap = 512;
 constexpr int kRangeCap = 128;
 constexpr int kItemCap = 512;
@@ -62,6 +62,11 @@ struct WaveShared {
 };
 
 struct WaveStats { unsigned int queries, candidates, evals, overflow, steps, trips; };
+// The counters are sharded over kStatShards cache lines (8 x u64 each): thousands of waves adding to ONE line
+// serialise at ~11 ns per atomic on this chip, which would cost more than the collision work itself.
+__device__ __forceinline__ unsigned long long* statShard(unsigned long long* stats) {
+    return stats + (size_t)(blockIdx.x % kStatShards) * 8;
+}
 #ifdef SGE_CCD_TIMING
 // diagnostic build only: shader-clock cycles per wave spent in traversal / sweep / everything
 __device__ unsigned long long g_cycTraverse, g_cycSweep, g_cycTotal;
@@ -1168,8 +1173,17 @@ __device__ __noinline__ void finishStep() { // ground state, GroundSnap, SlopeFr
     __syncthreads();
 }
 
-template <bool AGENTS>
-__global__ __launch_bounds__(kWave, 2) void move_kernel(MoveLaunch K) {
+static_assert(sizeof(MoveState) <= kMoveScratchBytes, "MoveLaunch::scratch stride");
+
+// The step runs as two launches so that each keeps its own register budget:
+//   PART 0  intent, gravity, VelocityGate, contact-cache decay and the pre-sweep depenetration (overlap queries only)
+//   PART 1  the slide iterations, the ground probe and the write-back (cast passes only)
+// The LDS-resident MoveState crosses the boundary through K.scratch (256 B per character).
+template <int PART, bool AGENTS>
+#ifndef SGE_MOVE_WAVES1
+#define SGE_MOVE_WAVES1 3
+#endif
+__global__ __launch_bounds__(kWave, PART == 0 ? 4 : SGE_MOVE_WAVES1) void move_kernel(MoveLaunch K) {
     const int e = K.first + blockIdx.x;
     const int lane = laneId();
     WaveStats st{0, 0, 0, 0, 0, 0};
@@ -1191,7 +1205,12 @@ __global__ __launch_bounds__(kWave, 2) void move_kernel(MoveLaunch K) {
     sge_controller_state& C = sCtrl;
     const float dt = K.dt;
     const F3 gravity{K.gx, K.gy, K.gz};
-    {
+    uint32_t* const scratch = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(K.scratch) + (size_t)e * kMoveScratchBytes);
+    if (PART == 1) {
+        if (lane < (int)(sizeof(MoveState) / 4)) reinterpret_cast<uint32_t*>(&ms)[lane] = scratch[lane];
+        __syncthreads();
+    }
+    if (PART == 0) {
         D3 velocity{body.linearVelocity[0], body.linearVelocity[1], body.linearVelocity[2]};
         // ---- PhysicsIntentSystem, controller branch (Systems.swift:217-247) ----
         if (K.stages & SGE_STAGE_INTENT) {
@@ -1221,15 +1240,16 @@ __global__ __launch_bounds__(kWave, 2) void move_kernel(MoveLaunch K) {
         }
         ms.velocity = velocity;
     }
-    ms.position = toF(D3{body.position[0], body.position[1], body.position[2]});
-    ms.phase = MP_DONE;
-    ms.dt = dt; ms.gravity = gravity; ms.materials = col.materials; ms.aHave = 0; ms.aToi = 0; ms.aNormal = F3{0, 0, 0};
-
     const bool doMove = (K.stages & SGE_STAGE_MOVE) && body.bodyType != SGE_BODY_STATIC;
     const bool hasAgent = (P.agentFlags & SGE_AGENT_PRESENT) != 0;
     const bool selfSolid = hasAgent && (P.agentFlags & SGE_AGENT_SOLID);
     const bool useAgents = AGENTS && (K.stages & SGE_STAGE_AGENTS) && selfSolid && K.agents.all != nullptr;
-    if (doMove) {
+    if (PART == 0) {
+        ms.position = toF(D3{body.position[0], body.position[1], body.position[2]});
+        ms.phase = MP_DONE;
+        ms.dt = dt; ms.gravity = gravity; ms.materials = col.materials; ms.aHave = 0; ms.aToi = 0; ms.aNormal = F3{0, 0, 0};
+    }
+    if (PART == 0 && doMove) {
         cacheDecay(C);
         ms.wasGrounded = (C.flags & SGE_CTRL_GROUNDED) != 0;
         ms.wasGroundedNear = (C.flags & SGE_CTRL_GROUNDED_NEAR) != 0;
@@ -1250,12 +1270,12 @@ __global__ __launch_bounds__(kWave, 2) void move_kernel(MoveLaunch K) {
     }
     __syncthreads();
 
-    // Each trip issues at most one BVH query; the two query routines are inlined exactly once.
-    while (ms.phase != MP_DONE) {
+    // Each trip issues at most one BVH query; each query routine is inlined exactly once (one per PART).
+    while (ms.phase != MP_DONE && (PART == 1 || ms.phase == MP_DEPEN)) {
         const int phase = ms.phase;
         // ---------------- 1. which query does this phase need? ----------------
         bool doOverlap = false, doCast = false, blocking = false;
-        if (phase == MP_DEPEN) {
+        if (PART == 0) {
             doOverlap = true;
         } else if (phase == MP_SLIDE) {
             // head of the slide loop :1674-1676
@@ -1288,10 +1308,10 @@ __global__ __launch_bounds__(kWave, 2) void move_kernel(MoveLaunch K) {
         __syncthreads();
         // ---------------- 2. the query ----------------
         int nOverlap = 0;
-        if (doOverlap) nOverlap = waveCapsuleOverlapAll(col, ms.position, P.radius, P.halfHeight, 8, P.collisionMask, st);
-        if (doCast) waveCastRays(col, P.radius, P.halfHeight, blocking, !blocking, P.minGroundDot, P.collisionMask, st);
+        if (PART == 0 && doOverlap) nOverlap = waveCapsuleOverlapAll(col, ms.position, P.radius, P.halfHeight, 8, P.collisionMask, st);
+        if (PART == 1 && doCast) waveCastRays(col, P.radius, P.halfHeight, blocking, !blocking, P.minGroundDot, P.collisionMask, st);
         // ---------------- 3. consume ----------------
-        if (phase == MP_DEPEN) consumeDepen(nOverlap);
+        if (PART == 0) consumeDepen(nOverlap);
         else if (phase == MP_SLIDE) {
             if (AGENTS && useAgents) { // AgentSweepSolver.bestHit :1053-1091 (independent of the static hit)
                 const F3 remaining = ms.remaining;
@@ -1305,15 +1325,16 @@ __global__ __launch_bounds__(kWave, 2) void move_kernel(MoveLaunch K) {
         } else if (phase == MP_GROUND_CENTER) consumeGroundCenter();
         else if (phase == MP_GROUND_SAMPLE) consumeGroundSample();
         __syncthreads();
-        if (ms.phase == MP_GROUND_EVAL) { groundEval(); __syncthreads(); }
-        if (ms.phase == MP_FINISH) { finishStep(); __syncthreads(); }
+        if (PART == 1 && ms.phase == MP_GROUND_EVAL) { groundEval(); __syncthreads(); }
+        if (PART == 1 && ms.phase == MP_FINISH) { finishStep(); __syncthreads(); }
     }
 
-    {
+    if (ms.phase == MP_DONE) { // the step (or, without SGE_STAGE_MOVE, the velocity update) is complete
         D3 velocity = ms.velocity;
         body.linearVelocity[0] = velocity.x; body.linearVelocity[1] = velocity.y; body.linearVelocity[2] = velocity.z;
     }
     __syncthreads();
+    if (PART == 0 && lane < (int)(sizeof(MoveState) / 4)) scratch[lane] = reinterpret_cast<const uint32_t*>(&ms)[lane];
     {
         uint32_t* gb = reinterpret_cast<uint32_t*>(K.crowd.bodies + e);
         uint32_t* gc = reinterpret_cast<uint32_t*>(K.crowd.controllers + e);
@@ -1331,16 +1352,17 @@ __global__ __launch_bounds__(kWave, 2) void move_kernel(MoveLaunch K) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
         if (lane == 0) {
-            atomicAdd(&K.stats[0], (unsigned long long)st.queries);
-            atomicAdd(&K.stats[1], (unsigned long long)st.candidates);
-            atomicAdd(&K.stats[3], (unsigned long long)st.overflow);
+            unsigned long long* sp = statShard(K.stats);
+            if (st.queries) atomicAdd(&sp[0], (unsigned long long)st.queries);
+            if (st.candidates) atomicAdd(&sp[1], (unsigned long long)st.candidates);
+            if (st.overflow) atomicAdd(&sp[3], (unsigned long long)st.overflow);
 #ifdef SGE_CCD_TIMING
-            // diagnostic build: the three counters below carry cycle sums instead
+            // diagnostic build: the three counters below carry cycle sums instead (shard 0 only)
             K.stats[2] = g_cycTotal; K.stats[4] = g_cycTraverse; K.stats[5] = g_cycSweep;
 #else
-            atomicAdd(&K.stats[2], (unsigned long long)v);
-            atomicAdd(&K.stats[4], (unsigned long long)st.steps);
-            atomicAdd(&K.stats[5], (unsigned long long)st.trips);
+            if (v) atomicAdd(&sp[2], (unsigned long long)v);
+            if (st.steps) atomicAdd(&sp[4], (unsigned long long)st.steps);
+            if (st.trips) atomicAdd(&sp[5], (unsigned long long)st.trips);
 #endif
         }
     }
@@ -1348,8 +1370,10 @@ __global__ __launch_bounds__(kWave, 2) void move_kernel(MoveLaunch K) {
 
 void launch_move(const MoveLaunch& L, hipStream_t s) {
     if (L.count <= 0) return;
-    if ((L.stages & SGE_STAGE_AGENTS) && L.agents.all) hipLaunchKernelGGL(move_kernel<true>, dim3(L.count), dim3(kWave), 0, s, L);
-    else hipLaunchKernelGGL(move_kernel<false>, dim3(L.count), dim3(kWave), 0, s, L);
+    hipLaunchKernelGGL((move_kernel<0, false>), dim3(L.count), dim3(kWave), 0, s, L);
+    if (!(L.stages & SGE_STAGE_MOVE)) return;
+    if ((L.stages & SGE_STAGE_AGENTS) && L.agents.all) hipLaunchKernelGGL((move_kernel<1, true>), dim3(L.count), dim3(kWave), 0, s, L);
+    else hipLaunchKernelGGL((move_kernel<1, false>), dim3(L.count), dim3(kWave), 0, s, L);
 }
 
 // ---- batched single queries (the CollisionQuery facade) ---------------------
@@ -1379,9 +1403,10 @@ __global__ __launch_bounds__(kWave, 3) void cast_query_kernel(DevCollision col, 
         h.material.muS = m.muS; h.material.muK = m.muK; h.material.flattenGround = m.flatten;
         out[i] = h;
         if (stats) {
-            atomicAdd(&stats[0], (unsigned long long)st.queries);
-            atomicAdd(&stats[1], (unsigned long long)st.candidates);
-            atomicAdd(&stats[3], (unsigned long long)st.overflow);
+            unsigned long long* sp = statShard(stats);
+            atomicAdd(&sp[0], (unsigned long long)st.queries);
+            atomicAdd(&sp[1], (unsigned long long)st.candidates);
+            if (st.overflow) atomicAdd(&sp[3], (unsigned long long)st.overflow);
         }
     }
 }
@@ -1415,7 +1440,7 @@ __global__ __launch_bounds__(kWave, 3) void overlap_query_kernel(DevCollision co
     }
     if (lane == 0) {
         counts[i] = cnt;
-        if (stats) atomicAdd(&stats[3], (unsigned long long)st.overflow);
+        if (stats && st.overflow) atomicAdd(&statShard(stats)[3], (unsigned long long)st.overflow);
     }
 }
 
@@ -1482,7 +1507,7 @@ __global__ __launch_bounds__(kWave, 3) void overlap_deepest_kernel(DevCollision 
         DevMaterial m = got ? col.materials[r.triIndex] : DevMaterial{0, 0, 0};
         h.material.muS = m.muS; h.material.muK = m.muK; h.material.flattenGround = m.flatten;
         out[i] = h;
-        if (stats) atomicAdd(&stats[3], (unsigned long long)st.overflow);
+        if (stats && st.overflow) atomicAdd(&statShard(stats)[3], (unsigned long long)st.overflow);
     }
 }
 

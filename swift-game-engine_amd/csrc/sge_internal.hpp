@@ -137,8 +137,11 @@ struct HostCollision {
 struct MoveLaunch {
     DevCrowd crowd; DevCollision col; DevAgents agents;
     float dt; float gx, gy, gz; uint32_t stages; int first, count;
-    unsigned long long* stats; // [4]
+    unsigned long long* stats; // [8]
+    void* scratch;             // [count] x kMoveScratchBytes: per-character working set between the two launches
 };
+constexpr int kMoveScratchBytes = 256;
+constexpr int kStatShards = 256; // device counters: kStatShards lines of 8 x u64
 void launch_move(const MoveLaunch& L, hipStream_t s);
 void launch_cast_queries(const DevCollision& col, const sge_capsule_query* d_q, int n, sge_capsule_cast_hit* d_out,
                          unsigned long long* stats, hipStream_t s);
