@@ -18,8 +18,12 @@
 
 namespace sge {
 
-constexpr int kSkinBlock = 256;
+#ifndef SGE_SKIN_BLOCK
+#define SGE_SKIN_BLOCK 256
+#endif
+constexpr int kSkinBlock = SGE_SKIN_BLOCK;
 
+typedef float v4f __attribute__((ext_vector_type(4)));
 struct Row3 { float4 r0, r1, r2; };
 
 __device__ __forceinline__ Row3 loadRows(const float4* pal, int bone) {
@@ -116,6 +120,17 @@ __global__ __launch_bounds__(kSkinBlock) void skin_kernel(SkinLaunch L, int spli
         const size_t o = obase + gid;
         float* op = reinterpret_cast<float*>(L.outPos) + o * DST_STRIDE;
         float* on = reinterpret_cast<float*>(L.outNrm) + o * DST_STRIDE;
+#ifndef SGE_SKIN_PLAIN_STORES
+        // streaming output: non-temporal stores (0.95-1.07 ms vs 1.10 ms with plain stores on MI355X)
+        if (DST_STRIDE == 4) {
+            __builtin_nontemporal_store(v4f{acc.x, acc.y, acc.z, 0.f}, reinterpret_cast<v4f*>(op));
+            __builtin_nontemporal_store(v4f{nn.x, nn.y, nn.z, 0.f}, reinterpret_cast<v4f*>(on));
+        } else {
+            __builtin_nontemporal_store(acc.x, op); __builtin_nontemporal_store(acc.y, op + 1); __builtin_nontemporal_store(acc.z, op + 2);
+            __builtin_nontemporal_store(nn.x, on); __builtin_nontemporal_store(nn.y, on + 1); __builtin_nontemporal_store(nn.z, on + 2);
+        }
+        __builtin_nontemporal_store(v4f{tn.x, tn.y, tn.z, cur.t.w}, reinterpret_cast<v4f*>(L.outTan) + o);
+#else
         if (DST_STRIDE == 4) {
             *reinterpret_cast<float4*>(op) = make_float4(acc.x, acc.y, acc.z, 0.f);
             *reinterpret_cast<float4*>(on) = make_float4(nn.x, nn.y, nn.z, 0.f);
@@ -124,6 +139,7 @@ __global__ __launch_bounds__(kSkinBlock) void skin_kernel(SkinLaunch L, int spli
             on[0] = nn.x; on[1] = nn.y; on[2] = nn.z;
         }
         reinterpret_cast<float4*>(L.outTan)[o] = make_float4(tn.x, tn.y, tn.z, cur.t.w);
+#endif
         cur = nxt;
     }
 }
