@@ -119,7 +119,10 @@ __device__ __forceinline__ int groundedNextState(int current, float speed, const
     return SGE_LOCO_FALLING;
 }
 
-__global__ __launch_bounds__(kWave) void pose_kernel(PoseLaunch K) {
+#ifndef SGE_POSE_WAVES
+#define SGE_POSE_WAVES 1
+#endif
+__global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch K) {
     __shared__ float sLocal[SGE_MAX_BONES * 12];
     __shared__ float sModel[SGE_MAX_BONES * 12];
     const int e = K.first + blockIdx.x;
