@@ -22,10 +22,12 @@ _SKIP = {"sge_context_create", "sge_context_destroy", "sge_last_error", "sge_abi
 
 
 def build_oracle():
-    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".h"))]
-    srcs.append(os.path.join(ROOT, "include", "sge_amd.h"))
-    if not os.path.exists(ORACLE_LIB) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_LIB) for s in srcs):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    """Builds (content-hash checked, lock protected) through __graft_entry__.build()."""
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import __graft_entry__
+    __graft_entry__.build()
     return ORACLE_LIB
 
 
