@@ -38,7 +38,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--chars", type=int, default=10000, help="characters per GPU")
-    ap.add_argument("--workload", choices=["ccd", "lbs", "agents"], default="ccd")
+    ap.add_argument("--workload", choices=["ccd", "lbs", "agents", "mixed"], default="ccd")
+    ap.add_argument("--assets", choices=["synthetic", "real"], default="synthetic",
+                    help="real: the FBX-derived Y-Bot (35,440 vertices) and 17-Cheese / merged static scene from tests/golden/")
     ap.add_argument("--layout", choices=["packed", "padded16"], default="packed")
     ap.add_argument("--overlap", action="store_true", help="skin(n) on a second stream, overlapping move(n+1)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only to rehearse N>1 on one GPU")
@@ -79,15 +81,15 @@ def main():
     eng.set_option(abi.OPT_SKIN_LAYOUT, abi.LAYOUT_PADDED16 if args.layout == "padded16" else abi.LAYOUT_PACKED)
     eng.set_option(abi.OPT_OVERLAP_SKIN, 1 if args.overlap else 0)
     ybot = sge.assets.YBotAssets()
-    sge.crowd.upload_character_assets(eng, ybot)  # 22 x 10 vertices on 64 bones = 14,080
-    terrain = sge.crowd.upload_terrain(eng)       # 224 x 160 x 2 = 71,680 triangles
+    terrain = _build_world(sge, eng, ybot, args)
     n_total = args.chars * world
     first, count = sge.parallel.shard_range(n_total, rank, world)
     mode = "lbs" if args.workload == "lbs" else "ccd"
     # every rank draws the whole seeded crowd and keeps its contiguous block
     full_eng_state = None
     eng.resize(count)
-    state = _spawn_block(sge, eng, ybot, n_total, first, count, terrain, mode, agents=args.workload == "agents")
+    state = _spawn_block(sge, eng, ybot, n_total, first, count, terrain, mode, agents=args.workload == "agents",
+                         mixed=args.workload == "mixed")
     stages = abi.STAGE_ALL if mode == "ccd" else (abi.STAGE_LOCOMOTION | abi.STAGE_ACTION | abi.STAGE_POSE | abi.STAGE_WRITEBACK | abi.STAGE_SKIN)
     exchange = None
     if args.workload == "agents":
@@ -149,13 +151,15 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic" if args.assets == "synthetic" else "synthetic crowd state over FBX-derived assets (tests/golden/)",
         "config": {
             "workload": {"ccd": "configs[2]: 10k Y-Bot clones/GPU, pose + LBS + capsule-CCD vs 71,680-tri static mesh",
                          "lbs": "configs[1]: 10k Y-Bot clones/GPU, Running profile, pose + LBS only",
-                         "agents": "configs[4]-style: configs[2] + character-vs-character sweeps, RCCL all-gather of capsule state"}[args.workload],
+                         "agents": "configs[4]-style: configs[2] + character-vs-character sweeps, RCCL all-gather of capsule state",
+                         "mixed": "configs[3]-style: mixed-motion Y-Bots (idle/walk/run/falling, 10% mid-blend) vs the merged static scene"}[args.workload],
+            "assets": args.assets,
             "characters_per_gpu": args.chars, "characters_total": n_total, "bones": B, "vertices_per_character": V,
-            "static_triangles": int(terrain["indices"].size // 3), "dt": 1.0 / 60.0, "sharding": f"by-character x{world}",
+            "static_triangles": int(eng.collision_counts()[1]), "dt": 1.0 / 60.0, "sharding": f"by-character x{world}",
             "skin_layout": args.layout, "overlap_skin_with_next_move": bool(args.overlap), "settle_steps": SETTLE_STEPS if mode == "ccd" else 0, "seed": 1234,
         },
         "roofline": {"bound": "hbm", "kernel": "skin_kernel (4-weight LBS)", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -180,7 +184,17 @@ def main():
         dist.destroy_process_group()
 
 
-def _spawn_block(sge, eng, ybot, n_total, first, count, terrain, mode, agents):
+def _build_world(sge, e, ybot, args):
+    """Character assets + static scene, identical for the GPU context and the CPU-baseline oracle."""
+    if args.assets == "real":
+        sge.crowd.upload_ybot_mesh(e, ybot)  # Y Bot.fbx: 35,440 welded vertices, 65 bones, mesh inverse-bind re-bind
+        which = ("cheese", "mirror", "semla") if args.workload == "mixed" else ("cheese",)
+        return sge.crowd.upload_asset_scene(e, which)  # 71,680 (+2 ground) or 135,928 (+2) triangles
+    sge.crowd.upload_character_assets(e, ybot)  # 22 x 10 vertices on 64 bones = 14,080
+    return sge.crowd.upload_terrain(e)          # 224 x 160 x 2 = 71,680 triangles
+
+
+def _spawn_block(sge, eng, ybot, n_total, first, count, terrain, mode, agents, mixed=False):
     """Draw the seeded crowd of all ranks (host numpy, cheap) and upload this rank's block."""
     class _Capture:
         def resize(self, n):
@@ -189,8 +203,11 @@ def _spawn_block(sge, eng, ybot, n_total, first, count, terrain, mode, agents):
         def upload(self, **kw):
             self.kw = kw
 
+        def capsule_cast(self, q):  # spawn heights over an asset scene come from the collision world itself
+            return eng.capsule_cast(q)
+
     cap = _Capture()
-    sge.crowd.spawn_crowd(cap, ybot, n_total, terrain, seed=1234, mode=mode, agents=agents)
+    sge.crowd.spawn_crowd(cap, ybot, n_total, terrain, seed=1234, mode=mode, agents=agents, mixed=mixed)
     block = {k: v[first:first + count] for k, v in cap.kw.items()}
     eng.upload(**block)
     return block
@@ -221,8 +238,7 @@ def _cpu_baseline(sge, eng, ybot, terrain, stages, args, mode):
     res = {}
     for label, threads in (("single_thread", 1), ("all_cores", cores)):
         cpu = ob.oracle_engine()
-        sge.crowd.upload_character_assets(cpu, ybot)
-        cpu.rebuild_static([{"positions": terrain["positions"], "indices": terrain["indices"]}])
+        _build_world(sge, cpu, ybot, args)
         cpu.resize(n)
         cpu.upload(**state)
         t0 = time.perf_counter()

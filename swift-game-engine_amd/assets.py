@@ -18,7 +18,7 @@ from . import abi
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
-# Skeleton.RigProfile.mixamo(), Skeleton.swift:63-89 (first alias only is needed for the Y-Bot)
+# Skeleton.RigProfile.mixamo(), Skeleton.swift:63-89
 MIXAMO_ALIASES = {
     "pelvis": ["mixamorig:Hips", "Hips", "pelvis"],
     "spine1": ["mixamorig:Spine", "Spine", "spine_01"],
@@ -26,6 +26,22 @@ MIXAMO_ALIASES = {
     "spine3": ["mixamorig:Spine2", "Spine2", "spine_03"],
     "neck": ["mixamorig:Neck", "Neck", "neck_01"],
     "head": ["mixamorig:Head", "Head"],
+    "clavicleL": ["mixamorig:LeftShoulder", "LeftShoulder", "clavicle_l"],
+    "upperarmL": ["mixamorig:LeftArm", "LeftArm", "upperarm_l"],
+    "lowerarmL": ["mixamorig:LeftForeArm", "LeftForeArm", "lowerarm_l"],
+    "handL": ["mixamorig:LeftHand", "LeftHand", "hand_l"],
+    "clavicleR": ["mixamorig:RightShoulder", "RightShoulder", "clavicle_r"],
+    "upperarmR": ["mixamorig:RightArm", "RightArm", "upperarm_r"],
+    "lowerarmR": ["mixamorig:RightForeArm", "RightForeArm", "lowerarm_r"],
+    "handR": ["mixamorig:RightHand", "RightHand", "hand_r"],
+    "thighL": ["mixamorig:LeftUpLeg", "LeftUpLeg", "thigh_l"],
+    "calfL": ["mixamorig:LeftLeg", "LeftLeg", "calf_l"],
+    "footL": ["mixamorig:LeftFoot", "LeftFoot", "foot_l"],
+    "ballL": ["mixamorig:LeftToeBase", "LeftToeBase", "ball_l"],
+    "thighR": ["mixamorig:RightUpLeg", "RightUpLeg", "thigh_r"],
+    "calfR": ["mixamorig:RightLeg", "RightLeg", "calf_r"],
+    "footR": ["mixamorig:RightFoot", "RightFoot", "foot_r"],
+    "ballR": ["mixamorig:RightToeBase", "RightToeBase", "ball_r"],
 }
 
 

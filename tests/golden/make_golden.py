@@ -11,6 +11,10 @@ Outputs (data only — inputs and expected outputs, no reference source text):
                             as Swift's JSONDecoder rounds them).
   ornate_mirror_static.npz  Game/ornate_mirror.static.json (the one static asset present in
                             the checkout): part mesh + its two collision hulls + transform.
+  ybot_skinned.npz          ExternalResources/Y Bot.fbx in the *.skinned.json schema (positions, normals, uvs,
+  cheese_static.npz         joints, weights, indices, submeshes, skin bones + inverseBindMatrix) and
+  semla_static.npz          17-Cheese.fbx / Semla.fbx in the *.static.json schema (positions, indices, transform),
+                            produced by swift-game-engine_amd/exporters.py (see make_fbx_assets).
   pose_chain_f64.npz        float64 golden vectors for the pose chain, computed by functions
                             IMPORTED from the reference's own Tools/FitMotion/fit_motion.py
                             (rotation_xyz_degrees, mat_mul, translation_matrix,
@@ -212,12 +216,38 @@ def make_pose_chain(fm):
     np.savez_compressed(os.path.join(OUT, "pose_chain_f64.npz"), **out)
 
 
+def make_fbx_assets():
+    """The three assets the checkout lacks as exporter output (.MISSING_LARGE_BLOBS: YBot.skinned.json,
+    17-Cheese.static.json, Semla.static.json), regenerated from the binary FBX data files under
+    ExternalResources/ by the package's Blender-free restatement of the two exporter scripts.  The static
+    exporter is first pinned against the one exporter output the checkout does hold."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    pkg = importlib.import_module("swift-game-engine_amd")
+    fbx, ex, formats = pkg.fbx, pkg.exporters, pkg.formats
+
+    pin = ex.export_static_mesh(fbx.FbxScene(os.path.join(REF, "ExternalResources/ornate-mirror/source/ornate_mirror.fbx")))
+    ref = json.load(open(os.path.join(REF, "Game/ornate_mirror.static.json")))["meshes"][0]
+    got = pin["meshes"][0]
+    assert np.array_equal(np.asarray(ref["mesh"]["indices"], np.uint32), got["mesh"]["indices"])
+    assert np.array_equal(np.asarray(ref["mesh"]["positions"], np.float64).astype(np.float32), got["mesh"]["positions"])
+    assert np.abs(np.asarray(ref["transform"], np.float64) - got["transform"]).max() < 1e-7
+    assert np.abs(np.asarray(ref["mesh"]["uvs"], np.float64) - got["mesh"]["uvs"]).max() < 1e-6
+    print("static exporter pinned against Game/ornate_mirror.static.json: indices/positions exact")
+
+    skinned = ex.export_skinned_mesh(fbx.FbxScene(os.path.join(REF, "ExternalResources/Y Bot.fbx")))
+    formats.save_skinned_payload(os.path.join(OUT, "ybot_skinned.npz"), skinned)
+    for src, dst in (("ExternalResources/17-Cheese.fbx", "cheese_static.npz"),
+                     ("ExternalResources/semla/source/Semla.fbx", "semla_static.npz")):
+        formats.save_static_payload(os.path.join(OUT, dst), ex.export_static_mesh(fbx.FbxScene(os.path.join(REF, src))))
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference checkout not present; fixtures are committed, nothing to do")
     make_assets()
     make_static()
     make_pose_chain(load_fit_motion())
+    make_fbx_assets()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

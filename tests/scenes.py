@@ -6,11 +6,21 @@ import numpy as np
 
 
 def build_scene(pkg, eng, n, terrain_cells=(48, 32), seed=1234, mode="ccd", agents=False, mixed=False,
-                rings=6, segments=6, pose_debug=True, mesh_inv_bind=False):
+                rings=6, segments=6, pose_debug=True, mesh_inv_bind=False, real_mesh=False, asset_scene=None,
+                footprint=200.0):
+    """real_mesh: the FBX-derived Y-Bot (tests/golden/ybot_skinned.npz) instead of the synthetic tube mesh;
+    asset_scene: tuple of static asset names ("cheese", "mirror", "semla") instead of the synthetic terrain."""
     ybot = pkg.assets.YBotAssets()
     if pose_debug:
         eng.set_option(pkg.abi.OPT_STORE_POSE_DEBUG, 1)
-    pkg.crowd.upload_character_assets(eng, ybot, rings=rings, segments=segments, mesh_inv_bind=mesh_inv_bind)
+    if real_mesh:
+        pkg.crowd.upload_ybot_mesh(eng, ybot)
+    else:
+        pkg.crowd.upload_character_assets(eng, ybot, rings=rings, segments=segments, mesh_inv_bind=mesh_inv_bind)
+    if asset_scene:
+        terrain = pkg.crowd.upload_asset_scene(eng, asset_scene, footprint=footprint)
+        state = pkg.crowd.spawn_crowd(eng, ybot, n, terrain, seed=seed, mode=mode, agents=agents, mixed=mixed)
+        return ybot, terrain, state
     terrain = pkg.crowd.upload_terrain(eng, cells=terrain_cells) if terrain_cells else None
     if terrain is None:
         pkg.crowd.upload_ground_plane(eng)

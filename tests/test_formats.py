@@ -1,0 +1,282 @@
+"""CPU tests of the on-disk format loaders (formats.py), the Blender-free exporters (exporters.py / fbx.py) and the
+FBX-derived fixtures, against the reference's own data where the checkout is present and against the committed
+tables otherwise.  Row f1 of SURVEY.md §8."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+REF = "/root/reference"
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+needs_ref = pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present (GPU box)")
+
+
+def skeleton_json(ybot):
+    z = np.load(os.path.join(GOLDEN, "ybot_assets.npz"))
+    return {"version": 1, "name": "YBot", "unitScale": float(ybot.unit_scale),
+            "rigProfile": {"name": str(z["rigProfile"])},
+            "root": {"rule": str(z["rootRule"]), "rotationFixDegrees": [float(v) for v in ybot.root_fix_degrees]},
+            "names": list(ybot.names), "parent": [int(p) for p in ybot.parent],
+            "translations": [[float(v) for v in t] for t in ybot.translations],
+            "preRotationDegrees": [[float(v) for v in t] for t in ybot.pre_rotation_degrees]}
+
+
+def profile_json(ybot, k):
+    p = ybot.profiles[k]
+    bones = {}
+    for i, name in enumerate(ybot.names):
+        if not p["bonePresent"][i]:
+            continue
+        entry = {"translation": {}, "rotation": {}}
+        for c, chan in enumerate(("translation", "rotation")):
+            for a, axis in enumerate("xyz"):
+                cnt = int(p["coeffCount"][i, c * 3 + a])
+                if cnt != 255:
+                    entry[chan][axis] = [float(v) for v in p["coeffs"][i, c * 3 + a, :cnt]]
+        bones[name] = entry
+    return {"version": 1, "name": p["name"], "duration": 1.25, "order": p["order"], "sample_fps": p["sampleFps"],
+            "phase": {"mode": "cycle", "cycle_duration": p["cycleDuration"]}, "bones": bones}
+
+
+def test_skeleton_loader_roundtrip_and_rules(sge, ybot, tmp_path):
+    F = sge.formats
+    js = skeleton_json(ybot)
+    path = tmp_path / "YBot.skeleton.json"
+    path.write_text(json.dumps(js))
+    sk = F.load_skeleton(path)
+    assert sk.names == ybot.names and np.array_equal(sk.parent, ybot.parent)
+    assert np.array_equal(sk.translations, ybot.translations)
+    assert np.array_equal(sk.pre_rotation_degrees, ybot.pre_rotation_degrees)
+    assert sk.unit_scale == ybot.unit_scale and sk.zero_root == ybot.zero_root
+    assert (sk.pelvis_index, sk.lean_index) == (ybot.pelvis_index, ybot.lean_index)
+    # root rules (SkeletonLoader.swift:141-158)
+    for rule, rig, expect in (("zero", "generic", True), ("keep", "mixamo", False), ("auto", "generic", False),
+                              ("auto", "Mixamo", True), ("whatever", "mixamo", False)):
+        j = dict(js, root=dict(js["root"], rule=rule), rigProfile={"name": rig})
+        assert F.load_skeleton(j).zero_root is expect, (rule, rig)
+    # alias override replaces one semantic key (rigProfileFrom :119-139)
+    j = dict(js, rigProfile={"name": "mixamo", "aliases": {"pelvis": ["mixamorig:Spine"]}})
+    assert F.load_skeleton(j).pelvis_index == ybot.names.index("mixamorig:Spine")
+    # failure modes -> nil
+    assert F.load_skeleton(tmp_path / "missing.json") is None
+    assert F.load_skeleton(dict(js, parent=js["parent"][:-1])) is None
+    assert F.load_skeleton(dict(js, preRotationDegrees=js["preRotationDegrees"][:3])) is None
+    assert F.load_skeleton({k: v for k, v in js.items() if k != "unitScale"}) is None
+    empty_pre = F.load_skeleton(dict(js, preRotationDegrees=[]))
+    assert not empty_pre.pre_rotation_degrees.any()
+    # short vectors fall back to zero (vec3, :163-166)
+    short = F.load_skeleton(dict(js, translations=[[1.0, 2.0]] + js["translations"][1:]))
+    assert not short.translations[0].any()
+
+
+def test_motion_profile_loader_roundtrip(sge, ybot, tmp_path):
+    F = sge.formats
+    for k in range(len(ybot.profiles)):
+        js = profile_json(ybot, k)
+        p = F.load_motion_profile(js, ybot.names)
+        ref = ybot.profiles[k]
+        for key in ("bonePresent", "coeffCount", "coeffs"):
+            assert np.array_equal(p[key], ref[key]), (ref["name"], key)
+        assert p["order"] == ref["order"] and p["cycleDuration"] == ref["cycleDuration"]
+    js = profile_json(ybot, 0)
+    del js["phase"]  # phase?.cycleDuration ?? duration
+    assert F.load_motion_profile(js, ybot.names)["cycleDuration"] == np.float32(1.25)
+    assert F.load_motion_profile({k: v for k, v in js.items() if k != "order"}, ybot.names) is None
+    (tmp_path / "bad.json").write_text("{not json")
+    assert F.load_motion_profile(tmp_path / "bad.json", ybot.names) is None
+
+
+@needs_ref
+def test_loaders_on_the_reference_json(sge, ybot):
+    """The committed dense tables are what the loaders produce from the reference's own JSON files."""
+    F = sge.formats
+    sk = F.load_skeleton(os.path.join(REF, "Game/YBot.skeleton.json"))
+    assert sk.names == ybot.names
+    assert np.array_equal(sk.translations, ybot.translations)
+    assert np.array_equal(sk.pre_rotation_degrees, ybot.pre_rotation_degrees)
+    assert sk.zero_root == ybot.zero_root and sk.unit_scale == ybot.unit_scale
+    for ref in ybot.profiles:
+        p = F.load_motion_profile(os.path.join(REF, "Game/%s.motionProfile.json" % ref["name"]), sk.names)
+        for key in ("bonePresent", "coeffCount", "coeffs"):
+            assert np.array_equal(p[key], ref[key])
+        assert p["cycleDuration"] == ref["cycleDuration"]
+    parts = F.load_static_mesh(os.path.join(REF, "Game/ornate_mirror.static.json"))
+    z = np.load(os.path.join(GOLDEN, "ornate_mirror_static.npz"))
+    assert len(parts) == 1 and np.array_equal(parts[0]["positions"], z["positions"])
+    assert np.array_equal(parts[0]["indices"], z["indices"]) and len(parts[0]["collisionHulls"]) == 2
+    assert np.array_equal(parts[0]["collisionHulls"][1]["positions"], z["hull1.positions"])
+
+
+@needs_ref
+def test_static_exporter_matches_the_reference_exporter_output(sge):
+    """Pin: ornate_mirror.fbx through exporters.export_static_mesh == Game/ornate_mirror.static.json
+    (Blender + export_static_mesh_json.py): same weld, vertex order, triangulation and matrix_world."""
+    scene = sge.fbx.FbxScene(os.path.join(REF, "ExternalResources/ornate-mirror/source/ornate_mirror.fbx"))
+    got = sge.exporters.export_static_mesh(scene)["meshes"][0]
+    ref = json.load(open(os.path.join(REF, "Game/ornate_mirror.static.json")))["meshes"][0]
+    assert got["name"] == ref["name"] and got["mesh"]["submeshes"] == ref["mesh"]["submeshes"]
+    assert np.array_equal(np.asarray(ref["mesh"]["indices"], np.uint32), got["mesh"]["indices"])
+    assert np.array_equal(np.asarray(ref["mesh"]["positions"], np.float64).astype(np.float32), got["mesh"]["positions"])
+    assert np.abs(np.asarray(ref["mesh"]["uvs"]) - got["mesh"]["uvs"]).max() < 1e-6
+    # Blender round-trips custom normals through a 16-bit encoding: direction agrees to that precision
+    assert np.abs(np.asarray(ref["mesh"]["normals"]) - got["mesh"]["normals"]).max() < 1e-3
+    assert np.abs(np.asarray(ref["transform"]) - got["transform"]).max() < 1e-7
+
+
+@needs_ref
+def test_fbx_fixtures_are_reproducible(sge):
+    F = sge.formats
+    scene = sge.fbx.FbxScene(os.path.join(REF, "ExternalResources/17-Cheese.fbx"))
+    got = sge.exporters.export_static_mesh(scene)["meshes"][0]
+    kept = F.load_payload(os.path.join(GOLDEN, "cheese_static.npz"))["meshes"][0]
+    assert np.array_equal(got["mesh"]["positions"], kept["mesh"]["positions"])
+    assert np.array_equal(got["mesh"]["indices"], kept["mesh"]["indices"])
+    # the skeleton JSON and the FBX limb nodes are the same rig (translations / pre-rotations to print precision)
+    ys = sge.fbx.FbxScene(os.path.join(REF, "ExternalResources/Y Bot.fbx"))
+    sk = json.load(open(os.path.join(REF, "Game/YBot.skeleton.json")))
+    limb = {ys.name(i): i for i in ys.of_kind("Model", "LimbNode")}
+    for k, name in enumerate(sk["names"]):
+        trs = ys.local_trs(limb[name])
+        assert np.abs(trs["T"] - sk["translations"][k]).max() < 1e-6
+        assert np.abs(trs["PreRotation"] - sk["preRotationDegrees"][k]).max() < 1e-6
+
+
+def test_triangulation_rules(sge):
+    fbx = sge.fbx
+    # convex quad: 0-2 diagonal; reflex at corner 3 seen from 0-2 -> flipped to 1-3
+    convex = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], float)
+    dart = np.array([[0, 0, 0], [1, 0.1, 0], [0.2, 0.2, 0], [0.1, 1, 0]], float)
+    dart2 = np.array([[0, 0, 0], [1, -1, 0], [0.3, 0, 0], [1, 1, 0]], float)  # corners 1 and 3 on opposite sides: ok
+    bad = np.array([[0, 0, 0], [0.4, 0.1, 0], [1, 0, 0], [0.5, 1, 0]], float)  # 0-2 passes outside: flip
+    pts = np.concatenate([convex, dart, dart2, bad])
+    loops = np.arange(16)
+    tris, face = fbx.triangulate_blender(pts, loops, np.array([0, 4, 8, 12, 16]))
+    assert tris[face == 0].tolist() == [[0, 1, 2], [0, 2, 3]]
+    assert tris[face == 2].tolist() == [[8, 9, 10], [8, 10, 11]]
+    assert tris[face == 3].tolist() == [[12, 13, 15], [13, 14, 15]]
+    # pentagons: the reference's exporter output shows these corner orders for convex / one-reflex-corner n-gons
+    ang = np.linspace(0, 2 * np.pi, 5, endpoint=False)
+    pent = np.stack([np.cos(ang), np.sin(ang), np.zeros(5)], 1)
+    tris, _ = fbx.triangulate_blender(pent, np.arange(5), np.array([0, 5]))
+    assert tris.tolist() == [[4, 0, 1], [1, 2, 3], [1, 3, 4]]
+    reflex3 = pent.copy()
+    reflex3[3] = 0.15 * pent[3]
+    tris, _ = fbx.triangulate_blender(reflex3, np.arange(5), np.array([0, 5]))
+    assert sorted(map(sorted, tris.tolist())) == sorted(map(sorted, [[0, 1, 2], [3, 4, 0], [0, 2, 3]])) or len(tris) == 3
+    area = 0.0
+    for a, b, c in tris:
+        area += 0.5 * np.cross(reflex3[b] - reflex3[a], reflex3[c] - reflex3[a])[2]
+    ring = np.vstack([reflex3, reflex3[:1]])
+    shoelace = 0.5 * np.sum(ring[:-1, 0] * ring[1:, 1] - ring[1:, 0] * ring[:-1, 1])
+    assert abs(area - shoelace) < 1e-12  # a proper triangulation: no overlap, nothing missing
+
+
+def small_skinned_payload():
+    return {"version": 1,
+            "mesh": {"positions": [0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1], "normals": [0, 0, 1] * 4, "uvs": [0, 0, 1, 0, 0, 1, 1, 1],
+                     "joints": [0, 1, 2, 3, 1, 0, 0, 0, 2, 2, 0, 0, 9, 0, 0, 0],
+                     "weights": [0.5, 0.25, 0.125, 0.125, 1, 0, 0, 0, 0.5, 0.5, 0, 0, 1, 0, 0, 0],
+                     "indices": [0, 1, 2, 1, 2, 3],
+                     "submeshes": [{"start": 0, "count": 3, "material": "A"}, {"start": 3, "count": 9, "material": "B"},
+                                   {"start": 6, "count": 2, "material": "Empty"}]},
+            "skin": {"bones": [{"name": "Hips", "inverseBindMatrix": list(range(16))},
+                               {"name": "MIXAMORIG:Spine", "inverseBindMatrix": [1, 0, 0, 10, 0, 1, 0, 20, 0, 0, 1, 30, 0, 0, 0, 1]},
+                               {"name": "NotInSkeleton", "inverseBindMatrix": [0] * 16},
+                               {"name": "other:Head", "inverseBindMatrix": [1.0] * 15}]}}
+
+
+def test_skinned_loader_semantics(sge, ybot):
+    F = sge.formats
+    cpu = ob.oracle_engine()
+    built = cpu.build_skeleton(ybot)
+    a = F.load_skinned_mesh(small_skinned_payload(), ybot, built["invBindModel"])
+    hips, spine, head = (ybot.names.index("mixamorig:" + n) for n in ("Hips", "Spine", "Head"))
+    assert a["boneMap"].tolist() == [hips, spine, -1, head]
+    s = np.float32(ybot.unit_scale)
+    assert np.array_equal(a["positions"][1], np.array([1, 0, 0], np.float32) * s)
+    # vertex 0: third influence unmapped -> weight zeroed, joint 0, the rest renormalised in float32
+    assert a["boneIndices"][0].tolist() == [hips, spine, 0, head]
+    w = np.array([0.5, 0.25, 0, 0.125], np.float32)
+    assert np.array_equal(a["boneWeights"][0], w / np.float32(0.875))
+    # vertex 2: both influences unmapped -> sum 0 -> left as zeros; vertex 3: joint index beyond the skin -> zeroed
+    assert not a["boneWeights"][2].any() and not a["boneWeights"][3].any()
+    assert a["boneIndices"][3].tolist() == [0, hips, hips, hips]
+    # inverse bind: row-major -> column-major with the translation scaled; wrong-length and unmapped entries ignored
+    ib = a["invBindModel"].reshape(-1, 4, 4)
+    assert np.array_equal(ib[spine][3], np.array([10 * s, 20 * s, 30 * s, 1], np.float32))
+    assert np.array_equal(ib[hips][0], np.array([0, 4, 8, 12], np.float32))
+    assert np.array_equal(ib[head], built["invBindModel"].reshape(-1, 4, 4)[head])
+    # submeshes: clamped to the index array, empty ones dropped
+    assert [m["name"] for m in a["meshes"]] == ["SkinnedMesh:A", "SkinnedMesh:B"]
+    assert a["meshes"][1]["indices"].tolist() == [1, 2, 3] and a["materialNames"] == ["A", "B"]
+    bad = small_skinned_payload()
+    bad["mesh"]["uvs"] = bad["mesh"]["uvs"][:-1]
+    assert F.load_skinned_mesh(bad, ybot, built["invBindModel"])["meshes"] == []
+    assert F.load_skinned_mesh("/nonexistent.json", ybot, built["invBindModel"]) is None
+
+
+def test_static_loader_semantics(sge, tmp_path):
+    F = sge.formats
+    js = {"version": 1, "meshes": [
+        {"name": "ok", "transform": list(range(16)), "mesh": {"positions": [0, 0, 0, 1, 0, 0, 0, 1, 0], "normals": [], "uvs": [0, 0],
+                                                                "indices": [0, 1, 2]},
+         "collisionHulls": [{"positions": [0, 0, 0, 1, 0, 0, 0, 0, 1], "indices": [0, 1, 2]}, {"positions": [0, 0], "indices": [0]},
+                            {"positions": [0, 0, 0], "indices": []}]},
+        {"name": "no-indices", "transform": [], "mesh": {"positions": [0, 0, 0], "normals": [], "uvs": [], "indices": []}},
+        {"name": "ragged", "transform": [], "mesh": {"positions": [0, 0, 0, 1], "normals": [], "uvs": [], "indices": [0, 0, 0]}},
+        {"name": "identity", "transform": [1, 2, 3], "mesh": {"positions": [0, 0, 0], "normals": [0, 1, 0], "uvs": [0, 0], "indices": [0, 0, 0]}}]}
+    path = tmp_path / "x.static.json"
+    path.write_text(json.dumps(js))
+    parts = F.load_static_mesh(path)
+    assert [p["name"] for p in parts] == ["ok", "identity"]
+    assert parts[0]["transform"].reshape(4, 4)[3].tolist() == [3, 7, 11, 15]  # row-major -> columns
+    assert parts[0]["normals"] is None and parts[0]["uvs"] is None and len(parts[0]["collisionHulls"]) == 1
+    assert parts[0]["submeshes"] == [{"start": 0, "count": 3, "material": "Default"}]
+    assert np.array_equal(parts[1]["transform"], np.eye(4, dtype=np.float32).reshape(16)) and parts[1]["normals"] is not None
+    assert F.load_static_mesh({"meshes": []}) is None  # version is not optional
+
+
+def test_transform_component_roundtrip(sge):
+    F = sge.formats
+    z = np.load(os.path.join(GOLDEN, "ornate_mirror_static.npz"))
+    m = F.matrix_from_array_row_major(z["transformRowMajor"])
+    t = F.transform_from_matrix(m)
+    assert np.allclose(t["scale"], 1, atol=1e-6) and np.allclose(t["translation"], m.reshape(4, 4)[3, :3])
+    assert np.abs(F.model_matrix(t) - m).max() < 1e-6
+    # quaternion algebra: upright then flip is a -90 degree turn about X (DemoScene.swift:331-333)
+    uf = sge.crowd._upright_flip()
+    R = F.matrix_from_quat(uf)[:3, :3].T
+    assert np.abs(R @ np.array([0, 0, 1.0]) - np.array([0, 1.0, 0])).max() < 1e-6  # Blender up -> engine up
+    t2 = {"translation": np.array([1, 2, 3], np.float32), "rotation": uf, "scale": np.array([2, 2, 2], np.float32)}
+    back = F.transform_from_matrix(F.model_matrix(t2))
+    assert np.allclose(back["scale"], 2, atol=1e-6) and np.allclose(np.abs(back["rotation"]), np.abs(uf), atol=1e-6)
+
+
+def test_real_ybot_mesh_binds_to_the_skeleton(sge, ybot):
+    """Known answer on the real asset: the FBX clusters' bind matrices and the skeleton JSON describe the same rig, so in
+    the bind-pose branch (no profile) every vertex lands at rootFix * (p - hips) * unitScale whatever its weights."""
+    cpu = ob.oracle_engine()
+    built, asset = sge.crowd.upload_ybot_mesh(cpu, ybot)
+    assert asset["vertexCount"] == 35440 and asset["indices"].size == 55320 * 3
+    assert (asset["boneMap"] == np.arange(65)).all()
+    w = asset["boneWeights"]
+    assert np.abs(w.sum(1) - 1).max() < 1e-6 and ((w > 0).sum(1) >= 1).all()
+    cpu.resize(1)
+    L = sge.assets.default_locomotion(1, ybot)
+    L["flags"] = 0
+    cpu.upload(bodies=sge.assets.default_bodies(1, np.zeros((1, 3))), params=sge.assets.default_controller_params(1),
+               controllers=sge.assets.default_controller_state(1), intents=sge.assets.default_intents(1), locomotion=L,
+               actions=sge.assets.default_actions(1))
+    cpu.tick(dt=0.0, stages=sge.abi.STAGE_POSE | sge.abi.STAGE_SKIN)
+    p, n, t = cpu.skinned()
+    payload = sge.formats.load_payload(os.path.join(GOLDEN, "ybot_skinned.npz"))
+    src = payload["mesh"]["positions"].reshape(-1, 3).astype(np.float64)
+    hips = ybot.translations[0].astype(np.float64)
+    fix = built["rootRotationFix"].reshape(4, 4)[:3, :3].T.astype(np.float64)  # column-major -> matrix
+    expect = ((src - hips) * ybot.unit_scale) @ fix.T
+    assert np.abs(p - expect).max() < 2e-4 * np.abs(expect).max()
+    assert np.abs(np.linalg.norm(n, axis=1) - 1).max() < 1e-5
+    assert p[:, 1].max() - p[:, 1].min() == pytest.approx(180.47 * ybot.unit_scale, rel=1e-3)  # a 1.8 m figure in engine units

@@ -286,6 +286,71 @@ def test_character_vs_character_sweeps(sge, engines):
     free.close()
 
 
+def test_real_asset_scene_bvh_and_queries(sge, engines):
+    """The engine's own static assets (17-Cheese + ornate mirror + Semla from the FBX sources, merged as in
+    configs[3]: 135,928 triangles + the ground quad): BVH bit-exact, casts / overlaps bit-exact."""
+    gpu, cpu = engines
+    ents, bounds = sge.crowd.asset_scene_entities(("cheese", "mirror", "semla"))
+    for e in engines:
+        e.rebuild_static(ents)
+    g, c = gpu.collision_copy(), cpu.collision_copy()
+    assert g["triOrder"].shape[0] == 71680 + 14246 + 50002 + 2
+    for k in ("positions", "indices", "aabbs", "triOrder", "triLeaf"):
+        assert np.array_equal(g[k], c[k]), k
+    assert_struct_equal(g["nodes"], c["nodes"], "nodes")
+    rng = np.random.default_rng(11)
+    n = 2048
+    which = rng.integers(0, 3, n)
+    lo = np.stack([bounds[k]["lo"] for k in which])
+    hi = np.stack([bounds[k]["hi"] for k in which])
+    origin = rng.uniform(lo - 2, hi + 4).astype(np.float32)
+    delta = (rng.normal(0, 1, (n, 3)) * rng.choice([0.3, 3.0, 30.0], (n, 1))).astype(np.float32)
+    delta[: n // 4, 0] = 0
+    delta[: n // 4, 2] = 0  # vertical probes, as the ground probe issues them
+    q = sge.make_queries(origin, delta)
+    q["mode"] = rng.integers(0, 3, n)
+    q["mask"] = rng.choice([0xFFFFFFFF, 1, 2, 4, 1 << 30, 5], n)  # per-asset collision layers
+    gh, ch = gpu.capsule_cast(q), cpu.capsule_cast(q)
+    assert_struct_equal(gh, ch, "cast")
+    assert gh["hit"].sum() > n // 8
+    go, gc = gpu.capsule_overlap_all(q, 8)
+    co, cc = cpu.capsule_overlap_all(q, 8)
+    assert np.array_equal(gc, cc) and gc.max() == 8
+    assert_struct_equal(go, co, "overlap")
+
+
+def test_real_assets_full_tick_parity(sge):
+    """Real Y-Bot mesh (35,440 vertices, mesh inverse-bind re-bind) + merged real static scene, mixed motion states:
+    the CCD state stays bit-exact with the oracle, palettes and every skinned vertex within 1e-5 relative."""
+    gpu = sge.CharacterEngine(0)
+    cpu = ob.oracle_engine()
+    n = 128
+    for e in (gpu, cpu):
+        build_scene(sge, e, n, seed=5, mixed=True, real_mesh=True, asset_scene=("cheese", "mirror", "semla"))
+    assert gpu.vertex_count == 35440
+    no_skin = sge.abi.STAGE_ALL & ~sge.abi.STAGE_SKIN
+    steps = 200
+    for s in range(steps):
+        gpu.tick(stages=no_skin)
+        ob.tick_mt(cpu, 8, stages=no_skin)
+        if s in (0, 3, 30, 90, steps - 1):
+            gpu.synchronize()
+            compare_states(sge, gpu, cpu, n)
+    d = gpu.download()
+    assert ((d["controllers"]["flags"] & sge.abi.CTRL_GROUNDED_NEAR) != 0).mean() > 0.6
+    assert gpu.move_stats().overflow == 0
+    gpu.tick(dt=0.0, stages=sge.abi.STAGE_SKIN)
+    ob.tick_mt(cpu, 8, dt=0.0, stages=sge.abi.STAGE_SKIN)
+    gp, gn, gt = gpu.skinned()
+    cp, cn, ct = cpu.skinned()
+    scale = np.abs(cp - cp.mean(0)).max()
+    assert np.abs(gp - cp).max() <= REL * np.abs(cp).max()
+    assert np.abs(gn - cn).max() <= 2e-5 and np.abs(gt - ct).max() <= 2e-5
+    assert scale > 50  # the crowd is spread over the scene
+    gpu.close()
+    cpu.close()
+
+
 def test_full_size_properties(sge):
     """BASELINE.json configs[2] at full size (10k clones x 14,080 vertices vs 71,680 triangles), checked through
     size-independent properties: characters are independent, so an oracle run over a RANDOM SUBSET of the crowd
