@@ -52,6 +52,7 @@ enum {
 #define SGE_MAX_FOURIER_ORDER 8
 #define SGE_MAX_COEFFS (1 + 2 * SGE_MAX_FOURIER_ORDER)
 #define SGE_MAX_OVERLAP_HITS 8
+#define SGE_MAX_PLATFORMS 64 /* kinematic platforms per step (the demo scene has two) */
 #define SGE_MANIFOLD_MAX 4 /* ContactManifoldCache.maxCount, Game/Systems.swift:1160 */
 
 /* ------------------------------------------------------------------------- */
@@ -363,6 +364,21 @@ typedef struct sge_static_mesh_entity {
  * (CollisionQuery.swift:331-417, 577-670) for the static set. */
 int sge_collision_rebuild_static(sge_context* ctx, const sge_static_mesh_entity* entities, int32_t count);
 
+/* The dynamic triangle set: collidable StaticMeshComponents whose PhysicsBodyComponent is not .static
+ * (StaticTriMesh.partitionEntities, CollisionQuery.swift:886-900; rebuildDynamic :744-751). Every query
+ * consults the static set first, then this one; its triangle indices are reported offset by the static
+ * set's triangle count (:796-801 and the other combined queries). count = 0 empties the set. */
+int sge_collision_rebuild_dynamic(sge_context* ctx, const sge_static_mesh_entity* entities, int32_t count);
+
+enum { SGE_SET_STATIC = 0, SGE_SET_DYNAMIC = 1 };
+/* CollisionQuery.updateStaticTransforms / updateDynamicTransforms (CollisionQuery.swift:69-83):
+ * TriangleMeshSet.updateTransforms (:419-462) re-poses the listed entities of the last rebuild of `set`
+ * (entity_indices index that call's array; entities that kept no triangle are skipped) with new
+ * TransformComponent.modelMatrix values [n][16], recomputes their triangle AABBs and refits the BVH
+ * (BVH.refit :528-575) — topology, triangle order and the area filter of the rebuild are kept. */
+int sge_collision_update_transforms(sge_context* ctx, int32_t set, const int32_t* entity_indices,
+                                    const float* model_matrices, int32_t n);
+
 /* Introspection for parity tests: sizes, then copies of the host-side build. */
 typedef struct sge_bvh_node {
     float boundsMin[3];
@@ -372,6 +388,10 @@ typedef struct sge_bvh_node {
 int sge_collision_counts(sge_context* ctx, int32_t* vertex_count, int32_t* triangle_count, int32_t* node_count);
 int sge_collision_copy(sge_context* ctx, float* positions, uint32_t* indices, float* triangle_aabbs,
                        sge_bvh_node* nodes, int32_t* tri_order, int32_t* tri_leaf);
+/* the same two calls for either set (the two above = SGE_SET_STATIC) */
+int sge_collision_counts_set(sge_context* ctx, int32_t set, int32_t* vertex_count, int32_t* triangle_count, int32_t* node_count);
+int sge_collision_copy_set(sge_context* ctx, int32_t set, float* positions, uint32_t* indices, float* triangle_aabbs,
+                           sge_bvh_node* nodes, int32_t* tri_order, int32_t* tri_leaf);
 
 enum { SGE_CAST = 0, SGE_CAST_BLOCKING = 1, SGE_CAST_GROUND = 2 };
 
@@ -419,6 +439,43 @@ int sge_capsule_overlap_all_batch(sge_context* ctx, const sge_capsule_query* que
  * overlapping triangle (first in visit order among equal depths); out_found[i] = 0 means nil. Synchronous. */
 int sge_capsule_overlap_batch(sge_context* ctx, const sge_capsule_query* queries, int32_t count,
                               sge_capsule_overlap_hit* out, int32_t* out_found);
+
+/* CollisionQuery.raycast(origin:direction:maxDistance:mask:) (CollisionQuery.swift:85-94, 768-785, 916-978) */
+typedef struct sge_ray_query {
+    float origin[3];
+    float direction[3]; /* used as given (the reference does not normalise it) */
+    float maxDistance;
+    uint32_t mask;
+} sge_ray_query;
+/* RaycastHit, CollisionQuery.swift:28-34 */
+typedef struct sge_raycast_hit {
+    int32_t hit; /* 0 = nil */
+    float distance;
+    float position[3];
+    float normal[3];
+    int32_t triangleIndex;
+    sge_surface_material material;
+} sge_raycast_hit;
+int sge_raycast_batch(sge_context* ctx, const sge_ray_query* queries, int32_t count, sge_raycast_hit* out);
+
+/* Kinematic platforms — the inputs PlatformCarry.computeDelta (Systems.swift:644-732) reads per platform entity
+ * (PhysicsBodyComponent + TransformComponent + StaticMeshComponent + KinematicPlatformComponent, :1832-1835), in
+ * entity order: the body type, pDelta = positionF - prevPositionF, and meshWorldAABB(collisionMesh ?? mesh, transform)
+ * (:627-642), which the reference recomputes per character and this ABI takes once per step. */
+typedef struct sge_platform_state {
+    float aabbMin[3];
+    float aabbMax[3];
+    float delta[3];
+    uint32_t kinematic; /* bodyType == .kinematic */
+    uint32_t hasAABB;   /* 0 when the mesh has no positions (meshWorldAABB returned nil) */
+    uint32_t _pad;
+} sge_platform_state;
+/* meshWorldAABB (Systems.swift:627-642): host helper. Returns SGE_OK and writes min/max, or SGE_ERR_INVALID for an
+ * empty mesh. */
+int sge_mesh_world_aabb(const float* positions, int32_t vertex_count, const float model_matrix[16],
+                        float out_min[3], float out_max[3]);
+/* The platform list of the coming ticks (count = 0: none, PlatformCarry returns .zero at :651). */
+int sge_platforms_upload(sge_context* ctx, const sge_platform_state* platforms, int32_t count);
 
 /* ------------------------------------------------------------------------- */
 /* Characters + the batched fixed step                                        */

@@ -46,7 +46,9 @@ struct BVH {
     std::vector<int> triOrder, triLeaf;
     int root = -1;
     void build(const std::vector<AABB>& triangleAABBs);
+    void refit(const std::vector<int>& updatedTriangles, const std::vector<AABB>& triangleAABBs); // :528-575
 };
+struct MeshSlice { int vertexBegin = 0, vertexEnd = 0, indexBegin = 0, indexEnd = 0, triBegin = 0, triEnd = 0; bool valid = false; }; // :480-485
 struct TriangleMeshSet {
     std::vector<V3> positions;
     std::vector<uint32_t> indices;
@@ -55,7 +57,11 @@ struct TriangleMeshSet {
     std::vector<uint32_t> triangleLayers;
     BVH bvh;
     bool hasBVH = false;
+    std::vector<MeshSlice> slices;   // by entity index of the rebuild call (the reference keys them by Entity)
+    std::vector<V3> localPositions;  // collisionMesh.streams.positions of every entity, same indexing as `positions`
     void rebuild(const sge_static_mesh_entity* ents, int count);
+    // updateTransforms (:419-462): new model matrices for `n` entities of the last rebuild; returns the updated triangles
+    std::vector<int> updateTransforms(const int32_t* entities, const float* modelMatrices, int n);
 };
 struct QueryStats { long long candidates = 0, sweeps = 0, iterations = 0, queries = 0; };
 
@@ -66,8 +72,11 @@ struct CapsuleOverlapHit { float depth; V3 position, normal, triangleNormal; int
 QueryStats& thread_stats();
 QueryStats take_thread_stats();
 
+struct RaycastHit { float distance; V3 position, normal; int triangleIndex; sge_surface_material material; };
+
 struct CollisionQuery {
-    TriangleMeshSet staticSet;
+    TriangleMeshSet staticSet, dynamicSet; // StaticTriMesh.staticSet / dynamicSet (:710-711)
+    bool raycast(V3 origin, V3 direction, float maxDistance, uint32_t mask, RaycastHit& out) const; // :768-785
     bool capsuleCastCombined(V3 from, V3 delta, float radius, float halfHeight, bool blockingOnly,
                              bool hasMinNormalY, float minNormalY, uint32_t mask, CapsuleCastHit& out) const;
     int capsuleOverlapAll(V3 from, float radius, float halfHeight, int maxHits, uint32_t mask,
@@ -93,6 +102,8 @@ struct World {
     std::vector<M4> local, model, palette; // [N][B]
     // skinned outputs, packed
     std::vector<float> outPositions, outNormals, outTangents;
+    // kinematic platforms of this step (PlatformCarry.computeDelta inputs, Systems.swift:644-732)
+    std::vector<sge_platform_state> platforms;
     // agents (start-of-step snapshot over ALL ranks' characters)
     std::vector<sge_agent_state> importedAgents;
     int agentSelfOffset = 0;

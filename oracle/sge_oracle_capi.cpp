@@ -82,17 +82,80 @@ int sgeo_collision_rebuild_static(sgeo_world* h, const sge_static_mesh_entity* e
     return SGE_OK;
 }
 
-int sgeo_collision_counts(sgeo_world* h, int32_t* v, int32_t* t, int32_t* n) {
-    const TriangleMeshSet& s = h->w.query.staticSet;
+int sgeo_collision_rebuild_dynamic(sgeo_world* h, const sge_static_mesh_entity* ents, int32_t count) {
+    if (!h || (count > 0 && !ents)) return SGE_ERR_INVALID;
+    h->w.query.dynamicSet.rebuild(ents, count);
+    return SGE_OK;
+}
+
+int sgeo_collision_update_transforms(sgeo_world* h, int32_t set, const int32_t* entities, const float* matrices, int32_t n) {
+    if (!h || (set != SGE_SET_STATIC && set != SGE_SET_DYNAMIC) || n < 0 || (n > 0 && (!entities || !matrices))) return SGE_ERR_INVALID;
+    (set == SGE_SET_STATIC ? h->w.query.staticSet : h->w.query.dynamicSet).updateTransforms(entities, matrices, n);
+    return SGE_OK;
+}
+
+int sgeo_collision_counts_set(sgeo_world* h, int32_t set, int32_t* v, int32_t* t, int32_t* n) {
+    const TriangleMeshSet& s = set == SGE_SET_DYNAMIC ? h->w.query.dynamicSet : h->w.query.staticSet;
     if (v) *v = (int32_t)s.positions.size();
     if (t) *t = (int32_t)s.triangleAABBs.size();
     if (n) *n = (int32_t)s.bvh.nodes.size();
     return SGE_OK;
 }
 
+int sgeo_collision_counts(sgeo_world* h, int32_t* v, int32_t* t, int32_t* n) { return sgeo_collision_counts_set(h, SGE_SET_STATIC, v, t, n); }
+
+int sgeo_collision_copy_set(sgeo_world* h, int32_t set, float* positions, uint32_t* indices, float* aabbs, sge_bvh_node* nodes,
+                            int32_t* triOrder, int32_t* triLeaf);
 int sgeo_collision_copy(sgeo_world* h, float* positions, uint32_t* indices, float* aabbs, sge_bvh_node* nodes,
                         int32_t* triOrder, int32_t* triLeaf) {
-    const TriangleMeshSet& s = h->w.query.staticSet;
+    return sgeo_collision_copy_set(h, SGE_SET_STATIC, positions, indices, aabbs, nodes, triOrder, triLeaf);
+}
+
+int sgeo_raycast_batch(sgeo_world* h, const sge_ray_query* q, int32_t count, sge_raycast_hit* out) {
+    for (int i = 0; i < count; ++i) {
+        RaycastHit hit;
+        bool got = h->w.query.raycast(V3{q[i].origin[0], q[i].origin[1], q[i].origin[2]},
+                                      V3{q[i].direction[0], q[i].direction[1], q[i].direction[2]}, q[i].maxDistance, q[i].mask, hit);
+        std::memset(&out[i], 0, sizeof(out[i]));
+        out[i].hit = got ? 1 : 0;
+        out[i].triangleIndex = -1;
+        if (got) {
+            out[i].distance = hit.distance;
+            out[i].position[0] = hit.position.x; out[i].position[1] = hit.position.y; out[i].position[2] = hit.position.z;
+            out[i].normal[0] = hit.normal.x; out[i].normal[1] = hit.normal.y; out[i].normal[2] = hit.normal.z;
+            out[i].triangleIndex = hit.triangleIndex;
+            out[i].material = hit.material;
+        }
+    }
+    return SGE_OK;
+}
+
+// meshWorldAABB, Systems.swift:627-642
+int sgeo_mesh_world_aabb(const float* positions, int32_t count, const float* m, float* outMin, float* outMax) {
+    if (!positions || count <= 0 || !m || !outMin || !outMax) return SGE_ERR_INVALID;
+    M4 model;
+    for (int k = 0; k < 16; ++k) (&model.c[0].x)[k] = m[k];
+    const float big = 3.402823466e+38f;
+    V3 mn = V3{big, big, big}, mx = V3{-big, -big, -big};
+    for (int i = 0; i < count; ++i) {
+        V4 wp = mul(model, V4{positions[i * 3], positions[i * 3 + 1], positions[i * 3 + 2], 1});
+        V3 v = V3{wp.x, wp.y, wp.z};
+        mn = vmin(mn, v); mx = vmax(mx, v);
+    }
+    outMin[0] = mn.x; outMin[1] = mn.y; outMin[2] = mn.z;
+    outMax[0] = mx.x; outMax[1] = mx.y; outMax[2] = mx.z;
+    return SGE_OK;
+}
+
+int sgeo_platforms_upload(sgeo_world* h, const sge_platform_state* p, int32_t count) {
+    if (!h || count < 0 || (count > 0 && !p)) return SGE_ERR_INVALID;
+    h->w.platforms.assign(p, p + count);
+    return SGE_OK;
+}
+
+int sgeo_collision_copy_set(sgeo_world* h, int32_t set, float* positions, uint32_t* indices, float* aabbs, sge_bvh_node* nodes,
+                            int32_t* triOrder, int32_t* triLeaf) {
+    const TriangleMeshSet& s = set == SGE_SET_DYNAMIC ? h->w.query.dynamicSet : h->w.query.staticSet;
     if (positions) std::memcpy(positions, s.positions.data(), s.positions.size() * 12);
     if (indices) std::memcpy(indices, s.indices.data(), s.indices.size() * 4);
     if (aabbs) std::memcpy(aabbs, s.triangleAABBs.data(), s.triangleAABBs.size() * 24);

@@ -13,6 +13,7 @@
 // (GameTests/GameTests.swift:12-16 is empty); tests pin this file with analytic
 // known answers and brute-force cross-checks instead.
 #include <algorithm>
+#include <limits>
 #include "sge_oracle.h"
 
 namespace sgeo {
@@ -111,16 +112,20 @@ void BVH::build(const std::vector<AABB>& triangleAABBs) { // :502-513
 
 void TriangleMeshSet::rebuild(const sge_static_mesh_entity* ents, int count) { // :331-417
     positions.clear(); indices.clear(); triangleAABBs.clear(); triangleMaterials.clear(); triangleLayers.clear();
+    slices.assign(count > 0 ? count : 0, MeshSlice{});
+    localPositions.clear();
     const float areaEps = 1e-10f;
     for (int e = 0; e < count; ++e) {
         const sge_static_mesh_entity& m = ents[e];
         M4 model;
         for (int k = 0; k < 16; ++k) (&model.c[0].x)[k] = m.modelMatrix[k];
         uint32_t baseVertex = (uint32_t)positions.size();
+        const int indexStart = (int)indices.size(), triStart = (int)triangleAABBs.size();
         for (int v = 0; v < m.vertexCount; ++v) {
             V4 p = V4{m.positions[v * 3], m.positions[v * 3 + 1], m.positions[v * 3 + 2], 1};
             V4 wp = mul(model, p);
             positions.push_back(V3{wp.x, wp.y, wp.z});
+            localPositions.push_back(V3{p.x, p.y, p.z});
         }
         int triCount = m.indexCount / 3;
         bool perTri = m.triangleMaterials && m.triangleMaterialCount == triCount;
@@ -136,10 +141,81 @@ void TriangleMeshSet::rebuild(const sge_static_mesh_entity* ents, int count) { /
             triangleLayers.push_back(m.collisionLayer);
             t += 3; triLocal += 1;
         }
+        const int indexEnd = (int)indices.size(), triEnd = (int)triangleAABBs.size();
+        if (indexEnd > indexStart && triEnd > triStart) // :404-410
+            slices[e] = MeshSlice{(int)baseVertex, (int)positions.size(), indexStart, indexEnd, triStart, triEnd, true};
     }
     hasBVH = !triangleAABBs.empty();
     if (hasBVH) bvh.build(triangleAABBs);
     else { bvh.nodes.clear(); bvh.triOrder.clear(); bvh.triLeaf.clear(); bvh.root = -1; }
+}
+
+// :419-462
+std::vector<int> TriangleMeshSet::updateTransforms(const int32_t* entities, const float* modelMatrices, int n) {
+    std::vector<int> updatedTriangles;
+    if (n <= 0 || triangleAABBs.empty()) return updatedTriangles;
+    for (int k = 0; k < n; ++k) {
+        const int e = entities[k];
+        if (e < 0 || e >= (int)slices.size() || !slices[e].valid) continue; // `guard let slice = slices[e]`
+        const MeshSlice& slice = slices[e];
+        M4 model;
+        for (int j = 0; j < 16; ++j) (&model.c[0].x)[j] = modelMatrices[(size_t)k * 16 + j];
+        for (int i = slice.vertexBegin; i < slice.vertexEnd; ++i) {
+            V3 pl = localPositions[i];
+            V4 wp = mul(model, V4{pl.x, pl.y, pl.z, 1});
+            positions[i] = V3{wp.x, wp.y, wp.z};
+        }
+        int triIndex = slice.triBegin;
+        int i = slice.indexBegin;
+        while (i + 2 < slice.indexEnd) {
+            V3 p0 = positions[indices[i]], p1 = positions[indices[i + 1]], p2 = positions[indices[i + 2]];
+            triangleAABBs[triIndex] = AABB{vmin(p0, vmin(p1, p2)), vmax(p0, vmax(p1, p2))};
+            updatedTriangles.push_back(triIndex);
+            i += 3;
+            triIndex += 1;
+        }
+    }
+    if (!updatedTriangles.empty() && hasBVH) bvh.refit(updatedTriangles, triangleAABBs);
+    return updatedTriangles;
+}
+
+// :528-575 — leaves holding an updated triangle are re-bounded from their triangles, then every ancestor,
+// deepest first, from its two children
+void BVH::refit(const std::vector<int>& updatedTriangles, const std::vector<AABB>& triangleAABBs) {
+    if (nodes.empty()) return;
+    std::vector<char> leafDirty(nodes.size(), 0), parentDirty(nodes.size(), 0);
+    std::vector<int> updatedLeaves, dirtyParents;
+    for (int tri : updatedTriangles) {
+        int leaf = triLeaf[tri];
+        if (leaf >= 0 && !leafDirty[leaf]) { leafDirty[leaf] = 1; updatedLeaves.push_back(leaf); }
+    }
+    for (int leaf : updatedLeaves) {
+        BVHNode& node = nodes[leaf];
+        AABB b = triangleAABBs[triOrder[node.start]]; // boundsForRange :672-683
+        for (int i = 1; i < node.count; ++i) b = merge(b, triangleAABBs[triOrder[node.start + i]]);
+        node.bounds = b;
+    }
+    for (int leaf : updatedLeaves) {
+        int parent = nodes[leaf].parent;
+        while (parent >= 0) {
+            if (!parentDirty[parent]) { parentDirty[parent] = 1; dirtyParents.push_back(parent); }
+            parent = nodes[parent].parent;
+        }
+    }
+    if (dirtyParents.empty()) return;
+    std::vector<int> depths(dirtyParents.size());
+    for (size_t i = 0; i < dirtyParents.size(); ++i) {
+        int depth = 0, node = dirtyParents[i];
+        while (node >= 0) { depth += 1; node = nodes[node].parent; }
+        depths[i] = depth;
+    }
+    std::vector<int> order(dirtyParents.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return depths[a] > depths[b]; });
+    for (int i : order) {
+        BVHNode& p = nodes[dirtyParents[i]];
+        p.bounds = merge(nodes[p.left].bounds, nodes[p.right].bounds);
+    }
 }
 
 // ---- primitive distance queries ----
@@ -314,8 +390,8 @@ static inline bool aabbDisjoint(const AABB& b, V3 minP, V3 maxP) {
            b.max.z < minP.z || b.min.z > maxP.z;
 }
 
-// :1011-1117 (static set; triangleIndexOffset 0)
-static bool capsuleCastBVH(const TriangleMeshSet& set, QueryStats& stats, V3 from, V3 delta, float radius,
+// :1011-1117
+static bool capsuleCastBVH(const TriangleMeshSet& set, int triangleIndexOffset, QueryStats& stats, V3 from, V3 delta, float radius,
                            float halfHeight, bool blockingOnly, bool hasMinNormalY, float minNormalY,
                            uint32_t mask, CapsuleCastHit& bestHit) {
     if (!set.hasBVH || set.bvh.root < 0) return false;
@@ -354,7 +430,7 @@ static bool capsuleCastBVH(const TriangleMeshSet& set, QueryStats& stats, V3 fro
                 stats.iterations += iterCount; // the reference skips this add on filtered hits (stats only)
                 if (got && hit.toi < bestT) {
                     hit.material = set.triangleMaterials[triIndex];
-                    hit.triangleIndex = triIndex;
+                    hit.triangleIndex = triIndex + triangleIndexOffset;
                     if (blockingOnly) {
                         if (dot(delta, hit.normal) >= 0) continue;
                         if (dot(delta, hit.triangleNormal) >= 0) continue;
@@ -380,15 +456,20 @@ bool CollisionQuery::capsuleCastCombined(V3 from, V3 delta, float radius, float 
     float len = length(delta);
     if (len < 1e-6f) return false;
     g_tls_stats.queries += 1;
-    return capsuleCastBVH(staticSet, g_tls_stats, from, delta, radius, halfHeight, blockingOnly, hasMinNormalY, minNormalY, mask, out);
+    CapsuleCastHit a, b;
+    bool haveA = capsuleCastBVH(staticSet, 0, g_tls_stats, from, delta, radius, halfHeight, blockingOnly, hasMinNormalY, minNormalY, mask, a);
+    bool haveB = capsuleCastBVH(dynamicSet, (int)staticSet.triangleAABBs.size(), g_tls_stats, from, delta, radius, halfHeight,
+                                blockingOnly, hasMinNormalY, minNormalY, mask, b);
+    if (haveA && haveB) { out = a.toi <= b.toi ? a : b; return true; } // chooseNearest :909-914
+    if (haveA) { out = a; return true; }
+    if (haveB) { out = b; return true; }
+    return false;
 }
 
-// :852-882 + :1201-1283 (static set only, so the over-budget sort never triggers)
-int CollisionQuery::capsuleOverlapAll(V3 from, float radius, float halfHeight, int maxHits, uint32_t mask,
-                                      CapsuleOverlapHit* hits) const {
-    const TriangleMeshSet& set = staticSet;
+// :1201-1283
+static int capsuleOverlapBVHAll(const TriangleMeshSet& set, int triangleIndexOffset, V3 from, float radius, float halfHeight,
+                                int maxHits, uint32_t mask, CapsuleOverlapHit* hits) {
     if (!set.hasBVH || set.bvh.root < 0) return 0;
-    g_tls_stats.queries += 1;
     const BVH& bvh = set.bvh;
     V3 up = V3{0, 1, 0};
     V3 a0 = from + up * halfHeight, b0 = from - up * halfHeight;
@@ -418,7 +499,7 @@ int CollisionQuery::capsuleOverlapAll(V3 from, float radius, float halfHeight, i
                 V3 nn = dist < 1e-6f ? triNormal : normalize(segPoint - triPoint);
                 V3 triN = triNormal;
                 if (dot(triN, nn) < 0) triN = -triN;
-                hits[n++] = CapsuleOverlapHit{depth, triPoint, nn, triN, triIndex, set.triangleMaterials[triIndex]};
+                hits[n++] = CapsuleOverlapHit{depth, triPoint, nn, triN, triIndex + triangleIndexOffset, set.triangleMaterials[triIndex]};
                 if (n >= maxHits) return n;
             }
         } else {
@@ -429,9 +510,20 @@ int CollisionQuery::capsuleOverlapAll(V3 from, float radius, float halfHeight, i
     return n;
 }
 
-// :830-850 + :1119-1199 (static set): the deepest overlap; `depth <= bestDepth` keeps the first visited on ties
-bool CollisionQuery::capsuleOverlap(V3 from, float radius, float halfHeight, uint32_t mask, CapsuleOverlapHit& best) const {
-    const TriangleMeshSet& set = staticSet;
+// :852-882 — static hits first, the dynamic set fills what is left of maxHits (so the over-budget sort never triggers)
+int CollisionQuery::capsuleOverlapAll(V3 from, float radius, float halfHeight, int maxHits, uint32_t mask,
+                                      CapsuleOverlapHit* hits) const {
+    if (staticSet.hasBVH || dynamicSet.hasBVH) g_tls_stats.queries += 1;
+    int n = capsuleOverlapBVHAll(staticSet, 0, from, radius, halfHeight, maxHits, mask, hits);
+    int remaining = maxHits - n;
+    if (remaining > 0)
+        n += capsuleOverlapBVHAll(dynamicSet, (int)staticSet.triangleAABBs.size(), from, radius, halfHeight, remaining, mask, hits + n);
+    return n;
+}
+
+// :1119-1199: the deepest overlap of one set; `depth <= bestDepth` keeps the first visited on ties
+static bool capsuleOverlapBVH(const TriangleMeshSet& set, int triangleIndexOffset, V3 from, float radius, float halfHeight,
+                              uint32_t mask, CapsuleOverlapHit& best) {
     if (!set.hasBVH || set.bvh.root < 0) return false;
     const BVH& bvh = set.bvh;
     V3 up = V3{0, 1, 0};
@@ -465,7 +557,7 @@ bool CollisionQuery::capsuleOverlap(V3 from, float radius, float halfHeight, uin
                 V3 triN = triNormal;
                 if (dot(triN, nn) < 0) triN = -triN;
                 bestDepth = depth;
-                best = CapsuleOverlapHit{depth, triPoint, nn, triN, triIndex, set.triangleMaterials[triIndex]};
+                best = CapsuleOverlapHit{depth, triPoint, nn, triN, triIndex + triangleIndexOffset, set.triangleMaterials[triIndex]};
                 have = true;
             }
         } else {
@@ -474,6 +566,101 @@ bool CollisionQuery::capsuleOverlap(V3 from, float radius, float halfHeight, uin
         }
     }
     return have;
+}
+
+// :830-850
+bool CollisionQuery::capsuleOverlap(V3 from, float radius, float halfHeight, uint32_t mask, CapsuleOverlapHit& best) const {
+    CapsuleOverlapHit a, b;
+    bool haveA = capsuleOverlapBVH(staticSet, 0, from, radius, halfHeight, mask, a);
+    bool haveB = capsuleOverlapBVH(dynamicSet, (int)staticSet.triangleAABBs.size(), from, radius, halfHeight, mask, b);
+    if (haveA && haveB) { best = a.depth >= b.depth ? a : b; return true; }
+    if (haveA) { best = a; return true; }
+    if (haveB) { best = b; return true; }
+    return false;
+}
+
+// ---- raycast (:768-785, 916-978, 1575-1631) ----
+static bool rayTriangle(V3 origin, V3 direction, V3 v0, V3 v1, V3 v2, float eps, float& tOut) { // :1575-1601
+    V3 e1 = v1 - v0, e2 = v2 - v0;
+    V3 pvec = cross(direction, e2);
+    float det = dot(e1, pvec);
+    if (fabsf(det) < eps) return false;
+    float invDet = 1.0f / det;
+    V3 tvec = origin - v0;
+    float u = dot(tvec, pvec) * invDet;
+    if (u < 0 || u > 1) return false;
+    V3 qvec = cross(tvec, e1);
+    float v = dot(direction, qvec) * invDet;
+    if (v < 0 || (u + v) > 1) return false;
+    float t = dot(e2, qvec) * invDet;
+    if (!(t >= 0)) return false;
+    tOut = t;
+    return true;
+}
+static bool rayAABB(V3 origin, V3 direction, const AABB& bounds, float& tminOut) { // :1603-1630
+    const float big = std::numeric_limits<float>::max();
+    float invX = direction.x != 0 ? 1.0f / direction.x : big;
+    float invY = direction.y != 0 ? 1.0f / direction.y : big;
+    float invZ = direction.z != 0 ? 1.0f / direction.z : big;
+    float tmin = (bounds.min.x - origin.x) * invX, tmax = (bounds.max.x - origin.x) * invX;
+    if (tmin > tmax) std::swap(tmin, tmax);
+    float tymin = (bounds.min.y - origin.y) * invY, tymax = (bounds.max.y - origin.y) * invY;
+    if (tymin > tymax) std::swap(tymin, tymax);
+    if (tmin > tymax || tymin > tmax) return false;
+    tmin = fmax_s(tmin, tymin);
+    tmax = fmin_s(tmax, tymax);
+    float tzmin = (bounds.min.z - origin.z) * invZ, tzmax = (bounds.max.z - origin.z) * invZ;
+    if (tzmin > tzmax) std::swap(tzmin, tzmax);
+    if (tmin > tzmax || tzmin > tmax) return false;
+    tmin = fmax_s(tmin, tzmin);
+    tminOut = tmin;
+    return true;
+}
+static bool raycastBVH(const TriangleMeshSet& set, int triangleIndexOffset, V3 origin, V3 direction, float maxDistance,
+                       uint32_t mask, RaycastHit& hit) { // :916-978
+    if (!set.hasBVH || set.bvh.root < 0) return false;
+    const BVH& bvh = set.bvh;
+    const float eps = 1e-6f;
+    float closestT = maxDistance;
+    bool have = false;
+    std::vector<int> stack{bvh.root};
+    while (!stack.empty()) {
+        int nodeIndex = stack.back(); stack.pop_back();
+        const BVHNode& node = bvh.nodes[nodeIndex];
+        float rangeMin;
+        if (!rayAABB(origin, direction, node.bounds, rangeMin)) continue;
+        if (rangeMin > closestT) continue;
+        if (node.left < 0) {
+            for (int i = node.start; i < node.start + node.count; ++i) {
+                int triIndex = bvh.triOrder[i];
+                if ((set.triangleLayers[triIndex] & mask) == 0) continue;
+                int base = triIndex * 3;
+                if (base + 2 >= (int)set.indices.size()) continue;
+                V3 v0 = set.positions[set.indices[base]], v1 = set.positions[set.indices[base + 1]], v2 = set.positions[set.indices[base + 2]];
+                float t;
+                if (rayTriangle(origin, direction, v0, v1, v2, eps, t) && t < closestT) {
+                    V3 n = normalize(cross(v1 - v0, v2 - v0));
+                    V3 normal = dot(n, direction) > 0 ? -n : n;
+                    closestT = t;
+                    hit = RaycastHit{t, origin + direction * t, normal, triIndex + triangleIndexOffset, set.triangleMaterials[triIndex]};
+                    have = true;
+                }
+            }
+        } else {
+            stack.push_back(node.left);
+            stack.push_back(node.right);
+        }
+    }
+    return have;
+}
+bool CollisionQuery::raycast(V3 origin, V3 direction, float maxDistance, uint32_t mask, RaycastHit& out) const {
+    RaycastHit a, b;
+    bool haveA = raycastBVH(staticSet, 0, origin, direction, maxDistance, mask, a);
+    bool haveB = raycastBVH(dynamicSet, (int)staticSet.triangleAABBs.size(), origin, direction, maxDistance, mask, b);
+    if (haveA && haveB) { out = a.distance <= b.distance ? a : b; return true; }
+    if (haveA) { out = a; return true; }
+    if (haveB) { out = b; return true; }
+    return false;
 }
 
 } // namespace sgeo

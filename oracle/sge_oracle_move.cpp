@@ -620,6 +620,61 @@ void collect_agent_states(const World& w, std::vector<AgentSweepState>& agents, 
     }
 }
 
+// PlatformCarry.computeDelta :644-732 over the step's platform list (meshWorldAABB is taken per platform, not per
+// character: it depends on the platform alone)
+static V3 platformCarryDelta(V3 position, const sge_controller_params& P, const std::vector<sge_platform_state>& platforms) {
+    if (platforms.empty()) return V3{0, 0, 0};
+    float capsuleHalf = P.halfHeight + P.radius;
+    float baseY = position.y - capsuleHalf;
+    V3 capMin = V3{position.x - P.radius, position.y - capsuleHalf, position.z - P.radius};
+    V3 capMax = V3{position.x + P.radius, position.y + capsuleHalf, position.z + P.radius};
+    float sideTol = fmax_s(P.skinWidth, P.groundSnapSkin);
+    V3 bestCarry = V3{0, 0, 0}, pushDelta = V3{0, 0, 0};
+    for (const sge_platform_state& pf : platforms) {
+        if (!pf.kinematic) continue;
+        V3 pDelta = V3{pf.delta[0], pf.delta[1], pf.delta[2]};
+        if (length_squared(pDelta) < 1e-8f) continue;
+        if (!pf.hasAABB) continue;
+        V3 amin = V3{pf.aabbMin[0], pf.aabbMin[1], pf.aabbMin[2]}, amax = V3{pf.aabbMax[0], pf.aabbMax[1], pf.aabbMax[2]};
+        V3 tol = V3{sideTol, sideTol, sideTol};
+        V3 expandedMin = amin - tol, expandedMax = amax + tol;
+        bool overlap = capMin.x <= expandedMax.x && capMax.x >= expandedMin.x && capMin.y <= expandedMax.y &&
+                       capMax.y >= expandedMin.y && capMin.z <= expandedMax.z && capMax.z >= expandedMin.z;
+        if (!overlap) continue;
+        bool withinXZ = position.x >= amin.x - P.radius && position.x <= amax.x + P.radius &&
+                        position.z >= amin.z - P.radius && position.z <= amax.z + P.radius;
+        float topY = amax.y;
+        float topTol = P.snapDistance + fmax_s(P.skinWidth, P.groundSnapSkin) + 0.05f;
+        bool onTop = withinXZ && baseY >= topY - topTol && baseY <= topY + topTol;
+        if (onTop) {
+            if (length_squared(pDelta) > length_squared(bestCarry)) bestCarry = pDelta;
+        } else {
+            float yMin = amin.y - capsuleHalf, yMax = amax.y + capsuleHalf;
+            if (position.y >= yMin && position.y <= yMax) {
+                bool outsideX = position.x < amin.x - P.radius || position.x > amax.x + P.radius;
+                bool outsideZ = position.z < amin.z - P.radius || position.z > amax.z + P.radius;
+                if (!outsideX && !outsideZ) continue;
+                float cx = fmax_s(amin.x, fmin_s(position.x, amax.x));
+                float cz = fmax_s(amin.z, fmin_s(position.z, amax.z));
+                float dx = position.x - cx, dz = position.z - cz;
+                float sideDistSq = dx * dx + dz * dz;
+                float sidePushTol = P.radius + sideTol;
+                if (sideDistSq <= sidePushTol * sidePushTol) {
+                    float dirLen = sqrtf(fmax_s(sideDistSq, 0.0f));
+                    if (dirLen > 1e-5f) {
+                        V3 dir = V3{dx / dirLen, 0, dz / dirLen};
+                        float moveToward = dot(V3{pDelta.x, 0, pDelta.z}, dir);
+                        if (moveToward > 0) pushDelta += V3{pDelta.x, 0, pDelta.z};
+                    }
+                }
+            }
+        }
+    }
+    if (length_squared(bestCarry) > 1e-8f) return bestCarry;
+    if (length_squared(pushDelta) > 1e-8f) return pushDelta;
+    return V3{0, 0, 0};
+}
+
 // KinematicMoveStopSystem.fixedUpdate :1823-1902
 void kinematic_move_fixed_update(World& w, int first, int count, float dt, V3 gravity,
                                  const std::vector<AgentSweepState>* agentsPtr, int selfOffset) {
@@ -635,7 +690,11 @@ void kinematic_move_fixed_update(World& w, int first, int count, float dt, V3 gr
         cacheDecay(C);
         bool selfSolid = (P.agentFlags & SGE_AGENT_PRESENT) && (P.agentFlags & SGE_AGENT_SOLID);
         float selfRadius = ((P.agentFlags & SGE_AGENT_PRESENT) && (P.agentFlags & SGE_AGENT_RADIUS_OVERRIDE)) ? P.agentRadiusOverride : P.radius;
-        // applyPlatformDelta: no kinematic platforms -> PlatformCarry.computeDelta returns .zero (:651)
+        // applyPlatformDelta :1619-1633
+        {
+            V3 platformDelta = platformCarryDelta(position, P, w.platforms);
+            if (length_squared(platformDelta) > 1e-8f) position += platformDelta;
+        }
         bool wasGrounded = (C.flags & SGE_CTRL_GROUNDED) != 0;
         bool wasGroundedNear = (C.flags & SGE_CTRL_GROUNDED_NEAR) != 0;
         // VelocityGate.apply :1037-1051

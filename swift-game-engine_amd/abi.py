@@ -11,6 +11,8 @@ import numpy as np
 
 SGE_OK = 0
 SGE_MAX_COEFFS = 17
+SGE_MAX_PLATFORMS = 64
+SET_STATIC, SET_DYNAMIC = 0, 1
 SGE_AXIS_ABSENT = 255
 SGE_MAX_OVERLAP_HITS = 8
 SGE_MANIFOLD_MAX = 4
@@ -133,6 +135,20 @@ class CapsuleOverlapHit(C.Structure):
                 ("triangleIndex", i32), ("material", SurfaceMaterial)]
 
 
+class RayQuery(C.Structure):
+    _fields_ = [("origin", f32 * 3), ("direction", f32 * 3), ("maxDistance", f32), ("mask", u32)]
+
+
+class RaycastHit(C.Structure):
+    _fields_ = [("hit", i32), ("distance", f32), ("position", f32 * 3), ("normal", f32 * 3), ("triangleIndex", i32),
+                ("material", SurfaceMaterial)]
+
+
+class PlatformState(C.Structure):
+    _fields_ = [("aabbMin", f32 * 3), ("aabbMax", f32 * 3), ("delta", f32 * 3), ("kinematic", u32), ("hasAABB", u32),
+                ("_pad", u32)]
+
+
 class TickDesc(C.Structure):
     _fields_ = [("dt", f32), ("gravity", f32 * 3), ("stages", u32), ("first", i32), ("count", i32), ("_pad", u32)]
 
@@ -154,7 +170,8 @@ class MoveStats(C.Structure):
 # sizes the C side static_asserts as well
 EXPECTED_SIZES = {BodyState: 96, ControllerParams: 64, ControllerState: 128, MoveIntent: 32,
                   LocomotionState: 96, ActionState: 32, AgentState: 32, CapsuleQuery: 44,
-                  CapsuleCastHit: 60, CapsuleOverlapHit: 56, BVHNode: 44, TickDesc: 32}
+                  CapsuleCastHit: 60, CapsuleOverlapHit: 56, BVHNode: 44, TickDesc: 32, RayQuery: 32, RaycastHit: 48,
+                  PlatformState: 48}
 for _cls, _sz in EXPECTED_SIZES.items():
     assert C.sizeof(_cls) == _sz, (_cls.__name__, C.sizeof(_cls), _sz)
 
@@ -187,6 +204,11 @@ query_dtype = np.dtype([("origin", "<f4", 3), ("delta", "<f4", 3), ("radius", "<
 material_dtype = np.dtype([("muS", "<f4"), ("muK", "<f4"), ("flattenGround", "<u4")])
 cast_hit_dtype = np.dtype([("hit", "<i4"), ("toi", "<f4"), ("position", "<f4", 3), ("normal", "<f4", 3),
                            ("triangleNormal", "<f4", 3), ("triangleIndex", "<i4"), ("material", material_dtype)])
+ray_query_dtype = np.dtype([("origin", "<f4", 3), ("direction", "<f4", 3), ("maxDistance", "<f4"), ("mask", "<u4")])
+raycast_hit_dtype = np.dtype([("hit", "<i4"), ("distance", "<f4"), ("position", "<f4", 3), ("normal", "<f4", 3),
+                              ("triangleIndex", "<i4"), ("material", material_dtype)])
+platform_dtype = np.dtype([("aabbMin", "<f4", 3), ("aabbMax", "<f4", 3), ("delta", "<f4", 3), ("kinematic", "<u4"),
+                           ("hasAABB", "<u4"), ("_pad", "<u4")])
 overlap_hit_dtype = np.dtype([("depth", "<f4"), ("position", "<f4", 3), ("normal", "<f4", 3),
                               ("triangleNormal", "<f4", 3), ("triangleIndex", "<i4"), ("material", material_dtype)])
 bvh_node_dtype = np.dtype([("boundsMin", "<f4", 3), ("boundsMax", "<f4", 3), ("left", "<i4"), ("right", "<i4"),
@@ -194,7 +216,8 @@ bvh_node_dtype = np.dtype([("boundsMin", "<f4", 3), ("boundsMax", "<f4", 3), ("l
 for _dt, _cls in ((body_dtype, BodyState), (params_dtype, ControllerParams), (controller_dtype, ControllerState),
                   (intent_dtype, MoveIntent), (locomotion_dtype, LocomotionState), (action_dtype, ActionState),
                   (agent_dtype, AgentState), (query_dtype, CapsuleQuery), (cast_hit_dtype, CapsuleCastHit),
-                  (overlap_hit_dtype, CapsuleOverlapHit), (bvh_node_dtype, BVHNode)):
+                  (overlap_hit_dtype, CapsuleOverlapHit), (bvh_node_dtype, BVHNode), (ray_query_dtype, RayQuery),
+                  (raycast_hit_dtype, RaycastHit), (platform_dtype, PlatformState)):
     assert _dt.itemsize == C.sizeof(_cls), (_cls.__name__, _dt.itemsize)
 
 # Every symbol include/sge_amd.h declares: name -> (restype, argtypes)
@@ -216,8 +239,15 @@ PROTOTYPES = {
     "sge_crowd_buffers": (C.c_int, [VP, P(VP), P(VP), P(VP), P(VP)]),
     "sge_skinned_mesh_buffers": (C.c_int, [VP, P(VP), P(VP), P(VP), P(VP), P(VP)]),
     "sge_collision_rebuild_static": (C.c_int, [VP, P(StaticMeshEntity), i32]),
+    "sge_collision_rebuild_dynamic": (C.c_int, [VP, P(StaticMeshEntity), i32]),
+    "sge_collision_update_transforms": (C.c_int, [VP, i32, VP, VP, i32]),
     "sge_collision_counts": (C.c_int, [VP, P(i32), P(i32), P(i32)]),
     "sge_collision_copy": (C.c_int, [VP, VP, VP, VP, VP, VP, VP]),
+    "sge_collision_counts_set": (C.c_int, [VP, i32, P(i32), P(i32), P(i32)]),
+    "sge_collision_copy_set": (C.c_int, [VP, i32, VP, VP, VP, VP, VP, VP]),
+    "sge_raycast_batch": (C.c_int, [VP, VP, i32, VP]),
+    "sge_mesh_world_aabb": (C.c_int, [VP, i32, VP, VP, VP]),
+    "sge_platforms_upload": (C.c_int, [VP, VP, i32]),
     "sge_capsule_cast_batch": (C.c_int, [VP, VP, i32, VP]),
     "sge_capsule_overlap_all_batch": (C.c_int, [VP, VP, i32, i32, VP, VP]),
     "sge_capsule_overlap_batch": (C.c_int, [VP, VP, i32, VP, VP]),

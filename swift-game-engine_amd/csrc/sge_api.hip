@@ -65,9 +65,10 @@ struct sge_context {
     DevMesh mesh{};
     DevBuf dMeshPos, dMeshNrm, dMeshTan, dMeshIdx, dMeshWgt;
     // collision
-    HostCollision hostCol;
+    HostCollision hostCol, hostDyn; // StaticTriMesh.staticSet / dynamicSet (CollisionQuery.swift:710-711)
     DevCollision col{};
-    DevBuf dNodes, dWide, dTris, dMaterials;
+    DevBuf dWide, dTris, dMaterials, dBinNodes[2], dPlatforms, dRayQueries, dRayOut;
+    int platformCount = 0;
     // crowd
     DevCrowd crowd{};
     DevBuf dBodies, dParams, dCtrl, dIntents, dLoco, dActions, dPalettes, dPoseModel, dPoseLocal, dMoveScratch;
@@ -287,7 +288,7 @@ void sge_context_destroy(sge_context* c) {
     drainEvents(c->evMove); drainEvents(c->evPose); drainEvents(c->evSkin); drainEvents(c->evAgents);
     DevBuf* bufs[] = {&c->dParent, &c->dDepth, &c->dLeanChain, &c->dBindLocal, &c->dInvBind, &c->dRestT, &c->dRawRestT, &c->dPreRot,
                       &c->dCoeffs, &c->dCoeffCount, &c->dBonePresent, &c->dMeshPos, &c->dMeshNrm, &c->dMeshTan, &c->dMeshIdx, &c->dMeshWgt,
-                      &c->dNodes, &c->dWide, &c->dTris, &c->dMaterials, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
+                      &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
                       &c->dPalettes, &c->dPoseModel, &c->dPoseLocal, &c->dMoveScratch, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
                       &c->dCellCursor, &c->dAgentMinMax, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats};
     for (DevBuf* b : bufs) b->release();
@@ -503,58 +504,194 @@ int sge_skinning_encode(sge_context* c, void* d_outPositions, void* d_outNormals
 }
 
 // ---- collision world ---------------------------------------------------------------
-int sge_collision_rebuild_static(sge_context* c, const sge_static_mesh_entity* ents, int32_t count) {
-    if (c) { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; }
-    if (!c || count < 0 || (count > 0 && !ents)) { set_error("sge_collision_rebuild_static: bad argument"); return SGE_ERR_INVALID; }
-    for (int e = 0; e < count; ++e) {
-        if (!ents[e].positions || !ents[e].indices || ents[e].vertexCount < 0 || ents[e].indexCount < 0) { set_error("bad entity"); return SGE_ERR_INVALID; }
-        for (int i = 0; i < ents[e].indexCount; ++i)
-            if (ents[e].indices[i] >= (uint32_t)ents[e].vertexCount) { set_error("index out of range"); return SGE_ERR_INVALID; }
-    }
-    HostCollision& hc = c->hostCol;
-    hc.rebuild(ents, count);
+namespace {
+
+// Device form of one set at its place in the merged arrays: triangles in slot order with the reference's
+// (offset) triangle index and visit rank, wide nodes with child / range references rebased.
+void deviceArrays(const HostCollision& hc, int triOffset, int wideOffset, std::vector<DevTri>& tris, std::vector<DevNode>& wide,
+                  std::vector<DevMaterial>* mats) {
     const int T = (int)hc.layers.size();
-    if (hc.maxDepth > 120) { set_error("BVH deeper than the traversal stack policy allows"); return SGE_ERR_CAPACITY; }
-    std::vector<DevNode> nodes(hc.nodes.size());
+    tris.resize(T);
+    for (int slot = 0; slot < T; ++slot) {
+        int t = hc.triOrder[slot];
+        const uint32_t* ix = &hc.indices[(size_t)t * 3];
+        const float *p0 = &hc.positions[(size_t)ix[0] * 3], *p1 = &hc.positions[(size_t)ix[1] * 3], *p2 = &hc.positions[(size_t)ix[2] * 3];
+        tris[slot] = DevTri{p0[0], p0[1], p0[2], p1[0], p1[1], p1[2], p2[0], p2[1], p2[2], hc.layers[t], triOffset + t, triOffset + hc.rank[t]};
+    }
+    wide = hc.wide;
+    for (size_t i = 0; i < wide.size(); ++i) {
+        if (hc.wideBinary[i] < 0) continue;
+        if (wide[i].b > 0) wide[i].a = ~((~wide[i].a) + triOffset); // triangle range: first slot
+        else wide[i].a += wideOffset;                                // child wide node
+    }
+    if (mats) {
+        mats->resize(T);
+        for (int t = 0; t < T; ++t) (*mats)[t] = DevMaterial{hc.materials[t].muS, hc.materials[t].muK, hc.materials[t].flattenGround};
+    }
+}
+
+void binaryNodes(const HostCollision& hc, std::vector<DevNode>& nodes) {
+    nodes.resize(hc.nodes.size());
     for (size_t i = 0; i < hc.nodes.size(); ++i) {
         const HostBVHNode& n = hc.nodes[i];
         DevNode d{n.mn[0], n.mn[1], n.mn[2], n.mx[0], n.mx[1], n.mx[2], 0, 0};
         if (n.left < 0) { d.a = ~n.start; d.b = n.count; } else { d.a = n.left; d.b = n.right; }
         nodes[i] = d;
     }
-    std::vector<DevTri> tris(T);
-    std::vector<DevMaterial> mats(T);
-    for (int slot = 0; slot < T; ++slot) {
-        int t = hc.triOrder[slot];
-        const uint32_t* ix = &hc.indices[(size_t)t * 3];
-        const float *p0 = &hc.positions[ix[0] * 3], *p1 = &hc.positions[ix[1] * 3], *p2 = &hc.positions[ix[2] * 3];
-        tris[slot] = DevTri{p0[0], p0[1], p0[2], p1[0], p1[1], p1[2], p2[0], p2[1], p2[2], hc.layers[t], t, hc.rank[t]};
-    }
-    for (int t = 0; t < T; ++t) mats[t] = DevMaterial{hc.materials[t].muS, hc.materials[t].muK, hc.materials[t].flattenGround};
+}
+
+struct MergedLayout { int Ts, Td, Ws, Wd; };
+MergedLayout mergedLayout(const sge_context* c) {
+    return MergedLayout{(int)c->hostCol.layers.size(), (int)c->hostDyn.layers.size(),
+                        (int)(c->hostCol.wide.size() / kWideWidth), (int)(c->hostDyn.wide.size() / kWideWidth)};
+}
+
+// (Re)allocates the merged device world and uploads both sets.
+int uploadCollisionAll(sge_context* c) {
+    const MergedLayout L = mergedLayout(c);
+    if (c->hostCol.maxDepth > 120 || c->hostDyn.maxDepth > 120) { set_error("BVH deeper than the traversal stack policy allows"); return SGE_ERR_CAPACITY; }
+    std::vector<DevTri> ts, td;
+    std::vector<DevNode> ws, wd;
+    std::vector<DevMaterial> ms, md;
+    deviceArrays(c->hostCol, 0, 0, ts, ws, &ms);
+    deviceArrays(c->hostDyn, L.Ts, L.Ws, td, wd, &md);
+    ts.insert(ts.end(), td.begin(), td.end());
+    ws.insert(ws.end(), wd.begin(), wd.end());
+    ms.insert(ms.end(), md.begin(), md.end());
     (void)hipSetDevice(c->device);
     int rc;
-    if ((rc = upload(c->dNodes, nodes.data(), nodes.size() * sizeof(DevNode), c->stream)) != SGE_OK) return rc;
-    if ((rc = upload(c->dWide, hc.wide.data(), hc.wide.size() * sizeof(DevNode), c->stream)) != SGE_OK) return rc;
-    if ((rc = upload(c->dTris, tris.data(), tris.size() * sizeof(DevTri), c->stream)) != SGE_OK) return rc;
-    if ((rc = upload(c->dMaterials, mats.data(), mats.size() * sizeof(DevMaterial), c->stream)) != SGE_OK) return rc;
+    if ((rc = upload(c->dWide, ws.data(), ws.size() * sizeof(DevNode), c->stream)) != SGE_OK) return rc;
+    if ((rc = upload(c->dTris, ts.data(), ts.size() * sizeof(DevTri), c->stream)) != SGE_OK) return rc;
+    if ((rc = upload(c->dMaterials, ms.data(), ms.size() * sizeof(DevMaterial), c->stream)) != SGE_OK) return rc;
+    std::vector<DevNode> bs, bd;
+    binaryNodes(c->hostCol, bs);
+    binaryNodes(c->hostDyn, bd);
+    if ((rc = upload(c->dBinNodes[0], bs.data(), bs.size() * sizeof(DevNode), c->stream)) != SGE_OK) return rc;
+    if ((rc = upload(c->dBinNodes[1], bd.data(), bd.size() * sizeof(DevNode), c->stream)) != SGE_OK) return rc;
     SGE_HIP(hipStreamSynchronize(c->stream));
-    c->col = DevCollision{(int)nodes.size(), T, hc.root, c->dWide.as<DevNode>(), (int)(hc.wide.size() / kWideWidth),
-                          c->dNodes.as<DevNode>(), c->dTris.as<DevTri>(), c->dMaterials.as<DevMaterial>()};
+    const int T = L.Ts + L.Td;
+    c->col = DevCollision{(int)(c->hostCol.nodes.size() + c->hostDyn.nodes.size()), T, T > 0 ? 0 : -1, c->dWide.as<DevNode>(), L.Ws + L.Wd,
+                          (L.Ts > 0 && L.Td > 0) ? L.Ws : -1, c->dTris.as<DevTri>(), c->dMaterials.as<DevMaterial>(),
+                          {c->dBinNodes[0].as<DevNode>(), c->dBinNodes[1].as<DevNode>()}, {c->hostCol.root, c->hostDyn.root}, {0, L.Ts}};
     return SGE_OK;
 }
 
-int sge_collision_counts(sge_context* c, int32_t* v, int32_t* t, int32_t* n) {
-    if (!c) return SGE_ERR_INVALID;
-    if (v) *v = (int32_t)(c->hostCol.positions.size() / 3);
-    if (t) *t = (int32_t)c->hostCol.layers.size();
-    if (n) *n = (int32_t)c->hostCol.nodes.size();
+// After updateTransforms: topology and sizes are unchanged, only this set's triangles and wide bounds are rewritten.
+int uploadCollisionSet(sge_context* c, int set) {
+    const MergedLayout L = mergedLayout(c);
+    const HostCollision& hc = set == SGE_SET_STATIC ? c->hostCol : c->hostDyn;
+    const int triOffset = set == SGE_SET_STATIC ? 0 : L.Ts, wideOffset = set == SGE_SET_STATIC ? 0 : L.Ws;
+    std::vector<DevTri> ts;
+    std::vector<DevNode> ws;
+    deviceArrays(hc, triOffset, wideOffset, ts, ws, nullptr);
+    (void)hipSetDevice(c->device);
+    if (!ts.empty()) SGE_HIP(hipMemcpyAsync(c->dTris.as<DevTri>() + triOffset, ts.data(), ts.size() * sizeof(DevTri), hipMemcpyHostToDevice, c->stream));
+    if (!ws.empty()) SGE_HIP(hipMemcpyAsync(c->dWide.as<DevNode>() + (size_t)wideOffset * kWideWidth, ws.data(), ws.size() * sizeof(DevNode), hipMemcpyHostToDevice, c->stream));
+    std::vector<DevNode> bn;
+    binaryNodes(hc, bn);
+    if (!bn.empty()) SGE_HIP(hipMemcpyAsync(c->dBinNodes[set].p, bn.data(), bn.size() * sizeof(DevNode), hipMemcpyHostToDevice, c->stream));
+    SGE_HIP(hipStreamSynchronize(c->stream));
     return SGE_OK;
 }
+
+int checkEntities(const sge_static_mesh_entity* ents, int32_t count) {
+    for (int e = 0; e < count; ++e) {
+        if (!ents[e].positions || !ents[e].indices || ents[e].vertexCount < 0 || ents[e].indexCount < 0) { set_error("bad entity"); return SGE_ERR_INVALID; }
+        for (int i = 0; i < ents[e].indexCount; ++i)
+            if (ents[e].indices[i] >= (uint32_t)ents[e].vertexCount) { set_error("index out of range"); return SGE_ERR_INVALID; }
+    }
+    return SGE_OK;
+}
+
+} // namespace
+
+int sge_collision_rebuild_static(sge_context* c, const sge_static_mesh_entity* ents, int32_t count) {
+    if (c) { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; }
+    if (!c || count < 0 || (count > 0 && !ents)) { set_error("sge_collision_rebuild_static: bad argument"); return SGE_ERR_INVALID; }
+    int rc = checkEntities(ents, count);
+    if (rc != SGE_OK) return rc;
+    c->hostCol.rebuild(ents, count);
+    return uploadCollisionAll(c);
+}
+
+int sge_collision_rebuild_dynamic(sge_context* c, const sge_static_mesh_entity* ents, int32_t count) {
+    if (c) { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; }
+    if (!c || count < 0 || (count > 0 && !ents)) { set_error("sge_collision_rebuild_dynamic: bad argument"); return SGE_ERR_INVALID; }
+    int rc = checkEntities(ents, count);
+    if (rc != SGE_OK) return rc;
+    c->hostDyn.rebuild(ents, count);
+    return uploadCollisionAll(c);
+}
+
+int sge_collision_update_transforms(sge_context* c, int32_t set, const int32_t* entities, const float* matrices, int32_t n) {
+    if (!c || (set != SGE_SET_STATIC && set != SGE_SET_DYNAMIC) || n < 0 || (n > 0 && (!entities || !matrices))) {
+        set_error("sge_collision_update_transforms: bad argument");
+        return SGE_ERR_INVALID;
+    }
+    { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; } // queries in flight read the arrays about to change
+    HostCollision& hc = set == SGE_SET_STATIC ? c->hostCol : c->hostDyn;
+    if (hc.updateTransforms(entities, matrices, n) == 0) return SGE_OK;
+    return uploadCollisionSet(c, set);
+}
+
+int sge_mesh_world_aabb(const float* positions, int32_t count, const float* M, float* outMin, float* outMax) {
+    if (!positions || count <= 0 || !M || !outMin || !outMax) { set_error("sge_mesh_world_aabb: empty mesh"); return SGE_ERR_INVALID; }
+    float mn[3] = {kFloatMax, kFloatMax, kFloatMax}, mx[3] = {-kFloatMax, -kFloatMax, -kFloatMax};
+    for (int i = 0; i < count; ++i) {
+        const float x = positions[i * 3], y = positions[i * 3 + 1], z = positions[i * 3 + 2];
+        for (int r = 0; r < 3; ++r) { // simd_mul(modelMatrix, (p,1)).xyz, then simd_min / simd_max
+            float w = ((M[r] * x + M[4 + r] * y) + M[8 + r] * z) + M[12 + r] * 1.0f;
+            mn[r] = fminf(mn[r], w); mx[r] = fmaxf(mx[r], w);
+        }
+    }
+    for (int r = 0; r < 3; ++r) { outMin[r] = mn[r]; outMax[r] = mx[r]; }
+    return SGE_OK;
+}
+
+int sge_platforms_upload(sge_context* c, const sge_platform_state* p, int32_t count) {
+    if (!c || count < 0 || count > SGE_MAX_PLATFORMS || (count > 0 && !p)) { set_error("sge_platforms_upload: bad argument (at most SGE_MAX_PLATFORMS)"); return SGE_ERR_INVALID; }
+    { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; }
+    (void)hipSetDevice(c->device);
+    int rc;
+    if ((rc = upload(c->dPlatforms, p, (size_t)count * sizeof(*p), c->stream)) != SGE_OK) return rc;
+    SGE_HIP(hipStreamSynchronize(c->stream));
+    c->platformCount = count;
+    return SGE_OK;
+}
+
+int sge_raycast_batch(sge_context* c, const sge_ray_query* q, int32_t count, sge_raycast_hit* out) {
+    if (!c || count < 0 || (count > 0 && (!q || !out))) { set_error("sge_raycast_batch: bad argument"); return SGE_ERR_INVALID; }
+    if (count == 0) return SGE_OK;
+    (void)hipSetDevice(c->device);
+    int rc;
+    if ((rc = upload(c->dRayQueries, q, (size_t)count * sizeof(*q), c->stream)) != SGE_OK) return rc;
+    if ((rc = c->dRayOut.alloc((size_t)count * sizeof(*out))) != SGE_OK) return rc;
+    launch_raycast_queries(c->col, c->dRayQueries.as<sge_ray_query>(), count, c->dRayOut.as<sge_raycast_hit>(), c->stream);
+    SGE_HIP(hipGetLastError());
+    SGE_HIP(hipMemcpyAsync(out, c->dRayOut.p, (size_t)count * sizeof(*out), hipMemcpyDeviceToHost, c->stream));
+    SGE_HIP(hipStreamSynchronize(c->stream));
+    return SGE_OK;
+}
+
+int sge_collision_counts_set(sge_context* c, int32_t set, int32_t* v, int32_t* t, int32_t* n) {
+    if (!c || (set != SGE_SET_STATIC && set != SGE_SET_DYNAMIC)) return SGE_ERR_INVALID;
+    const HostCollision& hc = set == SGE_SET_STATIC ? c->hostCol : c->hostDyn;
+    if (v) *v = (int32_t)(hc.positions.size() / 3);
+    if (t) *t = (int32_t)hc.layers.size();
+    if (n) *n = (int32_t)hc.nodes.size();
+    return SGE_OK;
+}
+int sge_collision_counts(sge_context* c, int32_t* v, int32_t* t, int32_t* n) { return sge_collision_counts_set(c, SGE_SET_STATIC, v, t, n); }
 
 int sge_collision_copy(sge_context* c, float* positions, uint32_t* indices, float* aabbs, sge_bvh_node* nodes,
                        int32_t* triOrder, int32_t* triLeaf) {
-    if (!c) return SGE_ERR_INVALID;
-    const HostCollision& hc = c->hostCol;
+    return sge_collision_copy_set(c, SGE_SET_STATIC, positions, indices, aabbs, nodes, triOrder, triLeaf);
+}
+
+int sge_collision_copy_set(sge_context* c, int32_t set, float* positions, uint32_t* indices, float* aabbs, sge_bvh_node* nodes,
+                           int32_t* triOrder, int32_t* triLeaf) {
+    if (!c || (set != SGE_SET_STATIC && set != SGE_SET_DYNAMIC)) return SGE_ERR_INVALID;
+    const HostCollision& hc = set == SGE_SET_STATIC ? c->hostCol : c->hostDyn;
     if (positions) std::memcpy(positions, hc.positions.data(), hc.positions.size() * 4);
     if (indices) std::memcpy(indices, hc.indices.data(), hc.indices.size() * 4);
     if (aabbs) std::memcpy(aabbs, hc.aabbs.data(), hc.aabbs.size() * 4);
@@ -741,7 +878,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
             if (rc != SGE_OK) return rc;
         }
         MoveLaunch L{c->crowd, c->col, c->agents, d->dt, d->gravity[0], d->gravity[1], d->gravity[2], st, first, count,
-                     c->dStats.as<unsigned long long>(), c->dMoveScratch.p};
+                     c->dStats.as<unsigned long long>(), c->dMoveScratch.p, c->dPlatforms.as<sge_platform_state>(), c->platformCount};
         if (!(st & SGE_STAGE_AGENTS) || c->agents.nx == 0) L.agents.all = nullptr;
         Bracket br(c, &c->evMove);
         launch_move(L, c->stream);

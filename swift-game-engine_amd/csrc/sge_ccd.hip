@@ -40,6 +40,7 @@ constexpr int kCandCap = 512;
 constexpr int kRangeCap = 128;
 constexpr int kItemCap = 512;
 constexpr int kMaxRays = 4;
+constexpr int kRefillIdle = 16;  // idle lanes that trigger a queue top-up while others still march
 
 struct OverlapRec { float depth; F3 position, normal, triNormal; int triIndex, rank; };
 struct CastRec { float toi; F3 position, normal, triNormal; int triIndex; };
@@ -48,7 +49,6 @@ struct WaveShared {
     int stack[kStackCap];
     int cand[kCandCap];
     int ranges[kRangeCap];   // pending (firstSlot << 7 | count) triangle ranges of the wide BVH
-    CastRec laneCast[kWave]; // each lane's accepted hit of the current batch
     int items[kItemCap];     // (ray << 28) | slot work items of a multi-ray cast
     // up to kMaxRays casts that share radius/halfHeight/filters run as ONE traversal + shared sweep batches
     int rayCount;
@@ -271,6 +271,12 @@ __device__ __forceinline__ void expandNodes(const DevCollision& col, F3 minP, F3
     __syncthreads();
 }
 
+// Start a traversal over both triangle sets: the static root, and the dynamic set's root when both exist.
+__device__ __forceinline__ int initTraversal(const DevCollision& col) {
+    if (laneId() == 0) { sh.stack[0] = 0; sh.stack[1] = col.dynWide; }
+    return col.dynWide >= 0 ? 2 : 1;
+}
+
 struct Tri { F3 v0, v1, v2; int triIndex, rank; };
 __device__ __forceinline__ Tri loadTri(const DevCollision& col, int slot) {
     const float4* tp = reinterpret_cast<const float4*>(col.tris + slot);
@@ -330,17 +336,30 @@ __device__ __forceinline__ void waveCastRays(const DevCollision& col, float radi
     const float minAdvance = smax(radius * 0.02f, 1e-4f); // :1295
     const float contactEps = 1e-5f;
     long long cycTrav = 0, cycSweep = 0; (void)cycTrav; (void)cycSweep;
-    int stackSize = 1, rangeCount = 0, candCount = 0, itemCount = 0;
-    if (lane == 0) sh.stack[0] = 0;
+    int stackSize = initTraversal(col), rangeCount = 0, candCount = 0, itemCount = 0;
     __syncthreads();
 
+    // Streaming sweep: every lane owns one (ray, triangle) work item at a time and pulls the next one from the
+    // LDS queue the moment its own finishes, so a query with hundreds of candidates keeps all 64 lanes marching
+    // instead of waiting, batch after batch, for each batch's slowest lane (conservative advancement runs up to
+    // 256 dependent iterations per triangle). The result does not depend on the processing order: the winner is
+    // the minimum (toi, visit rank) key.
+    int phase = PH_DONE;
+    int myRay = 0;
+    Tri tri;
+    tri.v0 = tri.v1 = tri.v2 = F3{0, 0, 0}; tri.triIndex = -1; tri.rank = 0x7fffffff;
+    F3 triNormal{0, 0, 0};
+    float t = 0, lastSafeT = 0, lo = 0, hi = 0, tEval = 0, len = 0, bestToi = 0;
+    int iter = 0, refineK = 0, maxIter = 0;
     while (true) {
-        // 1. traverse until a batch of candidates is ready
-        { SGE_T0();
-        while ((stackSize > 0 || rangeCount > 0) && candCount < kWave) expandNodes(col, minP, maxP, mask, stackSize, rangeCount, candCount, st);
-        SGE_T1(cycTrav); }
-        // 2. turn up to 64 candidates into (ray, slot) work items
-        if (candCount > 0 && itemCount <= kItemCap - kWave * kMaxRays) {
+        const unsigned long long idleMask = __ballot(phase == PH_DONE);
+        const int nIdle = __popcll(idleMask);
+        const bool moreCandidates = stackSize > 0 || rangeCount > 0 || candCount > 0;
+        // 1. top the queue up when idle lanes cannot be fed from it: traverse to a batch of candidates and turn
+        //    them into (ray, slot) items
+        if (itemCount < nIdle && moreCandidates && (nIdle >= kRefillIdle || nIdle == kWave)) {
+            SGE_T0();
+            while ((stackSize > 0 || rangeCount > 0) && candCount < kWave) expandNodes(col, minP, maxP, mask, stackSize, rangeCount, candCount, st);
             int n = candCount < kWave ? candCount : kWave;
             candCount -= n;
             st.candidates += n;
@@ -360,101 +379,100 @@ __device__ __forceinline__ void waveCastRays(const DevCollision& col, float radi
                 itemCount += __popcll(mc);
             }
             __syncthreads();
+            SGE_T1(cycTrav);
+            continue;
         }
-        if (itemCount == 0) { if (candCount == 0 && stackSize == 0 && rangeCount == 0) break; else continue; }
-        if (itemCount < kWave && (candCount > 0 || stackSize > 0 || rangeCount > 0) && itemCount <= kItemCap - kWave * kMaxRays) continue; // fill the batch
-        // 3. sweep one batch of work items
-        int n = itemCount < kWave ? itemCount : kWave;
-        itemCount -= n;
-        const bool active = lane < n;
-        int myRay = 0;
-        Tri tri;
-        tri.v0 = tri.v1 = tri.v2 = F3{0, 0, 0}; tri.triIndex = -1; tri.rank = 0x7fffffff;
-        if (active) {
-            int it = sh.items[itemCount + lane];
-            myRay = (unsigned)it >> 28;
-            tri = loadTri(col, it & 0x0fffffff);
-        }
-        const F3 from = sh.rayFrom[myRay], dir = sh.rayDir[myRay];
-        const float len = sh.rayLen[myRay];
-        const int maxIter = sh.rayMaxIter[myRay];
-        float bestToi = __uint_as_float((unsigned)(sh.rayKey[myRay] >> 32));
-        F3 triNormal = normalize(cross(tri.v1 - tri.v0, tri.v2 - tri.v0));
-
-        int phase = active ? PH_MARCH : PH_DONE;
-        float t = 0, lastSafeT = 0, lo = 0, hi = 0, tEval = 0;
-        int iter = 0, refineK = 0;
-        unsigned long long myKey = ~0ull;
-        SGE_T0();
-        while (__any(phase != PH_DONE)) {
-            st.trips += 1;
-            if (phase == PH_MARCH) {
-                // loop head of :1303-1307 — iteration budget, then `if t > maxDistance return nil`
-                if (iter >= maxIter || t > len || lastSafeT > bestToi) phase = PH_DONE;
-                else { iter += 1; tEval = t; }
-            } else if (phase == PH_REFINE) {
-                if (lo > bestToi) phase = PH_DONE;
-                else tEval = 0.5f * (lo + hi);
+        // 2. idle lanes take the newest items
+        if (nIdle > 0 && itemCount > 0) {
+            const int take = nIdle < itemCount ? nIdle : itemCount;
+            const int p = prefixCount(idleMask);
+            if (phase == PH_DONE && p < take) {
+                const int it = sh.items[itemCount - 1 - p];
+                myRay = (unsigned)it >> 28;
+                tri = loadTri(col, it & 0x0fffffff);
+                triNormal = normalize(cross(tri.v1 - tri.v0, tri.v2 - tri.v0));
+                len = sh.rayLen[myRay];
+                maxIter = sh.rayMaxIter[myRay];
+                bestToi = __uint_as_float((unsigned)(sh.rayKey[myRay] >> 32));
+                phase = PH_MARCH;
+                t = 0; lastSafeT = 0; lo = 0; hi = 0; tEval = 0; iter = 0; refineK = 0;
             }
-            bool finished = false;
-            if (phase != PH_DONE) {
-                st.evals += 1;
-                F3 center = from + dir * tEval;
-                F3 segP, triP;
-                float dist = segmentTriangleDistance(center, halfHeight, tri.v0, tri.v1, tri.v2, segP, triP);
-                if (phase == PH_MARCH) {
-                    if (dist <= radius + contactEps) {
-                        // refineTOI(t0: lastSafeT, t1: t) :1361-1377
-                        float c0 = smax(0.0f, smin(lastSafeT, len));
-                        float c1 = smax(0.0f, smin(t, len));
-                        lo = smin(c0, c1);
-                        hi = smax(c0, c1);
-                        if (hi - lo < 1e-5f) { phase = PH_FINAL; tEval = hi; }
-                        else { phase = PH_REFINE; refineK = 0; }
-                    } else {
-                        lastSafeT = t;
-                        float advance = smax(dist - radius, minAdvance);
-                        if (advance <= 0) t += minAdvance; else t += advance;
-                    }
-                } else if (phase == PH_REFINE) {
-                    if (dist <= radius) hi = tEval; else lo = tEval;
-                    refineK += 1;
-                    if (refineK == 10) { phase = PH_FINAL; tEval = hi; }
-                } else { // PH_FINAL :1325-1346
-                    float tHit = tEval;
-                    F3 nrm;
-                    if (dist < 1e-6f) nrm = dot(triNormal, dir) > 0 ? -triNormal : triNormal;
-                    else nrm = normalize(segP - triP);
-                    F3 triN = triNormal;
-                    if (dot(triN, nrm) < 0) triN = -triN;
-                    phase = PH_DONE;
-                    // acceptance filters of capsuleCastBVH :1084-1097 (toi < len; blocking; minNormalY)
-                    bool ok = tHit < len;
-                    if (ok && blockingOnly) {
-                        F3 delta = sh.rayDelta[myRay];
-                        ok = !(dot(delta, nrm) >= 0) && !(dot(delta, triN) >= 0);
-                    }
-                    if (ok && hasMinNormalY) ok = !(triN.y < minNormalY);
-                    if (ok) {
-                        sh.laneCast[lane] = CastRec{tHit, triP, nrm, triN, tri.triIndex};
-                        myKey = ((unsigned long long)__float_as_uint(tHit) << 32) | (unsigned)tri.rank;
-                        atomicMin(&sh.rayKey[myRay], myKey);
-                        finished = true;
-                    }
+            itemCount -= take;
+            __syncthreads(); // the slots just read may be rewritten by the next top-up
+        } else if (nIdle == kWave) {
+            break; // nothing marching, nothing queued, nothing left to traverse
+        }
+        // 3. one trip: one distance evaluation per marching lane
+        st.trips += 1;
+        SGE_T0();
+        if (phase == PH_MARCH) {
+            // loop head of :1303-1307 — iteration budget, then `if t > maxDistance return nil`
+            if (iter >= maxIter || t > len || lastSafeT > bestToi) phase = PH_DONE;
+            else { iter += 1; tEval = t; }
+        } else if (phase == PH_REFINE) {
+            if (lo > bestToi) phase = PH_DONE;
+            else tEval = 0.5f * (lo + hi);
+        }
+        bool finished = false;
+        unsigned long long myKey = ~0ull;
+        CastRec rec;
+        rec.toi = 0; rec.position = rec.normal = rec.triNormal = F3{0, 0, 0}; rec.triIndex = -1;
+        if (phase != PH_DONE) {
+            st.evals += 1;
+            const F3 from = sh.rayFrom[myRay], dir = sh.rayDir[myRay];
+            F3 center = from + dir * tEval;
+            F3 segP, triP;
+            float dist = segmentTriangleDistance(center, halfHeight, tri.v0, tri.v1, tri.v2, segP, triP);
+            if (phase == PH_MARCH) {
+                if (dist <= radius + contactEps) {
+                    // refineTOI(t0: lastSafeT, t1: t) :1361-1377
+                    float c0 = smax(0.0f, smin(lastSafeT, len));
+                    float c1 = smax(0.0f, smin(t, len));
+                    lo = smin(c0, c1);
+                    hi = smax(c0, c1);
+                    if (hi - lo < 1e-5f) { phase = PH_FINAL; tEval = hi; }
+                    else { phase = PH_REFINE; refineK = 0; }
+                } else {
+                    lastSafeT = t;
+                    float advance = smax(dist - radius, minAdvance);
+                    if (advance <= 0) t += minAdvance; else t += advance;
+                }
+            } else if (phase == PH_REFINE) {
+                if (dist <= radius) hi = tEval; else lo = tEval;
+                refineK += 1;
+                if (refineK == 10) { phase = PH_FINAL; tEval = hi; }
+            } else { // PH_FINAL :1325-1346
+                float tHit = tEval;
+                F3 nrm;
+                if (dist < 1e-6f) nrm = dot(triNormal, dir) > 0 ? -triNormal : triNormal;
+                else nrm = normalize(segP - triP);
+                F3 triN = triNormal;
+                if (dot(triN, nrm) < 0) triN = -triN;
+                phase = PH_DONE;
+                // acceptance filters of capsuleCastBVH :1084-1097 (toi < len; blocking; minNormalY)
+                bool ok = tHit < len;
+                if (ok && blockingOnly) {
+                    F3 delta = sh.rayDelta[myRay];
+                    ok = !(dot(delta, nrm) >= 0) && !(dot(delta, triN) >= 0);
+                }
+                if (ok && hasMinNormalY) ok = !(triN.y < minNormalY);
+                if (ok) {
+                    rec = CastRec{tHit, triP, nrm, triN, tri.triIndex};
+                    myKey = ((unsigned long long)__float_as_uint(tHit) << 32) | (unsigned)tri.rank;
+                    atomicMin(&sh.rayKey[myRay], myKey);
+                    finished = true;
                 }
             }
-            // tighten every lane's prune bound as soon as any lane has published an accepted hit
-            if (__any(finished)) {
-                __syncthreads();
-                bestToi = __uint_as_float((unsigned)(sh.rayKey[myRay] >> 32));
-            }
+        }
+        // publish: the lane holding its ray's best key records the hit; every lane tightens its prune bound
+        if (__any(finished)) {
+            __syncthreads();
+            if (finished && sh.rayKey[myRay] == myKey) sh.rayRec[myRay] = rec;
+            bestToi = __uint_as_float((unsigned)(sh.rayKey[myRay] >> 32));
         }
         SGE_T1(cycSweep);
-        __syncthreads();
-        if (myKey != ~0ull && sh.rayKey[myRay] == myKey) sh.rayRec[myRay] = sh.laneCast[lane];
-        __syncthreads();
-        if (itemCount == 0 && candCount == 0 && stackSize == 0 && rangeCount == 0) break;
     }
+    __syncthreads();
 #ifdef SGE_CCD_TIMING
     if (lane == 0) { atomicAdd(&g_cycTraverse, (unsigned long long)cycTrav); atomicAdd(&g_cycSweep, (unsigned long long)cycSweep); }
 #endif
@@ -478,8 +496,7 @@ __device__ __forceinline__ int waveCapsuleOverlapAll(const DevCollision& col, F3
     F3 ext{radius, radius, radius};
     minP = minP - ext; maxP = maxP + ext;
     int count = 0; // entries in sh.ovl, sorted by rank
-    int stackSize = 1, rangeCount = 0, candCount = 0;
-    if (lane == 0) sh.stack[0] = 0;
+    int stackSize = initTraversal(col), rangeCount = 0, candCount = 0;
     __syncthreads();
     while (true) {
         while ((stackSize > 0 || rangeCount > 0) && candCount < kWave) expandNodes(col, minP, maxP, mask, stackSize, rangeCount, candCount, st);
@@ -751,6 +768,60 @@ __device__ __forceinline__ bool waveAgentBestHit(const DevAgents& ag, F3 positio
     toiOut = __uint_as_float((unsigned)(bestKey >> 32));
     normalOut = bestN;
     return true;
+}
+
+// PlatformCarry.computeDelta (Systems.swift:644-732) over the step's platform list; every lane computes the same value.
+__device__ __forceinline__ F3 platformCarryDelta(F3 position, const sge_controller_params& P, const sge_platform_state* platforms, int count) {
+    const float capsuleHalf = P.halfHeight + P.radius;
+    const float baseY = position.y - capsuleHalf;
+    const F3 capMin{position.x - P.radius, position.y - capsuleHalf, position.z - P.radius};
+    const F3 capMax{position.x + P.radius, position.y + capsuleHalf, position.z + P.radius};
+    const float sideTol = smax(P.skinWidth, P.groundSnapSkin);
+    F3 bestCarry{0, 0, 0}, pushDelta{0, 0, 0};
+    for (int k = 0; k < count; ++k) {
+        const sge_platform_state pf = platforms[k];
+        if (!pf.kinematic) continue;
+        const F3 pDelta{pf.delta[0], pf.delta[1], pf.delta[2]};
+        if (lengthSq(pDelta) < 1e-8f) continue;
+        if (!pf.hasAABB) continue;
+        const F3 amin{pf.aabbMin[0], pf.aabbMin[1], pf.aabbMin[2]}, amax{pf.aabbMax[0], pf.aabbMax[1], pf.aabbMax[2]};
+        const F3 tol{sideTol, sideTol, sideTol};
+        const F3 emin = amin - tol, emax = amax + tol;
+        const bool overlap = capMin.x <= emax.x && capMax.x >= emin.x && capMin.y <= emax.y && capMax.y >= emin.y &&
+                             capMin.z <= emax.z && capMax.z >= emin.z;
+        if (!overlap) continue;
+        const bool withinXZ = position.x >= amin.x - P.radius && position.x <= amax.x + P.radius &&
+                              position.z >= amin.z - P.radius && position.z <= amax.z + P.radius;
+        const float topY = amax.y;
+        const float topTol = P.snapDistance + smax(P.skinWidth, P.groundSnapSkin) + 0.05f;
+        const bool onTop = withinXZ && baseY >= topY - topTol && baseY <= topY + topTol;
+        if (onTop) {
+            if (lengthSq(pDelta) > lengthSq(bestCarry)) bestCarry = pDelta;
+        } else {
+            const float yMin = amin.y - capsuleHalf, yMax = amax.y + capsuleHalf;
+            if (position.y >= yMin && position.y <= yMax) {
+                const bool outsideX = position.x < amin.x - P.radius || position.x > amax.x + P.radius;
+                const bool outsideZ = position.z < amin.z - P.radius || position.z > amax.z + P.radius;
+                if (!outsideX && !outsideZ) continue;
+                const float cx = smax(amin.x, smin(position.x, amax.x));
+                const float cz = smax(amin.z, smin(position.z, amax.z));
+                const float dx = position.x - cx, dz = position.z - cz;
+                const float sideDistSq = dx * dx + dz * dz;
+                const float sidePushTol = P.radius + sideTol;
+                if (sideDistSq <= sidePushTol * sidePushTol) {
+                    const float dirLen = sqrtf(smax(sideDistSq, 0.0f));
+                    if (dirLen > 1e-5f) {
+                        const F3 dir{dx / dirLen, 0, dz / dirLen};
+                        const float moveToward = dot(F3{pDelta.x, 0, pDelta.z}, dir);
+                        if (moveToward > 0) pushDelta = pushDelta + F3{pDelta.x, 0, pDelta.z};
+                    }
+                }
+            }
+        }
+    }
+    if (lengthSq(bestCarry) > 1e-8f) return bestCarry;
+    if (lengthSq(pushDelta) > 1e-8f) return pushDelta;
+    return F3{0, 0, 0};
 }
 
 // ---------------------------------------------------------------------------
@@ -1251,6 +1322,10 @@ __global__ __launch_bounds__(kWave, PART == 0 ? 4 : SGE_MOVE_WAVES1) void move_k
     }
     if (PART == 0 && doMove) {
         cacheDecay(C);
+        if (K.platformCount > 0) { // applyPlatformDelta :1619-1633
+            F3 platformDelta = platformCarryDelta(ms.position, P, K.platforms, K.platformCount);
+            if (lengthSq(platformDelta) > 1e-8f) ms.position = ms.position + platformDelta;
+        }
         ms.wasGrounded = (C.flags & SGE_CTRL_GROUNDED) != 0;
         ms.wasGroundedNear = (C.flags & SGE_CTRL_GROUNDED_NEAR) != 0;
         // VelocityGate.apply :1037-1051
@@ -1459,8 +1534,7 @@ __global__ __launch_bounds__(kWave, 3) void overlap_deepest_kernel(DevCollision 
         F3 a0 = from + up * Q.halfHeight, b0 = from - up * Q.halfHeight;
         F3 ext{Q.radius, Q.radius, Q.radius};
         F3 minP = vmin(a0, b0) - ext, maxP = vmax(a0, b0) + ext;
-        int stackSize = 1, rangeCount = 0, candCount = 0;
-        if (lane == 0) sh.stack[0] = 0;
+        int stackSize = initTraversal(col), rangeCount = 0, candCount = 0;
         __syncthreads();
         while (true) {
             while ((stackSize > 0 || rangeCount > 0) && candCount < kWave) expandNodes(col, minP, maxP, Q.mask, stackSize, rangeCount, candCount, st);
@@ -1509,6 +1583,102 @@ __global__ __launch_bounds__(kWave, 3) void overlap_deepest_kernel(DevCollision 
         out[i] = h;
         if (stats && st.overflow) atomicAdd(&statShard(stats)[3], (unsigned long long)st.overflow);
     }
+}
+
+// ---------------------------------------------------------------------------
+// CollisionQuery.raycast (CollisionQuery.swift:768-785, 916-978, 1575-1631). Not on the tick path. Its result depends
+// on the order nodes are visited in (`range.0 > closestT` prunes with the running closest hit, and equal distances
+// keep the first found), so one thread follows the reference's own stack traversal of the binary BVH per ray.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool rayTriangle(F3 origin, F3 direction, F3 v0, F3 v1, F3 v2, float eps, float& tOut) { // :1575-1601
+    F3 e1 = v1 - v0, e2 = v2 - v0;
+    F3 pvec = cross(direction, e2);
+    float det = dot(e1, pvec);
+    if (fabsf(det) < eps) return false;
+    float invDet = 1.0f / det;
+    F3 tvec = origin - v0;
+    float u = dot(tvec, pvec) * invDet;
+    if (u < 0 || u > 1) return false;
+    F3 qvec = cross(tvec, e1);
+    float v = dot(direction, qvec) * invDet;
+    if (v < 0 || (u + v) > 1) return false;
+    float t = dot(e2, qvec) * invDet;
+    if (!(t >= 0)) return false;
+    tOut = t;
+    return true;
+}
+__device__ __forceinline__ bool rayAABB(F3 origin, F3 inv, const DevNode& n, float& tminOut) { // :1603-1630
+    float tmin = (n.mnx - origin.x) * inv.x, tmax = (n.mxx - origin.x) * inv.x;
+    if (tmin > tmax) { float w = tmin; tmin = tmax; tmax = w; }
+    float tymin = (n.mny - origin.y) * inv.y, tymax = (n.mxy - origin.y) * inv.y;
+    if (tymin > tymax) { float w = tymin; tymin = tymax; tymax = w; }
+    if (tmin > tymax || tymin > tmax) return false;
+    tmin = smax(tmin, tymin);
+    tmax = smin(tmax, tymax);
+    float tzmin = (n.mnz - origin.z) * inv.z, tzmax = (n.mxz - origin.z) * inv.z;
+    if (tzmin > tzmax) { float w = tzmin; tzmin = tzmax; tzmax = w; }
+    if (tmin > tzmax || tzmin > tmax) return false;
+    tminOut = smax(tmin, tzmin);
+    return true;
+}
+constexpr int kRayStack = 192; // binary BVH depth <= 120 (checked at build), + one sibling per level
+__global__ __launch_bounds__(kWave) void raycast_query_kernel(DevCollision col, const sge_ray_query* q, int n, sge_raycast_hit* out) {
+    const int i = blockIdx.x * kWave + threadIdx.x;
+    if (i >= n) return;
+    const sge_ray_query Q = q[i];
+    const F3 origin{Q.origin[0], Q.origin[1], Q.origin[2]}, direction{Q.direction[0], Q.direction[1], Q.direction[2]};
+    const F3 inv{direction.x != 0 ? 1.0f / direction.x : kFloatMax, direction.y != 0 ? 1.0f / direction.y : kFloatMax,
+                 direction.z != 0 ? 1.0f / direction.z : kFloatMax};
+    sge_raycast_hit best{};
+    best.triangleIndex = -1;
+    int stack[kRayStack];
+    for (int set = 0; set < 2; ++set) {
+        if (col.binRoot[set] < 0) continue;
+        const DevNode* nodes = col.binNodes[set];
+        float closestT = Q.maxDistance;
+        sge_raycast_hit hit{};
+        int sp = 0;
+        stack[sp++] = col.binRoot[set];
+        while (sp > 0) {
+            const DevNode node = nodes[stack[--sp]];
+            float rangeMin;
+            if (!rayAABB(origin, inv, node, rangeMin)) continue;
+            if (rangeMin > closestT) continue;
+            if (node.a < 0) { // leaf: slots [~a, ~a + b)
+                const int first = col.binSlotBase[set] + (~node.a);
+                for (int s = first; s < first + node.b; ++s) {
+                    Tri tri = loadTri(col, s);
+                    if ((col.tris[s].layer & Q.mask) == 0) continue;
+                    float t;
+                    if (rayTriangle(origin, direction, tri.v0, tri.v1, tri.v2, 1e-6f, t) && t < closestT) {
+                        F3 nrm = normalize(cross(tri.v1 - tri.v0, tri.v2 - tri.v0));
+                        if (dot(nrm, direction) > 0) nrm = -nrm;
+                        F3 pos = origin + direction * t;
+                        closestT = t;
+                        hit.hit = 1; hit.distance = t;
+                        hit.position[0] = pos.x; hit.position[1] = pos.y; hit.position[2] = pos.z;
+                        hit.normal[0] = nrm.x; hit.normal[1] = nrm.y; hit.normal[2] = nrm.z;
+                        hit.triangleIndex = tri.triIndex;
+                    }
+                }
+            } else if (sp + 2 <= kRayStack) {
+                stack[sp++] = node.a;
+                stack[sp++] = node.b;
+            }
+        }
+        // chooseNearest (:902-907): the static hit wins ties
+        if (hit.hit && (!best.hit || !(best.distance <= hit.distance))) best = hit;
+    }
+    if (best.hit) {
+        DevMaterial m = col.materials[best.triangleIndex];
+        best.material = sge_surface_material{m.muS, m.muK, m.flatten};
+    }
+    out[i] = best;
+}
+
+void launch_raycast_queries(const DevCollision& col, const sge_ray_query* d_q, int n, sge_raycast_hit* d_out, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(raycast_query_kernel, dim3((n + kWave - 1) / kWave), dim3(kWave), 0, s, col, d_q, n, d_out);
 }
 
 void launch_overlap_deepest_queries(const DevCollision& col, const sge_capsule_query* d_q, int n,

@@ -127,18 +127,21 @@ struct Builder {
 };
 
 void HostCollision::rebuild(const sge_static_mesh_entity* ents, int count) {
-    positions.clear(); indices.clear(); aabbs.clear(); materials.clear(); layers.clear();
-    nodes.clear(); triOrder.clear(); triLeaf.clear(); rank.clear();
+    positions.clear(); localPositions.clear(); indices.clear(); aabbs.clear(); materials.clear(); layers.clear();
+    nodes.clear(); triOrder.clear(); triLeaf.clear(); rank.clear(); wide.clear(); wideBinary.clear();
+    slices.assign(count > 0 ? count : 0, HostMeshSlice{});
     root = -1; maxDepth = 0;
     const float areaEps = 1e-10f;
     for (int e = 0; e < count; ++e) {
         const sge_static_mesh_entity& m = ents[e];
         const float* M = m.modelMatrix;
         uint32_t baseVertex = (uint32_t)(positions.size() / 3);
+        const int indexStart = (int)indices.size(), triStart = (int)layers.size();
         for (int v = 0; v < m.vertexCount; ++v) {
             float x = m.positions[v * 3], y = m.positions[v * 3 + 1], z = m.positions[v * 3 + 2];
             for (int r = 0; r < 3; ++r) // simd_mul(modelMatrix, (p,1)).xyz
                 positions.push_back(((M[r] * x + M[4 + r] * y) + M[8 + r] * z) + M[12 + r] * 1.0f);
+            localPositions.push_back(x); localPositions.push_back(y); localPositions.push_back(z);
         }
         int triCount = m.indexCount / 3;
         bool perTri = m.triangleMaterials && m.triangleMaterialCount == triCount;
@@ -157,6 +160,9 @@ void HostCollision::rebuild(const sge_static_mesh_entity* ents, int count) {
             layers.push_back(m.collisionLayer);
             t += 3; ++triLocal;
         }
+        const int indexEnd = (int)indices.size(), triEnd = (int)layers.size();
+        if (indexEnd > indexStart && triEnd > triStart) // a slice exists only for entities that kept a triangle (:404-410)
+            slices[e] = HostMeshSlice{(int)baseVertex, (int)(positions.size() / 3), indexStart, indexEnd, triStart, triEnd, true};
     }
     int T = (int)layers.size();
     triOrder.resize(T);
@@ -187,8 +193,75 @@ void HostCollision::rebuild(const sge_static_mesh_entity* ents, int count) {
 // entry with the most triangles until kWideWidth entries exist or every entry holds <= kWideWidth triangles.
 // Subtree triangle ranges are contiguous in triOrder because BVH.build partitions in place
 // (left = [start, mid), right = [mid, end), CollisionQuery.swift:655-663).
+// TriangleMeshSet.updateTransforms (CollisionQuery.swift:419-462)
+int HostCollision::updateTransforms(const int32_t* entities, const float* modelMatrices, int n) {
+    if (n <= 0 || layers.empty()) return 0;
+    std::vector<int> updated;
+    for (int k = 0; k < n; ++k) {
+        const int e = entities[k];
+        if (e < 0 || e >= (int)slices.size() || !slices[e].valid) continue;
+        const HostMeshSlice& sl = slices[e];
+        const float* M = modelMatrices + (size_t)k * 16;
+        for (int i = sl.vertexBegin; i < sl.vertexEnd; ++i) {
+            const float x = localPositions[(size_t)i * 3], y = localPositions[(size_t)i * 3 + 1], z = localPositions[(size_t)i * 3 + 2];
+            for (int r = 0; r < 3; ++r) positions[(size_t)i * 3 + r] = ((M[r] * x + M[4 + r] * y) + M[8 + r] * z) + M[12 + r] * 1.0f;
+        }
+        int tri = sl.triBegin;
+        for (int i = sl.indexBegin; i + 2 < sl.indexEnd; i += 3, ++tri) {
+            const float *p0 = &positions[(size_t)indices[i] * 3], *p1 = &positions[(size_t)indices[i + 1] * 3], *p2 = &positions[(size_t)indices[i + 2] * 3];
+            float* bb = &aabbs[(size_t)tri * 6];
+            for (int a = 0; a < 3; ++a) {
+                bb[a] = fminf(p0[a], fminf(p1[a], p2[a]));
+                bb[3 + a] = fmaxf(p0[a], fmaxf(p1[a], p2[a]));
+            }
+            updated.push_back(tri);
+        }
+    }
+    if (!updated.empty()) { refit(updated); reboundWide(); }
+    return (int)updated.size();
+}
+
+// BVH.refit (CollisionQuery.swift:528-575): dirty leaves from their triangles, then every ancestor from its children,
+// deepest first.
+void HostCollision::refit(const std::vector<int>& updatedTriangles) {
+    if (nodes.empty()) return;
+    std::vector<char> leafDirty(nodes.size(), 0), parentDirty(nodes.size(), 0);
+    std::vector<int> leaves, parents;
+    for (int tri : updatedTriangles) {
+        int leaf = triLeaf[tri];
+        if (leaf >= 0 && !leafDirty[leaf]) { leafDirty[leaf] = 1; leaves.push_back(leaf); }
+    }
+    Builder b{*this};
+    for (int leaf : leaves) b.rangeBounds(nodes[leaf].start, nodes[leaf].count, nodes[leaf].mn, nodes[leaf].mx);
+    for (int leaf : leaves)
+        for (int p = nodes[leaf].parent; p >= 0; p = nodes[p].parent)
+            if (!parentDirty[p]) { parentDirty[p] = 1; parents.push_back(p); }
+    std::vector<int> depth(parents.size()), order(parents.size());
+    for (size_t i = 0; i < parents.size(); ++i) {
+        int d = 0;
+        for (int nidx = parents[i]; nidx >= 0; nidx = nodes[nidx].parent) ++d;
+        depth[i] = d; order[i] = (int)i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return depth[a] > depth[c]; });
+    for (int i : order) {
+        HostBVHNode& p = nodes[parents[i]];
+        const HostBVHNode &l = nodes[p.left], &r = nodes[p.right];
+        for (int k = 0; k < 3; ++k) { p.mn[k] = fminf(l.mn[k], r.mn[k]); p.mx[k] = fmaxf(l.mx[k], r.mx[k]); }
+    }
+}
+
+void HostCollision::reboundWide() {
+    for (size_t i = 0; i < wide.size(); ++i) {
+        int b = wideBinary[i];
+        if (b < 0) continue;
+        const HostBVHNode& n = nodes[b];
+        wide[i].mnx = n.mn[0]; wide[i].mny = n.mn[1]; wide[i].mnz = n.mn[2];
+        wide[i].mxx = n.mx[0]; wide[i].mxy = n.mx[1]; wide[i].mxz = n.mx[2];
+    }
+}
+
 void HostCollision::buildWide() {
-    wide.clear();
+    wide.clear(); wideBinary.clear();
     if (root < 0) return;
     const int N = (int)nodes.size();
     std::vector<int> cnt(N), lo(N);
@@ -200,6 +273,7 @@ void HostCollision::buildWide() {
     struct Job { int binary, wideIndex; };
     std::vector<Job> jobs{{root, 0}};
     wide.resize(kWideWidth);
+    wideBinary.assign(kWideWidth, -1);
     for (size_t q = 0; q < jobs.size(); ++q) {
         std::vector<int> frontier{jobs[q].binary};
         while ((int)frontier.size() < kWideWidth) {
@@ -223,11 +297,13 @@ void HostCollision::buildWide() {
                 else {
                     int w = (int)(wide.size() / kWideWidth);
                     wide.resize(wide.size() + kWideWidth);
+                    wideBinary.resize(wide.size(), -1);
                     jobs.push_back({b, w});
                     d.a = w; d.b = 0;
                 }
             }
             wide[(size_t)jobs[q].wideIndex * kWideWidth + k] = d;
+            wideBinary[(size_t)jobs[q].wideIndex * kWideWidth + k] = k < (int)frontier.size() ? frontier[k] : -1;
         }
     }
 }

@@ -75,12 +75,16 @@ struct DevProfiles {
 constexpr int kWideWidth = 64;
 
 struct DevCollision {
-    int nodeCount, triCount, root;
-    const DevNode* wide;            // [wideCount][kWideWidth]; wide node 0 is the root (root < 0: empty world)
+    int nodeCount, triCount, root;  // root < 0: no triangle in either set
+    const DevNode* wide;            // [wideCount][kWideWidth]; wide node 0 is the root of the first non-empty set
     int wideCount;
-    const DevNode* nodes;
-    const DevTri* tris;             // slot order
-    const DevMaterial* materials;   // by triIndex
+    int dynWide;                    // wide node of the dynamic set's root when both sets hold triangles, else -1
+    const DevTri* tris;             // slot order: static set, then dynamic set (triIndex / rank offset by the static count)
+    const DevMaterial* materials;   // by (offset) triIndex
+    // the binary BVH of each set (leaf: a = ~firstSlot, b = count; inner: a = left, b = right) for the raycast, which
+    // follows the reference's own traversal order; binRoot < 0: empty set; binSlotBase: the set's first slot in `tris`
+    const DevNode* binNodes[2];
+    int binRoot[2], binSlotBase[2];
 };
 
 struct DevCrowd {
@@ -118,8 +122,11 @@ struct DevAgents {
 
 // ---- host-side collision build (sge_host.cpp) ---------------------------- //
 struct HostBVHNode { float mn[3], mx[3]; int left, right, start, count, parent; };
+struct HostMeshSlice { int vertexBegin = 0, vertexEnd = 0, indexBegin = 0, indexEnd = 0, triBegin = 0, triEnd = 0; bool valid = false; };
 struct HostCollision {
-    std::vector<float> positions;   // xyz
+    std::vector<float> positions;   // xyz, world space
+    std::vector<float> localPositions; // xyz as given (collisionMesh.streams.positions), same indexing as `positions`
+    std::vector<HostMeshSlice> slices; // per entity of the last rebuild (CollisionQuery.swift:480-485)
     std::vector<uint32_t> indices;
     std::vector<float> aabbs;       // [T][6] min xyz max xyz
     std::vector<sge_surface_material> materials;
@@ -129,8 +136,13 @@ struct HostCollision {
     int root = -1;
     int maxDepth = 0;
     std::vector<DevNode> wide;      // flattened wide nodes, kWideWidth entries each
+    std::vector<int> wideBinary;    // binary node behind every wide entry (-1: padding), to re-bound after a refit
     void rebuild(const sge_static_mesh_entity* ents, int count);
     void buildWide();
+    // TriangleMeshSet.updateTransforms + BVH.refit (CollisionQuery.swift:419-462, 528-575); returns #updated triangles
+    int updateTransforms(const int32_t* entities, const float* modelMatrices, int n);
+    void refit(const std::vector<int>& updatedTriangles);
+    void reboundWide();
 };
 
 // ---- kernel launchers ----------------------------------------------------- //
@@ -139,6 +151,8 @@ struct MoveLaunch {
     float dt; float gx, gy, gz; uint32_t stages; int first, count;
     unsigned long long* stats; // [8]
     void* scratch;             // [count] x kMoveScratchBytes: per-character working set between the two launches
+    const sge_platform_state* platforms; // PlatformCarry inputs of this step
+    int platformCount;
 };
 constexpr int kMoveScratchBytes = 256;
 constexpr int kStatShards = 256; // device counters: kStatShards lines of 8 x u64
@@ -147,6 +161,7 @@ void launch_cast_queries(const DevCollision& col, const sge_capsule_query* d_q, 
                          unsigned long long* stats, hipStream_t s);
 void launch_overlap_queries(const DevCollision& col, const sge_capsule_query* d_q, int n, int maxHits,
                             sge_capsule_overlap_hit* d_out, int32_t* d_counts, unsigned long long* stats, hipStream_t s);
+void launch_raycast_queries(const DevCollision& col, const sge_ray_query* d_q, int n, sge_raycast_hit* d_out, hipStream_t s);
 void launch_overlap_deepest_queries(const DevCollision& col, const sge_capsule_query* d_q, int n,
                                     sge_capsule_overlap_hit* d_out, int32_t* d_found, unsigned long long* stats, hipStream_t s);
 

@@ -162,6 +162,48 @@ class CharacterEngine:
     def rebuild_static(self, entities):
         """entities: list of dict(positions [V][3], indices u32, modelMatrix [16] (default identity),
         material (muS, muK, flatten) (default SurfaceMaterial.default), layer (default 1))."""
+        self._rebuild("collision_rebuild_static", entities)
+
+    def rebuild_dynamic(self, entities):
+        """The dynamic triangle set (collidable meshes on non-static bodies): same entity dicts as rebuild_static."""
+        self._rebuild("collision_rebuild_dynamic", entities)
+
+    def update_transforms(self, which, entity_indices, model_matrices):
+        """CollisionQuery.updateStaticTransforms / updateDynamicTransforms: new model matrices [n][16] for the listed
+        entities of the last rebuild of set `which` (abi.SET_STATIC / abi.SET_DYNAMIC); refits the BVH."""
+        idx = np.ascontiguousarray(entity_indices, np.int32)
+        mats = np.ascontiguousarray(model_matrices, np.float32).reshape(-1, 16)
+        assert mats.shape[0] == idx.shape[0]
+        self._call("collision_update_transforms", int(which), ptr(idx), ptr(mats), idx.shape[0])
+
+    def raycast(self, origins, directions, max_distance, mask=0xFFFFFFFF):
+        """CollisionQuery.raycast, batched -> raycast_hit_dtype array."""
+        o = np.asarray(origins, np.float32).reshape(-1, 3)
+        q = np.zeros(o.shape[0], abi.ray_query_dtype)
+        q["origin"] = o
+        q["direction"] = np.asarray(directions, np.float32).reshape(-1, 3)
+        q["maxDistance"] = max_distance
+        q["mask"] = mask
+        out = np.zeros(q.shape[0], abi.raycast_hit_dtype)
+        self._call("raycast_batch", ptr(q), q.shape[0], ptr(out))
+        return out
+
+    def mesh_world_aabb(self, positions, model_matrix):
+        """meshWorldAABB (Systems.swift:627-642), host helper -> (min[3], max[3])."""
+        pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        m = np.ascontiguousarray(model_matrix, np.float32).reshape(16)
+        mn, mx = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        rc = self.t.fn("mesh_world_aabb")(ptr(pos), pos.shape[0], ptr(m), ptr(mn), ptr(mx))
+        if rc != abi.SGE_OK:
+            raise SgeError("mesh_world_aabb failed")
+        return mn, mx
+
+    def upload_platforms(self, platforms):
+        """platforms: platform_dtype array (PlatformCarry inputs per kinematic platform entity), or None / empty."""
+        p = np.zeros(0, abi.platform_dtype) if platforms is None else np.ascontiguousarray(platforms, abi.platform_dtype)
+        self._call("platforms_upload", ptr(p) if p.shape[0] else None, p.shape[0])
+
+    def _rebuild(self, fn, entities):
         descs = (abi.StaticMeshEntity * max(len(entities), 1))()
         keep = []
         for k, e in enumerate(entities):
@@ -183,19 +225,19 @@ class CharacterEngine:
                 descs[k].triangleMaterials = tm.ctypes.data_as(C.POINTER(abi.SurfaceMaterial))
                 descs[k].triangleMaterialCount = tm.shape[0]
             descs[k].collisionLayer = int(e.get("layer", 1))
-        self._call("collision_rebuild_static", descs, len(entities))
+        self._call(fn, descs, len(entities))
 
-    def collision_counts(self):
+    def collision_counts(self, which=abi.SET_STATIC):
         v, t, n = C.c_int32(), C.c_int32(), C.c_int32()
-        self._call("collision_counts", C.byref(v), C.byref(t), C.byref(n))
+        self._call("collision_counts_set", int(which), C.byref(v), C.byref(t), C.byref(n))
         return v.value, t.value, n.value
 
-    def collision_copy(self):
-        v, t, n = self.collision_counts()
+    def collision_copy(self, which=abi.SET_STATIC):
+        v, t, n = self.collision_counts(which)
         out = {"positions": np.zeros((v, 3), np.float32), "indices": np.zeros(t * 3, np.uint32),
                "aabbs": np.zeros((t, 2, 3), np.float32), "nodes": np.zeros(n, abi.bvh_node_dtype),
                "triOrder": np.zeros(t, np.int32), "triLeaf": np.zeros(t, np.int32)}
-        self._call("collision_copy", ptr(out["positions"]), ptr(out["indices"]), ptr(out["aabbs"]),
+        self._call("collision_copy_set", int(which), ptr(out["positions"]), ptr(out["indices"]), ptr(out["aabbs"]),
                    ptr(out["nodes"]), ptr(out["triOrder"]), ptr(out["triLeaf"]))
         return out
 

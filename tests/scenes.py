@@ -60,3 +60,62 @@ def compare_states(pkg, gpu, cpu, n, float_tol_fields=("posePhase", "time", "mot
     cp, _, _ = cpu.palettes()
     scale = np.abs(cp).max()
     assert np.abs(gp - cp).max() <= 1e-5 * scale, ("palette", np.abs(gp - cp).max(), scale)
+
+
+# ---- kinematic platform scene (dynamic triangle set + PlatformCarry) ---------------------------------------------
+
+def box_mesh(hx, hy, hz):
+    """12-triangle box centred on the origin (outward winding)."""
+    p = np.array([[-hx, -hy, -hz], [hx, -hy, -hz], [hx, hy, -hz], [-hx, hy, -hz],
+                  [-hx, -hy, hz], [hx, -hy, hz], [hx, hy, hz], [-hx, hy, hz]], np.float32)
+    i = np.array([0, 2, 1, 0, 3, 2, 4, 5, 6, 4, 6, 7, 0, 1, 5, 0, 5, 4, 3, 6, 2, 3, 7, 6, 0, 4, 7, 0, 7, 3, 1, 2, 6, 1, 6, 5], np.uint32)
+    return p, i
+
+
+def translation_matrix(t):
+    m = np.eye(4, dtype=np.float32)
+    m[3, :3] = t
+    return m.reshape(16)
+
+
+class PlatformScene:
+    """Ground quad (static set) + kinematic box platforms (dynamic set) that move along a velocity each step, driven the
+    way the reference orders its systems: KinematicPlatformMotionSystem (Systems.swift:122-155) moves the bodies,
+    CollisionQueryRefreshSystem (:157-180) re-poses the dynamic set, then the character systems run."""
+
+    def __init__(self, pkg, eng, starts, velocities, half=(6.0, 0.5, 6.0), dt=1.0 / 60.0):
+        self.pkg, self.eng, self.dt = pkg, eng, dt
+        self.pos = np.asarray(starts, np.float64).reshape(-1, 3).copy()
+        self.vel = np.asarray(velocities, np.float64).reshape(-1, 3)
+        self.box = box_mesh(*half)
+        gp, gi, gm = pkg.assets.ground_plane()
+        eng.rebuild_static([{"positions": gp, "indices": gi, "modelMatrix": gm, "material": (0.9, 0.8, 0)}])
+        eng.rebuild_dynamic([{"positions": self.box[0], "indices": self.box[1], "modelMatrix": translation_matrix(p.astype(np.float32)),
+                              "material": (0.6, 0.5, 0), "layer": 2} for p in self.pos])
+        eng.upload_platforms(None)
+
+    def step(self, stages=None):
+        prev = self.pos.copy()
+        self.pos = self.pos + self.vel * self.dt
+        mats = np.stack([translation_matrix(p.astype(np.float32)) for p in self.pos])
+        self.eng.update_transforms(self.pkg.abi.SET_DYNAMIC, np.arange(len(self.pos)), mats)
+        pf = np.zeros(len(self.pos), self.pkg.abi.platform_dtype)
+        for k in range(len(self.pos)):
+            mn, mx = self.eng.mesh_world_aabb(self.box[0], mats[k])
+            pf[k]["aabbMin"], pf[k]["aabbMax"] = mn, mx
+            pf[k]["delta"] = self.pos[k].astype(np.float32) - prev[k].astype(np.float32)  # positionF - prevPositionF
+            pf[k]["kinematic"], pf[k]["hasAABB"] = 1, 1
+        self.eng.upload_platforms(pf)
+        A = self.pkg.abi
+        physics = A.STAGE_INTENT | A.STAGE_GRAVITY | A.STAGE_MOVE | A.STAGE_LOCOMOTION | A.STAGE_ACTION | A.STAGE_WRITEBACK
+        self.eng.tick(dt=self.dt, stages=physics if stages is None else stages)
+
+
+def spawn_on_platforms(pkg, eng, ybot, positions):
+    n = len(positions)
+    eng.resize(n)
+    state = {"bodies": pkg.assets.default_bodies(n, np.asarray(positions, np.float64)), "params": pkg.assets.default_controller_params(n),
+             "controllers": pkg.assets.default_controller_state(n), "intents": pkg.assets.default_intents(n),
+             "locomotion": pkg.assets.default_locomotion(n, ybot), "actions": pkg.assets.default_actions(n, ybot, present=True)}
+    eng.upload(**state)
+    return state

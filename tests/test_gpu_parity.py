@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle_binding as ob
-from scenes import assert_struct_equal, build_scene, compare_states
+from scenes import PlatformScene, assert_struct_equal, box_mesh, build_scene, compare_states, spawn_on_platforms, translation_matrix
 
 pytestmark = pytest.mark.gpu
 REL = 1e-5
@@ -300,10 +300,8 @@ def test_real_asset_scene_bvh_and_queries(sge, engines):
     assert_struct_equal(g["nodes"], c["nodes"], "nodes")
     rng = np.random.default_rng(11)
     n = 2048
-    which = rng.integers(0, 3, n)
-    lo = np.stack([bounds[k]["lo"] for k in which])
-    hi = np.stack([bounds[k]["hi"] for k in which])
-    origin = rng.uniform(lo - 2, hi + 4).astype(np.float32)
+    # probes start near the surfaces: a random mesh vertex plus a few units of noise
+    origin = (g["positions"][rng.integers(0, len(g["positions"]), n)] + rng.normal(0, 2.5, (n, 3))).astype(np.float32)
     delta = (rng.normal(0, 1, (n, 3)) * rng.choice([0.3, 3.0, 30.0], (n, 1))).astype(np.float32)
     delta[: n // 4, 0] = 0
     delta[: n // 4, 2] = 0  # vertical probes, as the ground probe issues them
@@ -312,10 +310,10 @@ def test_real_asset_scene_bvh_and_queries(sge, engines):
     q["mask"] = rng.choice([0xFFFFFFFF, 1, 2, 4, 1 << 30, 5], n)  # per-asset collision layers
     gh, ch = gpu.capsule_cast(q), cpu.capsule_cast(q)
     assert_struct_equal(gh, ch, "cast")
-    assert gh["hit"].sum() > n // 8
+    assert gh["hit"].sum() > n // 16
     go, gc = gpu.capsule_overlap_all(q, 8)
     co, cc = cpu.capsule_overlap_all(q, 8)
-    assert np.array_equal(gc, cc) and gc.max() == 8
+    assert np.array_equal(gc, cc) and gc.max() == 8 and (gc > 0).sum() > n // 8
     assert_struct_equal(go, co, "overlap")
 
 
@@ -343,10 +341,109 @@ def test_real_assets_full_tick_parity(sge):
     ob.tick_mt(cpu, 8, dt=0.0, stages=sge.abi.STAGE_SKIN)
     gp, gn, gt = gpu.skinned()
     cp, cn, ct = cpu.skinned()
-    scale = np.abs(cp - cp.mean(0)).max()
     assert np.abs(gp - cp).max() <= REL * np.abs(cp).max()
     assert np.abs(gn - cn).max() <= 2e-5 and np.abs(gt - ct).max() <= 2e-5
-    assert scale > 50  # the crowd is spread over the scene
+    gpu.close()
+    cpu.close()
+
+
+def test_dynamic_set_refit_and_raycast_bit_exact(sge, engines):
+    """Rows C1/C3/C4/C10: static terrain + a dynamic set of boxes; updateTransforms on both sets (refit), then the
+    BVH copies, capsule casts / overlaps and raycasts must match the oracle bit for bit."""
+    gpu, cpu = engines
+    pos, idx = sge.assets.make_synthetic_static_mesh(40, 28, 1.0)
+    box = box_mesh(2.0, 0.6, 3.0)
+    rng = np.random.default_rng(17)
+    centres = np.c_[rng.uniform(-15, 15, 6), rng.uniform(3, 9, 6), rng.uniform(-10, 10, 6)].astype(np.float32)
+    statics = [{"positions": pos, "indices": idx}, {"positions": box[0], "indices": box[1], "modelMatrix": translation_matrix((4, 8, 2)), "layer": 4}]
+    dynamics = [{"positions": box[0], "indices": box[1], "modelMatrix": translation_matrix(c), "layer": 2, "material": (0.5, 0.4, 1)} for c in centres]
+
+    def rot(deg, t):
+        a = np.radians(deg)
+        m = np.eye(4, dtype=np.float32)
+        m[0, 0], m[0, 2], m[2, 0], m[2, 2] = np.cos(a), -np.sin(a), np.sin(a), np.cos(a)
+        m[3, :3] = t
+        return m.reshape(16)
+
+    for e in engines:
+        e.rebuild_static(statics)
+        e.rebuild_dynamic(dynamics)
+        e.update_transforms(sge.abi.SET_DYNAMIC, [0, 3, 5], np.stack([rot(20, centres[0] + 1), rot(-50, centres[3] - 2), rot(90, centres[5])]))
+        e.update_transforms(sge.abi.SET_STATIC, [1], rot(33, (-6, 7, 1)).reshape(1, 16))
+        e.update_transforms(sge.abi.SET_DYNAMIC, [9, 1], np.stack([rot(0, (0, 0, 0)), rot(10, centres[1] + (0, 1, 0))]))  # 9: unknown entity
+    for which in (sge.abi.SET_STATIC, sge.abi.SET_DYNAMIC):
+        g, c = gpu.collision_copy(which), cpu.collision_copy(which)
+        for k in ("positions", "indices", "aabbs", "triOrder", "triLeaf"):
+            assert np.array_equal(g[k], c[k]), (which, k)
+        assert_struct_equal(g["nodes"], c["nodes"], "nodes")
+    T_static = gpu.collision_counts()[1]
+    n = 3000
+    anchor = np.concatenate([centres, [[-6, 7, 1]], pos[rng.integers(0, len(pos), 8)]])
+    origin = (anchor[rng.integers(0, len(anchor), n)] + rng.normal(0, 2.5, (n, 3))).astype(np.float32)
+    delta = (rng.normal(0, 1, (n, 3)) * rng.choice([0.5, 4.0, 25.0], (n, 1))).astype(np.float32)
+    q = sge.make_queries(origin, delta, radius=0.8, half_height=0.6)
+    q["mode"] = rng.integers(0, 3, n)
+    q["mask"] = rng.choice([0xFFFFFFFF, 1, 2, 4, 6], n)
+    gh, ch = gpu.capsule_cast(q), cpu.capsule_cast(q)
+    assert_struct_equal(gh, ch, "cast")
+    assert (gh["triangleIndex"] >= T_static).sum() > 100 and ((gh["hit"] != 0) & (gh["triangleIndex"] < T_static)).sum() > 100
+    go, gc = gpu.capsule_overlap_all(q, 8)
+    co, cc = cpu.capsule_overlap_all(q, 8)
+    assert np.array_equal(gc, cc) and (gc > 0).sum() > 200
+    assert_struct_equal(go, co, "overlapAll")
+    g1, gf = gpu.capsule_overlap(q)
+    c1, cf = cpu.capsule_overlap(q)
+    assert np.array_equal(gf, cf)
+    assert_struct_equal(g1[gf != 0], c1[cf != 0], "overlap")
+    direction = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    for mask in (0xFFFFFFFF, 2, 5):
+        gr, cr = gpu.raycast(origin, direction, 40.0, mask=mask), cpu.raycast(origin, direction, 40.0, mask=mask)
+        assert_struct_equal(gr, cr, "raycast")
+    assert gr["hit"].sum() > 100
+    # identical geometry in both sets: the static set wins every tie
+    for e in engines:
+        e.rebuild_dynamic(statics)
+    assert_struct_equal(gpu.capsule_cast(q), cpu.capsule_cast(q), "cast(tie)")
+    assert (gpu.capsule_cast(q)["triangleIndex"] < T_static).all()
+    go, gc = gpu.capsule_overlap_all(q, 8)
+    co, cc = cpu.capsule_overlap_all(q, 8)
+    assert np.array_equal(gc, cc)
+    assert_struct_equal(go, co, "overlapAll(tie)")
+    assert_struct_equal(gpu.raycast(origin, direction, 40.0), cpu.raycast(origin, direction, 40.0), "raycast(tie)")
+    for e in engines:
+        e.rebuild_dynamic([])
+        e.upload_platforms(None)
+
+
+def test_kinematic_platforms_tick_parity(sge):
+    """Rows C21/C23: characters riding, being pushed by and walking off moving platforms (dynamic set re-posed every step,
+    PlatformCarry inputs uploaded every step) stay bit-exact with the oracle."""
+    gpu = sge.CharacterEngine(0)
+    cpu = ob.oracle_engine()
+    ybot = sge.assets.YBotAssets()
+    starts = [(0, 2, 0), (30, 1, 0), (-30, 3, 10), (0, 6, 40)]
+    vels = [(3.0, 0, 1.5), (-4.0, 0, 0), (0, 1.2, 0), (0, -0.8, 2.0)]
+    rng = np.random.default_rng(8)
+    n = 96
+    spots = np.array(starts)[rng.integers(0, 4, n)] + np.c_[rng.uniform(-9, 9, n), rng.uniform(4, 7, n), rng.uniform(-9, 9, n)]
+    scenes = []
+    for e in (gpu, cpu):
+        sge.crowd.upload_character_assets(e, ybot, rings=3, segments=3)
+        scenes.append(PlatformScene(sge, e, starts, vels))
+        state = spawn_on_platforms(sge, e, ybot, spots)
+        heading = rng.uniform(0, 2 * np.pi, n) if e is gpu else heading
+        state["intents"] = sge.assets.default_intents(n, np.c_[np.cos(heading) * 3, np.zeros(n), np.sin(heading) * 3].astype(np.float32))
+        e.upload(**state)
+    rode = np.zeros(n, bool)
+    for s in range(240):
+        for sc in scenes:
+            sc.step(stages=sge.abi.STAGE_ALL)
+        if s % 20 == 0 or s == 239:
+            gpu.synchronize()
+            compare_states(sge, gpu, cpu, n)
+            rode |= gpu.download(what=("controllers",))["controllers"]["groundTriangleIndex"] >= 2
+    assert rode.sum() > n // 4, "a good part of the crowd must have stood on a platform"
+    assert gpu.move_stats().overflow == 0
     gpu.close()
     cpu.close()
 
