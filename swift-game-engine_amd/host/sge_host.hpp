@@ -84,6 +84,11 @@ public:
     void fixedUpdate(World& world, float dt) override {
         world.tick(dt, (pre_ ? (SGE_STAGE_INTENT | SGE_STAGE_GRAVITY) : 0u) | SGE_STAGE_MOVE, gravity_);
     }
+    // the platform entities of world.query(PhysicsBody, Transform, StaticMesh, KinematicPlatform) (Systems.swift:1832-1835)
+    // as PlatformCarry reads them; call once per step after the platform motion system ran
+    static void setPlatforms(World& world, const std::vector<sge_platform_state>& platforms) {
+        check(sge_platforms_upload(world.context(), platforms.data(), (int32_t)platforms.size()), "sge_platforms_upload");
+    }
 private:
     float3 gravity_;
     bool pre_;
@@ -99,14 +104,33 @@ struct PoseStackSystem : FixedStepSystem {
 };
 
 // ---- CollisionQuery (CollisionQuery.swift:54-160) ------------------------------------------------
+struct RaycastHit { float distance; float3 position, normal; int triangleIndex; sge_surface_material material; };
 struct CapsuleCastHit { float toi; float3 position, normal, triangleNormal; int triangleIndex; sge_surface_material material; };
 struct CapsuleOverlapHit { float depth; float3 position, normal, triangleNormal; int triangleIndex; sge_surface_material material; };
 
 class CollisionQuery {
 public:
-    // init(world:activeEntityIDs:) — builds the static triangle set + BVH from the collidable entities
-    CollisionQuery(World& world, const std::vector<sge_static_mesh_entity>& collidables) : world_(world) {
-        check(sge_collision_rebuild_static(world.context(), collidables.data(), (int32_t)collidables.size()), "sge_collision_rebuild_static");
+    // init(world:activeEntityIDs:) — builds both triangle sets + BVHs from the collidable entities, partitioned the way
+    // StaticTriMesh.partitionEntities does: bodies that are not .static go to the dynamic set (:886-900)
+    CollisionQuery(World& world, const std::vector<sge_static_mesh_entity>& staticCollidables,
+                   const std::vector<sge_static_mesh_entity>& dynamicCollidables = {}) : world_(world) {
+        check(sge_collision_rebuild_static(world.context(), staticCollidables.data(), (int32_t)staticCollidables.size()), "sge_collision_rebuild_static");
+        check(sge_collision_rebuild_dynamic(world.context(), dynamicCollidables.data(), (int32_t)dynamicCollidables.size()), "sge_collision_rebuild_dynamic");
+    }
+    // updateStaticTransforms / updateDynamicTransforms(world:entities:activeEntityIDs:) — `entities` index the arrays the
+    // sets were built from; modelMatrices = their TransformComponent.modelMatrix, column-major
+    void updateStaticTransforms(const std::vector<int32_t>& entities, const std::vector<std::array<float, 16>>& modelMatrices) {
+        update(SGE_SET_STATIC, entities, modelMatrices);
+    }
+    void updateDynamicTransforms(const std::vector<int32_t>& entities, const std::vector<std::array<float, 16>>& modelMatrices) {
+        update(SGE_SET_DYNAMIC, entities, modelMatrices);
+    }
+    std::optional<RaycastHit> raycast(float3 origin, float3 direction, float maxDistance, uint32_t mask = 0xFFFFFFFFu) {
+        sge_ray_query q{{origin.x, origin.y, origin.z}, {direction.x, direction.y, direction.z}, maxDistance, mask};
+        sge_raycast_hit h{};
+        check(sge_raycast_batch(world_.context(), &q, 1, &h), "sge_raycast_batch");
+        if (!h.hit) return std::nullopt;
+        return RaycastHit{h.distance, {h.position[0], h.position[1], h.position[2]}, {h.normal[0], h.normal[1], h.normal[2]}, h.triangleIndex, h.material};
     }
     std::optional<CapsuleCastHit> capsuleCast(float3 from, float3 delta, float radius, float halfHeight, uint32_t mask = 0xFFFFFFFFu) {
         return cast(from, delta, radius, halfHeight, SGE_CAST, 0.0f, mask);
@@ -147,6 +171,11 @@ public:
     }
 
 private:
+    void update(int32_t set, const std::vector<int32_t>& entities, const std::vector<std::array<float, 16>>& m) {
+        if (entities.size() != m.size()) throw std::invalid_argument("one model matrix per entity");
+        check(sge_collision_update_transforms(world_.context(), set, entities.data(), m.empty() ? nullptr : m[0].data(), (int32_t)entities.size()),
+              "sge_collision_update_transforms");
+    }
     std::optional<CapsuleCastHit> cast(float3 from, float3 delta, float radius, float halfHeight, uint32_t mode, float minNormalY, uint32_t mask) {
         sge_capsule_query q{{from.x, from.y, from.z}, {delta.x, delta.y, delta.z}, radius, halfHeight, minNormalY, mask, mode};
         sge_capsule_cast_hit h{};

@@ -402,6 +402,7 @@ def test_dynamic_set_refit_and_raycast_bit_exact(sge, engines):
     assert gr["hit"].sum() > 100
     # identical geometry in both sets: the static set wins every tie
     for e in engines:
+        e.rebuild_static(statics)
         e.rebuild_dynamic(statics)
     assert_struct_equal(gpu.capsule_cast(q), cpu.capsule_cast(q), "cast(tie)")
     assert (gpu.capsule_cast(q)["triangleIndex"] < T_static).all()
