@@ -31,6 +31,7 @@
 // Compiled with -ffp-contract=off; float32 arithmetic is IEEE and in the oracle's
 // order, so TOIs, normals and the discrete contact state match bit for bit.
 #include "sge_internal.hpp"
+#include "sge_ccd_prims.hpp"
 
 namespace sge {
 
@@ -97,120 +98,6 @@ __device__ __forceinline__ unsigned long long waveMinU64(unsigned long long v) {
         v = w < v ? w : v;
     }
     return v;
-}
-
-// ---------------------------------------------------------------------------
-// primitive distance queries (CollisionQuery.swift:1396-1573)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ bool segmentTriangleIntersect(F3 a, F3 b, F3 v0, F3 v1, F3 v2, F3& out) { // :1440
-    F3 dir = b - a;
-    const float eps = 1e-6f;
-    F3 e1 = v1 - v0, e2 = v2 - v0;
-    F3 pvec = cross(dir, e2);
-    float det = dot(e1, pvec);
-    if (fabsf(det) < eps) return false;
-    float invDet = 1.0f / det;
-    F3 tvec = a - v0;
-    float u = dot(tvec, pvec) * invDet;
-    if (u < 0 || u > 1) return false;
-    F3 qvec = cross(tvec, e1);
-    float v = dot(dir, qvec) * invDet;
-    if (v < 0 || (u + v) > 1) return false;
-    float t = dot(e2, qvec) * invDet;
-    if (t < 0 || t > 1) return false;
-    out = a + dir * t;
-    return true;
-}
-
-__device__ __forceinline__ float closestPointOnTriangle(F3 p, F3 a, F3 b, F3 c, F3& point) { // :1464
-    F3 ab = b - a, ac = c - a, ap = p - a;
-    float d1 = dot(ab, ap), d2 = dot(ac, ap);
-    if (d1 <= 0 && d2 <= 0) { point = a; return lengthSq(p - a); }
-    F3 bp = p - b;
-    float d3 = dot(ab, bp), d4 = dot(ac, bp);
-    if (d3 >= 0 && d4 <= d3) { point = b; return lengthSq(p - b); }
-    float vc = d1 * d4 - d3 * d2;
-    if (vc <= 0 && d1 >= 0 && d3 <= 0) {
-        float v = d1 / (d1 - d3);
-        point = a + ab * v;
-        return lengthSq(p - point);
-    }
-    F3 cp = p - c;
-    float d5 = dot(ab, cp), d6 = dot(ac, cp);
-    if (d6 >= 0 && d5 <= d6) { point = c; return lengthSq(p - c); }
-    float vb = d5 * d2 - d1 * d6;
-    if (vb <= 0 && d2 >= 0 && d6 <= 0) {
-        float w = d2 / (d2 - d6);
-        point = a + ac * w;
-        return lengthSq(p - point);
-    }
-    float va = d3 * d6 - d5 * d4;
-    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
-        float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
-        point = b + (c - b) * w;
-        return lengthSq(p - point);
-    }
-    float denom = 1.0f / (va + vb + vc);
-    float v = vb * denom, w = vc * denom;
-    point = (a + ab * v) + ac * w;
-    return lengthSq(p - point);
-}
-
-__device__ __forceinline__ float segmentSegmentDistanceSq(F3 p1, F3 q1, F3 p2, F3 q2, F3& c1o, F3& c2o) { // :1519
-    F3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
-    float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);
-    float s = 0, t = 0;
-    const float eps = 1e-6f;
-    if (a <= eps && e <= eps) { c1o = p1; c2o = p2; return lengthSq(p1 - p2); }
-    if (a <= eps) {
-        t = sclamp(f / e, 0, 1);
-        F3 c2 = p2 + d2 * t;
-        c1o = p1; c2o = c2;
-        return lengthSq(p1 - c2);
-    }
-    float c = dot(d1, r);
-    if (e <= eps) {
-        s = sclamp(-c / a, 0, 1);
-        F3 c1 = p1 + d1 * s;
-        c1o = c1; c2o = p2;
-        return lengthSq(c1 - p2);
-    }
-    float b = dot(d1, d2);
-    float denom = a * e - b * b;
-    if (denom != 0) s = sclamp((b * f - c * e) / denom, 0, 1);
-    else s = 0;
-    float tNom = b * s + f;
-    if (tNom < 0) { t = 0; s = sclamp(-c / a, 0, 1); }
-    else if (tNom > e) { t = 1; s = sclamp((b - c) / a, 0, 1); }
-    else t = tNom / e;
-    F3 c1 = p1 + d1 * s, c2 = p2 + d2 * t;
-    c1o = c1; c2o = c2;
-    return lengthSq(c1 - c2);
-}
-
-__device__ __forceinline__ float segmentTriangleDistance(F3 center, float halfHeight, F3 v0, F3 v1, F3 v2,
-                                                         F3& segPoint, F3& triPoint) { // :1396
-    F3 up{0, 1, 0};
-    F3 a = center + up * halfHeight;
-    F3 b = center - up * halfHeight;
-    F3 hit;
-    if (segmentTriangleIntersect(a, b, v0, v1, v2, hit)) { segPoint = hit; triPoint = hit; return 0; }
-    float bestDistSq = kFloatMax;
-    F3 bestSeg = a, bestTri = v0;
-    F3 p0, p1;
-    float d0 = closestPointOnTriangle(a, v0, v1, v2, p0);
-    if (d0 < bestDistSq) { bestDistSq = d0; bestSeg = a; bestTri = p0; }
-    float dd1 = closestPointOnTriangle(b, v0, v1, v2, p1);
-    if (dd1 < bestDistSq) { bestDistSq = dd1; bestSeg = b; bestTri = p1; }
-    F3 s, t;
-    float d = segmentSegmentDistanceSq(a, b, v0, v1, s, t);
-    if (d < bestDistSq) { bestDistSq = d; bestSeg = s; bestTri = t; }
-    d = segmentSegmentDistanceSq(a, b, v1, v2, s, t);
-    if (d < bestDistSq) { bestDistSq = d; bestSeg = s; bestTri = t; }
-    d = segmentSegmentDistanceSq(a, b, v2, v0, s, t);
-    if (d < bestDistSq) { bestDistSq = d; bestSeg = s; bestTri = t; }
-    segPoint = bestSeg; triPoint = bestTri;
-    return sqrtf(smax(bestDistSq, 0.0f));
 }
 
 // ---------------------------------------------------------------------------
