@@ -226,6 +226,9 @@ enum {
     SGE_OPT_STORE_POSE_DEBUG = 1, /* also keep PoseComponent.local/.model per character */
     SGE_OPT_SKIN_LAYOUT = 2,      /* SGE_LAYOUT_* for the skinned output streams */
     SGE_OPT_PROFILE = 3,          /* 1: bracket every kernel with HIP events */
+    SGE_OPT_HEAVY_THRESHOLD = 5,  /* distance evaluations in a character's previous step above which its slide / ground
+                                   * pass runs in the four-wave kernel (default 4000; 0: every character that swept
+                                   * anything; < 0: always the one-wave kernel). Scheduling only: results are identical. */
     SGE_OPT_OVERLAP_SKIN = 4      /* 1: run the skin stage on a second stream so that it overlaps the next
                                      step's move stage (ignored on a caller-provided stream) */
 };

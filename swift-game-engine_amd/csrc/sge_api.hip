@@ -49,6 +49,9 @@ struct sge_context {
     // LBS of step n overlaps move/CCD of step n+1: skinning runs on its own stream, ordered by two events
     hipStream_t skinStream = nullptr;
     hipEvent_t evPoseDone = nullptr, evSkinDone = nullptr;
+    hipStream_t heavyStream = nullptr; // part 1 of the move stage for the step's heavy characters
+    hipEvent_t evClassified = nullptr, evHeavyDone = nullptr;
+    int heavyThreshold = 4000; // distance evaluations in a character's last step above which it takes the 4-wave kernel; < 0: off
     bool skinPending = false, overlapSkin = false, customStream = false;
     // options
     bool storePoseDebug = false, profile = false;
@@ -67,7 +70,7 @@ struct sge_context {
     // collision
     HostCollision hostCol, hostDyn; // StaticTriMesh.staticSet / dynamicSet (CollisionQuery.swift:710-711)
     DevCollision col{};
-    DevBuf dWide, dTris, dMaterials, dBinNodes[2], dPlatforms, dRayQueries, dRayOut;
+    DevBuf dWide, dTris, dMaterials, dBinNodes[2], dSlotOfRank, dPlatforms, dRayQueries, dRayOut, dCost, dLists, dListCounts;
     int platformCount = 0;
     // crowd
     DevCrowd crowd{};
@@ -121,6 +124,7 @@ struct Bracket {
 int syncAll(sge_context* c) {
     SGE_HIP(hipStreamSynchronize(c->stream));
     if (c->skinStream) SGE_HIP(hipStreamSynchronize(c->skinStream));
+    if (c->heavyStream) SGE_HIP(hipStreamSynchronize(c->heavyStream));
     c->skinPending = false;
     return SGE_OK;
 }
@@ -276,7 +280,10 @@ sge_context* sge_context_create(int device_index) {
     c->stream = c->ownStream;
     if (hipStreamCreateWithFlags(&c->skinStream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->evPoseDone, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->evSkinDone, hipEventDisableTiming) != hipSuccess) { set_error("stream/event creation failed"); delete c; return nullptr; }
+        hipEventCreateWithFlags(&c->evSkinDone, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->heavyStream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evClassified, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evHeavyDone, hipEventDisableTiming) != hipSuccess) { set_error("stream/event creation failed"); delete c; return nullptr; }
     if (c->dStats.alloc((size_t)kStatShards * 64) != SGE_OK || hipMemsetAsync(c->dStats.p, 0, (size_t)kStatShards * 64, c->stream) != hipSuccess) { delete c; return nullptr; }
     return c;
 }
@@ -288,13 +295,16 @@ void sge_context_destroy(sge_context* c) {
     drainEvents(c->evMove); drainEvents(c->evPose); drainEvents(c->evSkin); drainEvents(c->evAgents);
     DevBuf* bufs[] = {&c->dParent, &c->dDepth, &c->dLeanChain, &c->dBindLocal, &c->dInvBind, &c->dRestT, &c->dRawRestT, &c->dPreRot,
                       &c->dCoeffs, &c->dCoeffCount, &c->dBonePresent, &c->dMeshPos, &c->dMeshNrm, &c->dMeshTan, &c->dMeshIdx, &c->dMeshWgt,
-                      &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
+                      &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dSlotOfRank, &c->dCost, &c->dLists, &c->dListCounts, &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
                       &c->dPalettes, &c->dPoseModel, &c->dPoseLocal, &c->dMoveScratch, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
                       &c->dCellCursor, &c->dAgentMinMax, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats};
     for (DevBuf* b : bufs) b->release();
     if (c->evPoseDone) (void)hipEventDestroy(c->evPoseDone);
     if (c->evSkinDone) (void)hipEventDestroy(c->evSkinDone);
     if (c->skinStream) (void)hipStreamDestroy(c->skinStream);
+    if (c->evClassified) (void)hipEventDestroy(c->evClassified);
+    if (c->evHeavyDone) (void)hipEventDestroy(c->evHeavyDone);
+    if (c->heavyStream) (void)hipStreamDestroy(c->heavyStream);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
 }
@@ -323,6 +333,7 @@ int sge_context_set_option(sge_context* c, int option, int value) {
         break;
     case SGE_OPT_PROFILE: c->profile = value != 0; break;
     case SGE_OPT_OVERLAP_SKIN: { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; c->overlapSkin = value != 0; break; }
+    case SGE_OPT_HEAVY_THRESHOLD: c->heavyThreshold = value; break;
     default: set_error("unknown option"); return SGE_ERR_INVALID;
     }
     return SGE_OK;
@@ -563,6 +574,9 @@ int uploadCollisionAll(sge_context* c) {
     if ((rc = upload(c->dWide, ws.data(), ws.size() * sizeof(DevNode), c->stream)) != SGE_OK) return rc;
     if ((rc = upload(c->dTris, ts.data(), ts.size() * sizeof(DevTri), c->stream)) != SGE_OK) return rc;
     if ((rc = upload(c->dMaterials, ms.data(), ms.size() * sizeof(DevMaterial), c->stream)) != SGE_OK) return rc;
+    std::vector<int> slotOfRank(ts.size());
+    for (size_t slot = 0; slot < ts.size(); ++slot) slotOfRank[ts[slot].rank] = (int)slot;
+    if ((rc = upload(c->dSlotOfRank, slotOfRank.data(), slotOfRank.size() * sizeof(int), c->stream)) != SGE_OK) return rc;
     std::vector<DevNode> bs, bd;
     binaryNodes(c->hostCol, bs);
     binaryNodes(c->hostDyn, bd);
@@ -572,7 +586,8 @@ int uploadCollisionAll(sge_context* c) {
     const int T = L.Ts + L.Td;
     c->col = DevCollision{(int)(c->hostCol.nodes.size() + c->hostDyn.nodes.size()), T, T > 0 ? 0 : -1, c->dWide.as<DevNode>(), L.Ws + L.Wd,
                           (L.Ts > 0 && L.Td > 0) ? L.Ws : -1, c->dTris.as<DevTri>(), c->dMaterials.as<DevMaterial>(),
-                          {c->dBinNodes[0].as<DevNode>(), c->dBinNodes[1].as<DevNode>()}, {c->hostCol.root, c->hostDyn.root}, {0, L.Ts}};
+                          {c->dBinNodes[0].as<DevNode>(), c->dBinNodes[1].as<DevNode>()}, {c->hostCol.root, c->hostDyn.root}, {0, L.Ts},
+                          c->dSlotOfRank.as<int>()};
     return SGE_OK;
 }
 
@@ -775,6 +790,9 @@ int sge_characters_resize(sge_context* c, int32_t count) {
     SGE_ZALLOC(c->dActions, N * sizeof(sge_action_state));
     SGE_ZALLOC(c->dPalettes, N * B * 64);
     SGE_ZALLOC(c->dMoveScratch, N * (size_t)kMoveScratchBytes);
+    SGE_ZALLOC(c->dCost, N * sizeof(int));
+    SGE_ZALLOC(c->dLists, 2 * N * sizeof(int));
+    SGE_ZALLOC(c->dListCounts, 2 * sizeof(int));
     if (c->storePoseDebug) { SGE_ZALLOC(c->dPoseModel, N * B * 64); SGE_ZALLOC(c->dPoseLocal, N * B * 64); }
 #undef SGE_ZALLOC
     c->crowd = DevCrowd{count, c->dBodies.as<sge_body_state>(), c->dParams.as<sge_controller_params>(),
@@ -878,7 +896,9 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
             if (rc != SGE_OK) return rc;
         }
         MoveLaunch L{c->crowd, c->col, c->agents, d->dt, d->gravity[0], d->gravity[1], d->gravity[2], st, first, count,
-                     c->dStats.as<unsigned long long>(), c->dMoveScratch.p, c->dPlatforms.as<sge_platform_state>(), c->platformCount};
+                     c->dStats.as<unsigned long long>(), c->dMoveScratch.p, c->dPlatforms.as<sge_platform_state>(), c->platformCount,
+                     c->dCost.as<int>(), c->heavyThreshold >= 0 ? c->dLists.as<int>() : nullptr, c->dListCounts.as<int>(),
+                     c->heavyThreshold, 2048, c->heavyStream, c->evClassified, c->evHeavyDone, nullptr, nullptr};
         if (!(st & SGE_STAGE_AGENTS) || c->agents.nx == 0) L.agents.all = nullptr;
         Bracket br(c, &c->evMove);
         launch_move(L, c->stream);

@@ -180,10 +180,146 @@ __device__ __forceinline__ Tri loadTri(const DevCollision& col, int slot) {
 // ---------------------------------------------------------------------------
 enum { PH_MARCH = 0, PH_REFINE = 1, PH_FINAL = 2, PH_DONE = 3 };
 
+// one capsuleCastCombined (CollisionQuery.swift:980-1009)
+__device__ __forceinline__ bool rayHit(int r) { return (unsigned)(sh.rayKey[r] & 0xffffffffull) != 0xffffffffu; }
+
+// ---- heavy characters: four wavefronts sweep one character's work items --------------------------------------------
+// A capsule falling beside a wall meets hundreds of triangles that each crawl through up to 256 dependent advancement
+// steps; one wavefront then needs a thousand trips for a single query while the rest of the GPU idles. Characters whose
+// previous step was that expensive run in a 256-thread workgroup: wave 0 executes the step exactly as the one-wave kernel
+// does, and whenever a cast has gathered its work items the other three waves join the sweep (items are handed out through an
+// LDS cursor; the result is still the minimum (toi, visit rank) key, so the answer is bit-identical). The helper waves
+// otherwise sit in a loop matching wave 0's barriers.
+enum { HCMD_NONE = 0, HCMD_MARCH = 1, HCMD_EXIT = 2 };
+#ifndef SGE_HEAVY_WAVES
+#define SGE_HEAVY_WAVES 4
+#endif
+constexpr int kHeavyWaves = SGE_HEAVY_WAVES;
+constexpr int kHeavyItemCap = 2048;
+struct HeavyShared {
+    int items[kHeavyItemCap];
+    int cursor, count, cmd;
+    unsigned evalSum; // distance evaluations of the current step over all four waves (the cost the classifier reads)
+    float radius, halfHeight, minNormalY;
+    int blockingOnly, hasMinNormalY;
+};
+__shared__ HeavyShared hv;
+
+// The sweep of hv.items[0..hv.count) by every wave of the workgroup, between two workgroup barriers. No barrier inside:
+// the waves run different numbers of trips. Accepted hits only lower sh.rayKey; the records are rebuilt afterwards.
+__device__ __forceinline__ void heavyMarch(const DevCollision& col, WaveStats& st) {
+    const int lane = laneId();
+    const float radius = hv.radius, halfHeight = hv.halfHeight, minNormalY = hv.minNormalY;
+    const bool blockingOnly = hv.blockingOnly != 0, hasMinNormalY = hv.hasMinNormalY != 0;
+    const int total = hv.count;
+    const float minAdvance = smax(radius * 0.02f, 1e-4f);
+    const float contactEps = 1e-5f;
+    int phase = PH_DONE, myRay = 0, iter = 0, refineK = 0, maxIter = 0;
+    bool more = true;
+    Tri tri;
+    tri.v0 = tri.v1 = tri.v2 = F3{0, 0, 0}; tri.triIndex = -1; tri.rank = 0x7fffffff;
+    F3 triNormal{0, 0, 0};
+    float t = 0, lastSafeT = 0, lo = 0, hi = 0, tEval = 0, len = 0;
+    unsigned evals = 0;
+    while (true) {
+        const unsigned long long want = __ballot(phase == PH_DONE && more);
+        if (want) {
+            const int first = __ffsll((long long)want) - 1;
+            int base = 0;
+            if (lane == first) base = atomicAdd(&hv.cursor, __popcll(want));
+            base = __shfl(base, first, kWave);
+            if (phase == PH_DONE && more) {
+                const int idx = base + prefixCount(want);
+                if (idx < total) {
+                    const int it = hv.items[idx];
+                    myRay = (unsigned)it >> 28;
+                    tri = loadTri(col, it & 0x0fffffff);
+                    triNormal = normalize(cross(tri.v1 - tri.v0, tri.v2 - tri.v0));
+                    len = sh.rayLen[myRay];
+                    maxIter = sh.rayMaxIter[myRay];
+                    phase = PH_MARCH;
+                    t = 0; lastSafeT = 0; lo = 0; hi = 0; tEval = 0; iter = 0; refineK = 0;
+                } else {
+                    more = false;
+                }
+            }
+        }
+        if (!__any(phase != PH_DONE)) break;
+        st.trips += 1;
+        const float bestToi = __uint_as_float((unsigned)(*(volatile unsigned long long*)&sh.rayKey[myRay] >> 32));
+        if (phase == PH_MARCH) {
+            if (iter >= maxIter || t > len || lastSafeT > bestToi) phase = PH_DONE;
+            else { iter += 1; tEval = t; }
+        } else if (phase == PH_REFINE) {
+            if (lo > bestToi) phase = PH_DONE;
+            else tEval = 0.5f * (lo + hi);
+        }
+        if (phase != PH_DONE) {
+            evals += 1;
+            const F3 from = sh.rayFrom[myRay], dir = sh.rayDir[myRay];
+            F3 center = from + dir * tEval;
+            F3 segP, triP;
+            float dist = segmentTriangleDistance(center, halfHeight, tri.v0, tri.v1, tri.v2, segP, triP);
+            if (phase == PH_MARCH) {
+                if (dist <= radius + contactEps) {
+                    float c0 = smax(0.0f, smin(lastSafeT, len));
+                    float c1 = smax(0.0f, smin(t, len));
+                    lo = smin(c0, c1);
+                    hi = smax(c0, c1);
+                    if (hi - lo < 1e-5f) { phase = PH_FINAL; tEval = hi; }
+                    else { phase = PH_REFINE; refineK = 0; }
+                } else {
+                    lastSafeT = t;
+                    float advance = smax(dist - radius, minAdvance);
+                    if (advance <= 0) t += minAdvance; else t += advance;
+                }
+            } else if (phase == PH_REFINE) {
+                if (dist <= radius) hi = tEval; else lo = tEval;
+                refineK += 1;
+                if (refineK == 10) { phase = PH_FINAL; tEval = hi; }
+            } else { // PH_FINAL
+                float tHit = tEval;
+                F3 nrm;
+                if (dist < 1e-6f) nrm = dot(triNormal, dir) > 0 ? -triNormal : triNormal;
+                else nrm = normalize(segP - triP);
+                F3 triN = triNormal;
+                if (dot(triN, nrm) < 0) triN = -triN;
+                phase = PH_DONE;
+                bool ok = tHit < len;
+                if (ok && blockingOnly) {
+                    F3 delta = sh.rayDelta[myRay];
+                    ok = !(dot(delta, nrm) >= 0) && !(dot(delta, triN) >= 0);
+                }
+                if (ok && hasMinNormalY) ok = !(triN.y < minNormalY);
+                if (ok) atomicMin(&sh.rayKey[myRay], ((unsigned long long)__float_as_uint(tHit) << 32) | (unsigned)tri.rank);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o, kWave);
+    if (lane == 0) atomicAdd(&hv.evalSum, evals);
+    st.evals += evals >> 6; // per-lane convention of WaveStats: the kernel epilogue sums over the 64 lanes
+}
+
+// Waves 1..3 of a heavy workgroup: match every barrier of wave 0, join the sweeps it announces, leave on HCMD_EXIT.
+// The iteration bound is a safety net only (a finished wave no longer takes part in barriers).
+__device__ __forceinline__ void heavyHelperLoop(const DevCollision& col, WaveStats& st) {
+    for (int guard = 0; guard < (1 << 22); ++guard) {
+        __syncthreads();
+        const int cmd = *(volatile int*)&hv.cmd;
+        if (cmd == HCMD_EXIT) return;
+        if (cmd == HCMD_MARCH) {
+            heavyMarch(col, st);
+            __syncthreads();
+        }
+    }
+}
+
 // Casts sh.rayFrom/rayDelta[0..rayCount) (same capsule, same filters) in one pass. Each ray is an
 // independent capsuleCastCombined call of the reference; a work item is a (ray, triangle) pair whose
 // triangle AABB overlaps THAT ray's swept box, so every ray sees exactly its own candidate set.
 // Results: sh.rayKey[r] != initial  <=>  hit, record in sh.rayRec[r].
+template <bool HEAVY = false>
 __device__ __forceinline__ void waveCastRays(const DevCollision& col, float radius, float halfHeight, bool blockingOnly,
                                              bool hasMinNormalY, float minNormalY, uint32_t mask, WaveStats& st) {
     const int lane = laneId();
@@ -226,6 +362,65 @@ __device__ __forceinline__ void waveCastRays(const DevCollision& col, float radi
     int stackSize = initTraversal(col), rangeCount = 0, candCount = 0, itemCount = 0;
     __syncthreads();
 
+    if constexpr (HEAVY) {
+        // wave 0 of a heavy workgroup: gather work items in chunks, let all four waves sweep each chunk
+        if (lane == 0) {
+            hv.radius = radius; hv.halfHeight = halfHeight; hv.minNormalY = minNormalY;
+            hv.blockingOnly = blockingOnly ? 1 : 0; hv.hasMinNormalY = hasMinNormalY ? 1 : 0;
+        }
+        int hCount = 0;
+        while (true) {
+            while ((stackSize > 0 || rangeCount > 0 || candCount > 0) && hCount <= kHeavyItemCap - kWave * kMaxRays) {
+                while ((stackSize > 0 || rangeCount > 0) && candCount < kWave) expandNodes(col, minP, maxP, mask, stackSize, rangeCount, candCount, st);
+                int n = candCount < kWave ? candCount : kWave;
+                candCount -= n;
+                st.candidates += n;
+                int slot = -1;
+                F3 bmin{0, 0, 0}, bmax{0, 0, 0};
+                if (lane < n) {
+                    slot = sh.cand[candCount + lane];
+                    const float4* tp = reinterpret_cast<const float4*>(col.tris + slot);
+                    float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    F3 v0{t0.x, t0.y, t0.z}, v1{t0.w, t1.x, t1.y}, v2{t1.z, t1.w, t2.x};
+                    bmin = vmin(v0, vmin(v1, v2)); bmax = vmax(v0, vmax(v1, v2));
+                }
+                for (int r = 0; r < R; ++r) {
+                    bool c = slot >= 0 && sh.rayValid[r] && !boxDisjoint(bmin, bmax, sh.rayMin[r], sh.rayMax[r]);
+                    unsigned long long mc = __ballot(c);
+                    if (c) hv.items[hCount + prefixCount(mc)] = (r << 28) | slot;
+                    hCount += __popcll(mc);
+                }
+                __syncthreads();
+            }
+            if (hCount == 0) break;
+            if (lane == 0) { hv.count = hCount; hv.cursor = 0; hv.cmd = HCMD_MARCH; }
+            __syncthreads();
+            heavyMarch(col, st);
+            __syncthreads();
+            if (lane == 0) hv.cmd = HCMD_NONE;
+            hCount = 0;
+            if (!(stackSize > 0 || rangeCount > 0 || candCount > 0)) break;
+        }
+        // rebuild each hit ray's record from its winning (toi, visit rank): the FINAL evaluation of that triangle again
+        if (lane < R && rayHit(lane)) {
+            const unsigned long long key = sh.rayKey[lane];
+            const float tHit = __uint_as_float((unsigned)(key >> 32));
+            const Tri tri = loadTri(col, col.slotOfRank[(unsigned)(key & 0xffffffffull)]);
+            const F3 from = sh.rayFrom[lane], dir = sh.rayDir[lane];
+            const F3 triNormal = normalize(cross(tri.v1 - tri.v0, tri.v2 - tri.v0));
+            F3 center = from + dir * tHit;
+            F3 segP, triP;
+            float dist = segmentTriangleDistance(center, halfHeight, tri.v0, tri.v1, tri.v2, segP, triP);
+            F3 nrm;
+            if (dist < 1e-6f) nrm = dot(triNormal, dir) > 0 ? -triNormal : triNormal;
+            else nrm = normalize(segP - triP);
+            F3 triN = triNormal;
+            if (dot(triN, nrm) < 0) triN = -triN;
+            sh.rayRec[lane] = CastRec{tHit, triP, nrm, triN, tri.triIndex};
+        }
+        __syncthreads();
+        return;
+    }
     // Streaming sweep: every lane owns one (ray, triangle) work item at a time and pulls the next one from the
     // LDS queue the moment its own finishes, so a query with hundreds of candidates keeps all 64 lanes marching
     // instead of waiting, batch after batch, for each batch's slowest lane (conservative advancement runs up to
@@ -365,8 +560,6 @@ __device__ __forceinline__ void waveCastRays(const DevCollision& col, float radi
 #endif
 }
 
-// one capsuleCastCombined (CollisionQuery.swift:980-1009)
-__device__ __forceinline__ bool rayHit(int r) { return (unsigned)(sh.rayKey[r] & 0xffffffffull) != 0xffffffffu; }
 
 // ---------------------------------------------------------------------------
 // capsuleOverlapAll over the static set (CollisionQuery.swift:852-882, 1201-1283):
@@ -1137,15 +1330,26 @@ static_assert(sizeof(MoveState) <= kMoveScratchBytes, "MoveLaunch::scratch strid
 //   PART 0  intent, gravity, VelocityGate, contact-cache decay and the pre-sweep depenetration (overlap queries only)
 //   PART 1  the slide iterations, the ground probe and the write-back (cast passes only)
 // The LDS-resident MoveState crosses the boundary through K.scratch (256 B per character).
-template <int PART, bool AGENTS>
+template <int PART, bool AGENTS, bool HEAVY = false>
 #ifndef SGE_MOVE_WAVES1
 #define SGE_MOVE_WAVES1 3
 #endif
-__global__ __launch_bounds__(kWave, PART == 0 ? 4 : SGE_MOVE_WAVES1) void move_kernel(MoveLaunch K) {
-    const int e = K.first + blockIdx.x;
+__global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? 4 : (HEAVY ? 1 : SGE_MOVE_WAVES1)) void move_kernel(MoveLaunch K) {
+    // PART 1 may run over an index list (light / heavy characters of this step, see classify_kernel)
+    if (PART == 1 && K.list && (int)blockIdx.x >= *K.listCount) return;
+    const int e = (PART == 1 && K.list) ? K.list[blockIdx.x] : K.first + (int)blockIdx.x;
     const int lane = laneId();
     WaveStats st{0, 0, 0, 0, 0, 0};
     const DevCollision& col = K.col;
+    if (HEAVY) {
+        if (threadIdx.x == 0) { hv.cmd = HCMD_NONE; hv.evalSum = 0; }
+        __syncthreads();
+        if (threadIdx.x >= kWave) { // helper waves
+            heavyHelperLoop(col, st);
+            if (K.stats && lane == 0 && st.trips) atomicAdd(&statShard(K.stats)[5], (unsigned long long)st.trips);
+            return;
+        }
+    }
 #ifdef SGE_CCD_TIMING
     const long long tStart = (long long)__builtin_amdgcn_s_memtime();
 #endif
@@ -1271,7 +1475,7 @@ __global__ __launch_bounds__(kWave, PART == 0 ? 4 : SGE_MOVE_WAVES1) void move_k
         // ---------------- 2. the query ----------------
         int nOverlap = 0;
         if (PART == 0 && doOverlap) nOverlap = waveCapsuleOverlapAll(col, ms.position, P.radius, P.halfHeight, 8, P.collisionMask, st);
-        if (PART == 1 && doCast) waveCastRays(col, P.radius, P.halfHeight, blocking, !blocking, P.minGroundDot, P.collisionMask, st);
+        if (PART == 1 && doCast) waveCastRays<HEAVY>(col, P.radius, P.halfHeight, blocking, !blocking, P.minGroundDot, P.collisionMask, st);
         // ---------------- 3. consume ----------------
         if (PART == 0) consumeDepen(nOverlap);
         else if (phase == MP_SLIDE) {
@@ -1308,6 +1512,18 @@ __global__ __launch_bounds__(kWave, PART == 0 ? 4 : SGE_MOVE_WAVES1) void move_k
         atomicAdd(&g_cycTotal, (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - tStart));
     }
 #endif
+    if (HEAVY) { // release the helper waves
+        if (lane == 0) hv.cmd = HCMD_EXIT;
+        __syncthreads();
+    }
+    {
+        // evals are counted per lane; sum over the wave
+        unsigned v = st.evals;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+        // this step's sweep cost decides which kernel takes the character next step
+        if (PART == 1 && K.cost && lane == 0) K.cost[e] = HEAVY ? (int)hv.evalSum : (int)v;
+    }
     if (K.stats) {
         // evals are counted per lane; sum over the wave
         unsigned v = st.evals;
@@ -1330,12 +1546,49 @@ __global__ __launch_bounds__(kWave, PART == 0 ? 4 : SGE_MOVE_WAVES1) void move_k
     }
 }
 
+// Sorts this step's characters into the one-wave list and the four-wave list by last step's sweep cost.
+// lists: [2][count] (light, heavy); counts: [2], zeroed before the launch. Order inside a list is arbitrary (atomics);
+// results do not depend on it.
+__global__ void classify_kernel(const int* cost, int first, int count, int threshold, int heavyCap, int* lists, int* counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int e = first + i;
+    bool heavy = cost[e] > threshold;
+    if (heavy) {
+        int pos = atomicAdd(&counts[1], 1);
+        if (pos < heavyCap) { lists[count + pos] = e; return; }
+        atomicSub(&counts[1], 1);
+    }
+    lists[atomicAdd(&counts[0], 1)] = e;
+}
+
 void launch_move(const MoveLaunch& L, hipStream_t s) {
     if (L.count <= 0) return;
     hipLaunchKernelGGL((move_kernel<0, false>), dim3(L.count), dim3(kWave), 0, s, L);
     if (!(L.stages & SGE_STAGE_MOVE)) return;
-    if ((L.stages & SGE_STAGE_AGENTS) && L.agents.all) hipLaunchKernelGGL((move_kernel<1, true>), dim3(L.count), dim3(kWave), 0, s, L);
-    else hipLaunchKernelGGL((move_kernel<1, false>), dim3(L.count), dim3(kWave), 0, s, L);
+    const bool agents = (L.stages & SGE_STAGE_AGENTS) && L.agents.all;
+    if (!L.lists) {
+        if (agents) hipLaunchKernelGGL((move_kernel<1, true>), dim3(L.count), dim3(kWave), 0, s, L);
+        else hipLaunchKernelGGL((move_kernel<1, false>), dim3(L.count), dim3(kWave), 0, s, L);
+        return;
+    }
+    // heavy characters first, on their own stream, so that their long single-character sweeps overlap the rest
+    (void)hipMemsetAsync(L.listCounts, 0, 2 * sizeof(int), s);
+    hipLaunchKernelGGL(classify_kernel, dim3((L.count + 255) / 256), dim3(256), 0, s, L.cost, L.first, L.count, L.heavyThreshold,
+                       L.heavyCap, L.lists, L.listCounts);
+    (void)hipEventRecord(L.evClassified, s);
+    (void)hipStreamWaitEvent(L.heavyStream, L.evClassified, 0);
+    MoveLaunch H = L;
+    H.list = L.lists + L.count; H.listCount = L.listCounts + 1;
+    const int heavyGrid = L.count < L.heavyCap ? L.count : L.heavyCap;
+    if (agents) hipLaunchKernelGGL((move_kernel<1, true, true>), dim3(heavyGrid), dim3(kWave * kHeavyWaves), 0, L.heavyStream, H);
+    else hipLaunchKernelGGL((move_kernel<1, false, true>), dim3(heavyGrid), dim3(kWave * kHeavyWaves), 0, L.heavyStream, H);
+    (void)hipEventRecord(L.evHeavyDone, L.heavyStream);
+    MoveLaunch G = L;
+    G.list = L.lists; G.listCount = L.listCounts;
+    if (agents) hipLaunchKernelGGL((move_kernel<1, true>), dim3(L.count), dim3(kWave), 0, s, G);
+    else hipLaunchKernelGGL((move_kernel<1, false>), dim3(L.count), dim3(kWave), 0, s, G);
+    (void)hipStreamWaitEvent(s, L.evHeavyDone, 0);
 }
 
 // ---- batched single queries (the CollisionQuery facade) ---------------------

@@ -85,6 +85,7 @@ struct DevCollision {
     // follows the reference's own traversal order; binRoot < 0: empty set; binSlotBase: the set's first slot in `tris`
     const DevNode* binNodes[2];
     int binRoot[2], binSlotBase[2];
+    const int* slotOfRank;          // slot in `tris` of the triangle with a given (offset) visit rank
 };
 
 struct DevCrowd {
@@ -153,6 +154,12 @@ struct MoveLaunch {
     void* scratch;             // [count] x kMoveScratchBytes: per-character working set between the two launches
     const sge_platform_state* platforms; // PlatformCarry inputs of this step
     int platformCount;
+    // light / heavy split of part 1 (sge_ccd.hip, "heavy characters"); lists == nullptr: one launch over [first, first+count)
+    int* cost;                 // [crowd.count] distance evaluations of each character's last step
+    int* lists; int* listCounts; // [2][count] indices + [2] lengths, filled by classify_kernel
+    int heavyThreshold, heavyCap;
+    hipStream_t heavyStream; hipEvent_t evClassified, evHeavyDone;
+    const int* list; const int* listCount; // what a part-1 launch iterates over (set by launch_move)
 };
 constexpr int kMoveScratchBytes = 256;
 constexpr int kStatShards = 256; // device counters: kStatShards lines of 8 x u64

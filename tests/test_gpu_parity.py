@@ -449,6 +449,39 @@ def test_kinematic_platforms_tick_parity(sge):
     cpu.close()
 
 
+@pytest.mark.parametrize("real", [False, True])
+def test_heavy_four_wave_kernel_parity(sge, real):
+    """SGE_OPT_HEAVY_THRESHOLD = 0 sends every character through the four-wave kernel from its second step on (the
+    default sends only the expensive ones): scheduling must not change a single bit of the result."""
+    gpu = sge.CharacterEngine(0)
+    cpu = ob.oracle_engine()
+    gpu.set_option(sge.abi.OPT_HEAVY_THRESHOLD, 0)
+    n = 96
+    for e in (gpu, cpu):
+        if real:
+            build_scene(sge, e, n, seed=9, mixed=True, rings=3, segments=3, asset_scene=("cheese", "mirror"))
+        else:
+            build_scene(sge, e, n, terrain_cells=(56, 40), seed=31, mixed=True, rings=3, segments=3, agents=True)
+    st = sge.abi.STAGE_ALL & ~sge.abi.STAGE_SKIN
+    for s in range(140):
+        gpu.tick(stages=st)
+        ob.tick_mt(cpu, 8, stages=st)
+        if s in (0, 1, 2, 10, 60, 139):
+            gpu.synchronize()
+            compare_states(sge, gpu, cpu, n)
+    stats = gpu.move_stats()
+    assert stats.overflow == 0 and stats.sweepTrips > 0
+    # and back to the one-wave kernel mid-run
+    gpu.set_option(sge.abi.OPT_HEAVY_THRESHOLD, -1)
+    for s in range(20):
+        gpu.tick(stages=st)
+        ob.tick_mt(cpu, 8, stages=st)
+    gpu.synchronize()
+    compare_states(sge, gpu, cpu, n)
+    gpu.close()
+    cpu.close()
+
+
 def test_full_size_properties(sge):
     """BASELINE.json configs[2] at full size (10k clones x 14,080 vertices vs 71,680 triangles), checked through
     size-independent properties: characters are independent, so an oracle run over a RANDOM SUBSET of the crowd
