@@ -46,8 +46,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only to rehearse N>1 on one GPU")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-chars", type=int, default=384)
-    ap.add_argument("--cpu-sample-steps", type=int, default=8)
+    ap.add_argument("--cpu-sample-chars", type=int, default=2048)
+    ap.add_argument("--cpu-sample-steps", type=int, default=16)
     args = ap.parse_args()
 
     import numpy as np
