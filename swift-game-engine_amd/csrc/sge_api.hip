@@ -276,12 +276,15 @@ sge_context* sge_context_create(int device_index) {
     if (hipSetDevice(device_index) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
     sge_context* c = new sge_context();
     c->device = device_index;
-    if (hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
+    // the latency-bound collision / pose launches go first when they compete with a streaming skin launch (overlap option)
+    int prLeast = 0, prGreatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest);
+    if (hipStreamCreateWithPriority(&c->ownStream, hipStreamNonBlocking, prGreatest) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
     c->stream = c->ownStream;
-    if (hipStreamCreateWithFlags(&c->skinStream, hipStreamNonBlocking) != hipSuccess ||
+    if (hipStreamCreateWithPriority(&c->skinStream, hipStreamNonBlocking, prLeast) != hipSuccess ||
         hipEventCreateWithFlags(&c->evPoseDone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evSkinDone, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->heavyStream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->heavyStream, hipStreamNonBlocking, prGreatest) != hipSuccess ||
         hipEventCreateWithFlags(&c->evClassified, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evHeavyDone, hipEventDisableTiming) != hipSuccess) { set_error("stream/event creation failed"); delete c; return nullptr; }
     if (c->dStats.alloc((size_t)kStatShards * 64) != SGE_OK || hipMemsetAsync(c->dStats.p, 0, (size_t)kStatShards * 64, c->stream) != hipSuccess) { delete c; return nullptr; }
