@@ -1332,7 +1332,7 @@ static_assert(sizeof(MoveState) <= kMoveScratchBytes, "MoveLaunch::scratch strid
 // The LDS-resident MoveState crosses the boundary through K.scratch (256 B per character).
 template <int PART, bool AGENTS, bool HEAVY = false>
 #ifndef SGE_MOVE_WAVES1
-#define SGE_MOVE_WAVES1 3
+#define SGE_MOVE_WAVES1 4
 #endif
 __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? 4 : (HEAVY ? 1 : SGE_MOVE_WAVES1)) void move_kernel(MoveLaunch K) {
     // PART 1 may run over an index list (light / heavy characters of this step, see classify_kernel)
