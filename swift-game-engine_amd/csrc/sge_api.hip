@@ -564,6 +564,8 @@ MergedLayout mergedLayout(const sge_context* c) {
 int uploadCollisionAll(sge_context* c) {
     const MergedLayout L = mergedLayout(c);
     if (c->hostCol.maxDepth > 120 || c->hostDyn.maxDepth > 120) { set_error("BVH deeper than the traversal stack policy allows"); return SGE_ERR_CAPACITY; }
+    // a traversal pops the newest node first, so at most 63 siblings stay pending per wide level (+ the other set's root)
+    if (std::max(c->hostCol.wideLevels, c->hostDyn.wideLevels) * 63 + 2 > kTraversalStackCap) { set_error("triangle set too large for the traversal stack"); return SGE_ERR_CAPACITY; }
     std::vector<DevTri> ts, td;
     std::vector<DevNode> ws, wd;
     std::vector<DevMaterial> ms, md;

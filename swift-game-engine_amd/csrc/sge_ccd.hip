@@ -36,7 +36,7 @@
 namespace sge {
 
 constexpr int kWave = 64;
-constexpr int kStackCap = 256;   // wide nodes pending (each pop adds <= 64)
+constexpr int kStackCap = kTraversalStackCap; // wide nodes pending (each pop adds <= 64; sge_api checks the tree depth against it)
 constexpr int kCandCap = 512;
 constexpr int kRangeCap = 128;
 constexpr int kItemCap = 512;

@@ -262,6 +262,7 @@ void HostCollision::reboundWide() {
 
 void HostCollision::buildWide() {
     wide.clear(); wideBinary.clear();
+    wideLevels = 0;
     if (root < 0) return;
     const int N = (int)nodes.size();
     std::vector<int> cnt(N), lo(N);
@@ -270,8 +271,9 @@ void HostCollision::buildWide() {
         if (n.left < 0) { cnt[i] = n.count; lo[i] = n.start; }
         else { cnt[i] = cnt[n.left] + cnt[n.right]; lo[i] = std::min(lo[n.left], lo[n.right]); }
     }
-    struct Job { int binary, wideIndex; };
-    std::vector<Job> jobs{{root, 0}};
+    struct Job { int binary, wideIndex, level; };
+    std::vector<Job> jobs{{root, 0, 1}};
+    wideLevels = 1;
     wide.resize(kWideWidth);
     wideBinary.assign(kWideWidth, -1);
     for (size_t q = 0; q < jobs.size(); ++q) {
@@ -298,7 +300,8 @@ void HostCollision::buildWide() {
                     int w = (int)(wide.size() / kWideWidth);
                     wide.resize(wide.size() + kWideWidth);
                     wideBinary.resize(wide.size(), -1);
-                    jobs.push_back({b, w});
+                    jobs.push_back({b, w, jobs[q].level + 1});
+                    wideLevels = std::max(wideLevels, jobs[q].level + 1);
                     d.a = w; d.b = 0;
                 }
             }

@@ -138,6 +138,7 @@ struct HostCollision {
     int maxDepth = 0;
     std::vector<DevNode> wide;      // flattened wide nodes, kWideWidth entries each
     std::vector<int> wideBinary;    // binary node behind every wide entry (-1: padding), to re-bound after a refit
+    int wideLevels = 0;             // depth of the wide tree (a depth-first traversal keeps <= 63 siblings pending per level)
     void rebuild(const sge_static_mesh_entity* ents, int count);
     void buildWide();
     // TriangleMeshSet.updateTransforms + BVH.refit (CollisionQuery.swift:419-462, 528-575); returns #updated triangles
@@ -162,6 +163,7 @@ struct MoveLaunch {
     const int* list; const int* listCount; // what a part-1 launch iterates over (set by launch_move)
 };
 constexpr int kMoveScratchBytes = 256;
+constexpr int kTraversalStackCap = 256; // LDS stack of pending wide nodes per query (sge_ccd.hip)
 constexpr int kStatShards = 256; // device counters: kStatShards lines of 8 x u64
 void launch_move(const MoveLaunch& L, hipStream_t s);
 void launch_cast_queries(const DevCollision& col, const sge_capsule_query* d_q, int n, sge_capsule_cast_hit* d_out,

@@ -5,6 +5,8 @@ Bars (BASELINE.json north_star: 1e-5 relative):
     (both sides run IEEE float32 in the same order with contraction off);
   - palettes and skinned vertices: |gpu - cpu| <= 1e-5 * max|cpu| (libm vs OCML trig, FMA in the LBS kernel).
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -544,3 +546,60 @@ def test_full_size_properties(sge):
     assert np.abs(gp - cp).max() <= REL * np.abs(cp).max()
     gpu.close()
     cpu.close()
+
+
+def test_api_edge_cases(sge):
+    """Empty crowd, empty world, state errors and argument checks of the C ABI (status codes, no crashes)."""
+    gpu = sge.CharacterEngine(0)
+    ybot = sge.assets.YBotAssets()
+    lib, h = gpu.t.lib, gpu.h
+    # nothing uploaded yet: an empty tick is fine, stages that need assets report a state error
+    gpu.resize(0)
+    gpu.tick()
+    gpu.resize(4)
+    with pytest.raises(sge.SgeError):
+        gpu.tick(stages=sge.abi.STAGE_POSE)
+    with pytest.raises(sge.SgeError):
+        gpu.tick(stages=sge.abi.STAGE_SKIN)
+    # an empty collision world: characters simply fall
+    sge.crowd.upload_character_assets(gpu, ybot, rings=3, segments=3)
+    gpu.rebuild_static([])
+    assert gpu.collision_counts() == (0, 0, 0)
+    q = sge.make_queries(np.zeros((3, 3), np.float32), np.array([[0, -5, 0]] * 3, np.float32))
+    assert gpu.capsule_cast(q)["hit"].sum() == 0 and gpu.capsule_overlap_all(q, 8)[1].sum() == 0
+    assert gpu.raycast(np.zeros((2, 3), np.float32), np.array([[0, -1, 0]] * 2, np.float32), 10.0)["hit"].sum() == 0
+    state = {"bodies": sge.assets.default_bodies(4, np.zeros((4, 3))), "params": sge.assets.default_controller_params(4),
+             "controllers": sge.assets.default_controller_state(4), "intents": sge.assets.default_intents(4),
+             "locomotion": sge.assets.default_locomotion(4, ybot), "actions": sge.assets.default_actions(4, ybot, present=True)}
+    gpu.upload(**state)
+    for _ in range(30):
+        gpu.tick()
+    d = gpu.download(what=("bodies", "controllers", "locomotion"))
+    assert (d["bodies"]["position"][:, 1] < -5).all() and (d["controllers"]["flags"] & sge.abi.CTRL_GROUNDED).sum() == 0
+    assert (d["locomotion"]["state"] == sge.abi.LOCO_FALLING).all()
+    # static bodies are skipped by the move stage (Systems.swift:1845)
+    state["bodies"]["bodyType"][:2] = sge.abi.BODY_STATIC
+    gpu.upload(**state)
+    gpu.tick()
+    y = gpu.download(what=("bodies",))["bodies"]["position"][:, 1]
+    assert (y[:2] == 0).all() and (y[2:] < 0).all()
+    # argument checks
+    assert lib.sge_characters_resize(h, -1) != 0
+    assert lib.sge_capsule_overlap_all_batch(h, None, 1, 8, None, None) != 0
+    qq = np.ascontiguousarray(q)
+    out = np.zeros((3, 9), sge.abi.overlap_hit_dtype)
+    cnt = np.zeros(3, np.int32)
+    assert lib.sge_capsule_overlap_all_batch(h, sge.abi.ptr(qq), 3, 9, sge.abi.ptr(out), sge.abi.ptr(cnt)) != 0   # max_hits > 8
+    assert lib.sge_capsule_overlap_all_batch(h, sge.abi.ptr(qq), 3, 0, sge.abi.ptr(out), sge.abi.ptr(cnt)) != 0
+    assert lib.sge_collision_update_transforms(h, 2, None, None, 0) != 0                                         # unknown set
+    too_many = np.zeros(sge.abi.SGE_MAX_PLATFORMS + 1, sge.abi.platform_dtype)
+    assert lib.sge_platforms_upload(h, sge.abi.ptr(too_many), too_many.shape[0]) != 0
+    bad = {"positions": np.zeros((3, 3), np.float32), "indices": np.array([0, 1, 7], np.uint32)}
+    with pytest.raises(sge.SgeError):
+        gpu.rebuild_static([bad])
+    assert b"index out of range" in lib.sge_last_error()
+    d = sge.abi.TickDesc()
+    d.dt, d.stages, d.first, d.count = 1 / 60, sge.abi.STAGE_ALL, 3, 5                                          # range past the crowd
+    assert lib.sge_tick(h, C.byref(d)) != 0
+    assert lib.sge_context_set_option(h, 99, 1) != 0
+    gpu.close()
