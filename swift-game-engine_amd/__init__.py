@@ -6,5 +6,5 @@ include/sge_amd.h), the ctypes mirror of that ABI (abi.py), the host driver
 preparation (assets.py). The directory name carries a hyphen, so import it with
 importlib.import_module("swift-game-engine_amd").
 """
-from . import abi, assets, crowd, engine, exporters, fbx, formats, parallel  # noqa: F401
+from . import abi, assets, crowd, engine, exporters, fbx, formats, parallel, services  # noqa: F401
 from .engine import CharacterEngine, SgeError, make_queries  # noqa: F401

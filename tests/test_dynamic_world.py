@@ -212,3 +212,61 @@ def test_character_rides_a_moving_platform(sge, ybot, cpu):
     assert rider[1] == pytest.approx(2 + 0.5 + 2.5 + 0.05, abs=0.05)                    # standing on its top (groundSnapSkin above)
     assert d["controllers"]["groundTriangleIndex"][0] >= 2                              # a dynamic-set triangle
     assert np.allclose(bystander[[0, 2]], (40, 40), atol=1e-3) and bystander[1] == pytest.approx(-3 + 2.5 + 0.05, abs=0.05)
+
+
+def test_collision_query_service_decisions(sge, cpu):
+    """CollisionQueryService (SceneServices.swift:33-207): rebuild vs transform update, from the entity snapshot."""
+    A = sge.abi
+    gp, gi, _ = sge.assets.ground_plane()
+    box = box_mesh(2, 0.5, 2)
+    ident = (0, 0, 0, 1)
+    world = [
+        {"id": 1, "translation": (0, -3, 0), "rotation": ident, "scale": (1, 1, 1), "positions": gp, "indices": gi, "bodyType": A.BODY_STATIC},
+        {"id": 2, "translation": (5, 1, 0), "rotation": ident, "scale": (1, 1, 1), "positions": box[0], "indices": box[1]},            # no body: static set
+        {"id": 3, "translation": (-5, 2, 0), "rotation": ident, "scale": (1, 1, 1), "positions": box[0], "indices": box[1],
+         "bodyType": A.BODY_KINEMATIC, "platform": True, "position": (-5, 2, 0), "prevPosition": (-5, 2, 0), "layer": 2},
+        {"id": 4, "translation": (0, 9, 0), "rotation": ident, "scale": (1, 1, 1), "positions": box[0], "indices": box[1], "collides": False},
+    ]
+    svc = sge.services.CollisionQueryService(cpu)
+    svc.update(world)                                   # first call: no query yet -> rebuild
+    assert svc.log == ["rebuild"] and cpu.collision_counts()[1] == 2 + 12 and cpu.collision_counts(A.SET_DYNAMIC)[1] == 12
+    assert svc.slot == {1: (A.SET_STATIC, 0), 2: (A.SET_STATIC, 1), 3: (A.SET_DYNAMIC, 0)}
+    svc.update(world)
+    assert svc.log == []                                # nothing moved
+    world[2]["translation"] = (-4.5, 2, 0)              # the kinematic platform moved
+    world[2]["prevPosition"], world[2]["position"] = (-5, 2, 0), (-4.5, 2, 0)
+    svc.update(world)
+    assert svc.log == [("dynamic", [3])]
+    probe = sge.make_queries(np.array([[-4.5 + 1.9, 8, 0], [-5 - 1.9, 8, 0]], np.float32), np.array([[0, -5.4, 0]] * 2, np.float32), radius=0.25, half_height=0.25)
+    assert cpu.capsule_cast(probe)["hit"].tolist() == [1, 0]     # the refitted set is where the platform now is
+    pf = svc.upload_platforms(world)
+    assert pf.shape[0] == 1 and pf[0]["kinematic"] == 1 and np.allclose(pf[0]["delta"], (0.5, 0, 0))
+    assert np.allclose(pf[0]["aabbMin"], (-6.5, 1.5, -2)) and np.allclose(pf[0]["aabbMax"], (-2.5, 2.5, 2))
+    world[1]["rotation"] = tuple(sge.formats.quat_angle_axis(0.3, (0, 1, 0)))   # a static prop turned: static-set update
+    world[2]["scale"] = (1, 2, 1)
+    svc.update(world)
+    assert sorted(svc.log) == [("dynamic", [3]), ("static", [2])]
+    tiny = dict(world[1], translation=(5 + 5e-4, 1, 0))                           # |delta|^2 <= 1e-6: not a change
+    world[1] = tiny
+    svc.update(world)
+    assert svc.log == []
+    # structural changes -> rebuild
+    for change in ("collides", "body", "mesh", "dirty", "added", "active", "marked"):
+        if change == "collides":
+            world[3]["collides"] = True
+        elif change == "body":
+            world[1]["bodyType"] = A.BODY_DYNAMIC
+        elif change == "mesh":
+            world[1]["indices"] = box[1][:-3]
+        elif change == "dirty":
+            world[0]["dirty"] = True
+        elif change == "added":
+            world.append(dict(world[1], id=9))
+        elif change == "marked":
+            svc.mark_dirty()
+        svc.update(world, active_ids={1, 2, 3} if change == "active" else None)
+        assert svc.log == ["rebuild"], change
+        svc.update(world, active_ids={1, 2, 3} if change == "active" else None)
+        assert svc.log == [], change
+    assert world[0]["dirty"] is False
+    assert cpu.collision_counts(A.SET_DYNAMIC)[1] == 12 + 11 + 11      # platform, the re-typed prop (one triangle dropped), its copy
