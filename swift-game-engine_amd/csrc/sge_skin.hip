@@ -94,13 +94,11 @@ __global__ __launch_bounds__(kSkinBlock) void skin_kernel(SkinLaunch L, int spli
     __syncthreads();
 
     const size_t obase = (size_t)L.dstBaseVertex + (size_t)c * L.vertexCount;
-    for (; gid < vEnd; gid += kSkinBlock) {
-        VertexIn nxt = cur;
-        const int gnext = gid + kSkinBlock;
-        if (gnext < vEnd) nxt = loadVertex<SRC_STRIDE>(L, gnext);
 
-        const float3 p = cur.p, n = cur.n;
-        const float3 tv = make_float3(cur.t.x, cur.t.y, cur.t.z);
+    // one vertex: blend the influences' matrices, transform position / normal / tangent once, stream the result out
+    auto skinOne = [&](const VertexIn& v, int g) {
+        const float3 p = v.p, n = v.n;
+        const float3 tv = make_float3(v.t.x, v.t.y, v.t.z);
 #ifdef SGE_SKIN_PER_INFLUENCE
         // the Metal kernel's literal order: transform by every influence's matrix, then blend the results
         float3 acc = make_float3(0.f, 0.f, 0.f), nAcc = acc, tAcc = acc;
@@ -112,35 +110,40 @@ __global__ __launch_bounds__(kSkinBlock) void skin_kernel(SkinLaunch L, int spli
             nAcc.x += b.x * (WGT); nAcc.y += b.y * (WGT); nAcc.z += b.z * (WGT); \
             tAcc.x += d.x * (WGT); tAcc.y += d.y * (WGT); tAcc.z += d.z * (WGT); \
         }
-        SGE_INFLUENCE(cur.idx.x, cur.w.x)
-        SGE_INFLUENCE(cur.idx.y, cur.w.y)
-        SGE_INFLUENCE(cur.idx.z, cur.w.z)
-        SGE_INFLUENCE(cur.idx.w, cur.w.w)
+        SGE_INFLUENCE(v.idx.x, v.w.x)
+        SGE_INFLUENCE(v.idx.y, v.w.y)
+        SGE_INFLUENCE(v.idx.z, v.w.z)
+        SGE_INFLUENCE(v.idx.w, v.w.w)
 #undef SGE_INFLUENCE
 #else
-        // blend the influences' matrices first (12 FMAs each), then transform position, normal and tangent once:
-        // sum_j w_j (M_j v) = (sum_j w_j M_j) v — the same linear map with a third of the multiplies at 2-3 influences
-        // (rounding differs from the per-influence order by ~1e-7 relative, inside the 1e-5 parity bound)
+        // sum_j w_j (M_j v) = (sum_j w_j M_j) v: blend the matrices (12 FMAs per influence), transform once. The first two
+        // influences are taken unconditionally with the weight clamped at 0 (a weight <= 0 contributes exactly nothing, as
+        // the reference's `w > 0` test does); the rarer third and fourth stay behind their tests.
+        const float w0 = fmaxf(v.w.x, 0.0f), w1 = fmaxf(v.w.y, 0.0f);
         Row3 M;
-        M.r0 = M.r1 = M.r2 = make_float4(0.f, 0.f, 0.f, 0.f);
-#define SGE_INFLUENCE(BONE, WGT)                                              \
-        if ((WGT) > 0.0f) {                                                   \
+        {
+            const Row3 m = loadRows(pal, v.idx.x);
+            M.r0 = make_float4(m.r0.x * w0, m.r0.y * w0, m.r0.z * w0, m.r0.w * w0);
+            M.r1 = make_float4(m.r1.x * w0, m.r1.y * w0, m.r1.z * w0, m.r1.w * w0);
+            M.r2 = make_float4(m.r2.x * w0, m.r2.y * w0, m.r2.z * w0, m.r2.w * w0);
+        }
+#define SGE_BLEND(BONE, WGT)                                                  \
+        {                                                                     \
             const Row3 m = loadRows(pal, (BONE));                             \
             M.r0.x += m.r0.x * (WGT); M.r0.y += m.r0.y * (WGT); M.r0.z += m.r0.z * (WGT); M.r0.w += m.r0.w * (WGT); \
             M.r1.x += m.r1.x * (WGT); M.r1.y += m.r1.y * (WGT); M.r1.z += m.r1.z * (WGT); M.r1.w += m.r1.w * (WGT); \
             M.r2.x += m.r2.x * (WGT); M.r2.y += m.r2.y * (WGT); M.r2.z += m.r2.z * (WGT); M.r2.w += m.r2.w * (WGT); \
         }
-        SGE_INFLUENCE(cur.idx.x, cur.w.x)
-        SGE_INFLUENCE(cur.idx.y, cur.w.y)
-        SGE_INFLUENCE(cur.idx.z, cur.w.z)
-        SGE_INFLUENCE(cur.idx.w, cur.w.w)
-#undef SGE_INFLUENCE
+        SGE_BLEND(v.idx.y, w1)
+        if (v.w.z > 0.0f) SGE_BLEND(v.idx.z, v.w.z)
+        if (v.w.w > 0.0f) SGE_BLEND(v.idx.w, v.w.w)
+#undef SGE_BLEND
         const float3 acc = xform(M, p, 1.0f), nAcc = xform(M, n, 0.0f), tAcc = xform(M, tv, 0.0f);
 #endif
-        float3 nn = normalizeFast(nAcc);
-        float3 tn = normalizeFast(tAcc);
+        const float3 nn = normalizeFast(nAcc);
+        const float3 tn = normalizeFast(tAcc);
 
-        const size_t o = obase + gid;
+        const size_t o = obase + g;
         float* op = reinterpret_cast<float*>(L.outPos) + o * DST_STRIDE;
         float* on = reinterpret_cast<float*>(L.outNrm) + o * DST_STRIDE;
 #ifndef SGE_SKIN_PLAIN_STORES
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(kSkinBlock) void skin_kernel(SkinLaunch L, int spli
             __builtin_nontemporal_store(acc.x, op); __builtin_nontemporal_store(acc.y, op + 1); __builtin_nontemporal_store(acc.z, op + 2);
             __builtin_nontemporal_store(nn.x, on); __builtin_nontemporal_store(nn.y, on + 1); __builtin_nontemporal_store(nn.z, on + 2);
         }
-        __builtin_nontemporal_store(v4f{tn.x, tn.y, tn.z, cur.t.w}, reinterpret_cast<v4f*>(L.outTan) + o);
+        __builtin_nontemporal_store(v4f{tn.x, tn.y, tn.z, v.t.w}, reinterpret_cast<v4f*>(L.outTan) + o);
 #else
         if (DST_STRIDE == 4) {
             *reinterpret_cast<float4*>(op) = make_float4(acc.x, acc.y, acc.z, 0.f);
@@ -161,9 +164,25 @@ __global__ __launch_bounds__(kSkinBlock) void skin_kernel(SkinLaunch L, int spli
             op[0] = acc.x; op[1] = acc.y; op[2] = acc.z;
             on[0] = nn.x; on[1] = nn.y; on[2] = nn.z;
         }
-        reinterpret_cast<float4*>(L.outTan)[o] = make_float4(tn.x, tn.y, tn.z, cur.t.w);
+        reinterpret_cast<float4*>(L.outTan)[o] = make_float4(tn.x, tn.y, tn.z, v.t.w);
 #endif
-        cur = nxt;
+    };
+
+    // two-deep software pipeline written out, so that the chunk in flight never has to be copied between registers
+    if (gid >= vEnd) return;
+    VertexIn nxt{};
+    while (true) {
+        const int g1 = gid + kSkinBlock;
+        const bool has1 = g1 < vEnd;
+        if (has1) nxt = loadVertex<SRC_STRIDE>(L, g1);
+        skinOne(cur, gid);
+        if (!has1) break;
+        const int g2 = g1 + kSkinBlock;
+        const bool has2 = g2 < vEnd;
+        if (has2) cur = loadVertex<SRC_STRIDE>(L, g2);
+        skinOne(nxt, g1);
+        if (!has2) break;
+        gid = g2;
     }
 }
 
