@@ -229,6 +229,9 @@ enum {
     SGE_OPT_HEAVY_THRESHOLD = 5,  /* distance evaluations in a character's previous step above which its slide / ground
                                    * pass runs in the four-wave kernel (default 4000; 0: every character that swept
                                    * anything; < 0: always the one-wave kernel). Scheduling only: results are identical. */
+    SGE_OPT_PLACEMENT_PROBES = 6, /* how many candidate placements of the skinned output streams are timed when they are
+                                   * (re)allocated; the fastest is kept (default 8, stops early at 6.5 TB/s; <= 1: take the
+                                   * first). Takes effect at the next sge_characters_resize / layout change. */
     SGE_OPT_OVERLAP_SKIN = 4      /* 1: run the skin stage on a second stream so that it overlaps the next
                                      step's move stage (ignored on a caller-provided stream) */
 };

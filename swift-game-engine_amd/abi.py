@@ -37,7 +37,7 @@ STAGE_INTENT, STAGE_GRAVITY, STAGE_MOVE, STAGE_LOCOMOTION = 1, 2, 4, 8
 STAGE_ACTION, STAGE_POSE, STAGE_WRITEBACK, STAGE_SKIN, STAGE_AGENTS = 16, 32, 64, 128, 256
 STAGE_ALL_FIXED, STAGE_ALL = 0x7F, 0xFF
 # options
-OPT_STORE_POSE_DEBUG, OPT_SKIN_LAYOUT, OPT_PROFILE, OPT_OVERLAP_SKIN, OPT_HEAVY_THRESHOLD = 1, 2, 3, 4, 5
+OPT_STORE_POSE_DEBUG, OPT_SKIN_LAYOUT, OPT_PROFILE, OPT_OVERLAP_SKIN, OPT_HEAVY_THRESHOLD, OPT_PLACEMENT_PROBES = 1, 2, 3, 4, 5, 6
 LAYOUT_PACKED, LAYOUT_PADDED16 = 0, 1
 
 f32, f64, i32, u32, u8, u16, i64, u64 = (C.c_float, C.c_double, C.c_int32, C.c_uint32, C.c_uint8,

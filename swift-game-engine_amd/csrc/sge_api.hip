@@ -7,6 +7,8 @@
 #include <cstring>
 #include <map>
 #include <vector>
+#include <cstdio>
+#include <cstdlib>
 #include "sge_internal.hpp"
 
 namespace sge {
@@ -51,6 +53,8 @@ struct sge_context {
     hipEvent_t evPoseDone = nullptr, evSkinDone = nullptr;
     hipStream_t heavyStream = nullptr; // part 1 of the move stage for the step's heavy characters
     hipEvent_t evClassified = nullptr, evHeavyDone = nullptr;
+    int placementProbes = 8;   // candidate placements of the skinned output streams compared at allocation time
+    float placementMs = 0; int placementTried = 0;
     int heavyThreshold = 4000; // distance evaluations in a character's last step above which it takes the 4-wave kernel; < 0: off
     bool skinPending = false, overlapSkin = false, customStream = false;
     // options
@@ -143,14 +147,67 @@ int refreshInvBind(sge_context* c, const float* meshInvBind, int meshInvBindCoun
     return rc;
 }
 
+// The three skinned output streams are the path's HBM traffic (40 B per vertex per step). On MI355X the rate at which a
+// buffer can be streamed to depends on where the driver placed it: the same store pattern runs at 5.3 or at 6.9 TB/s on
+// different hipMalloc results of one process, reproducibly per allocation (tools/alloc_bw.hip, tools/lbs_alloc.py). So a
+// large output set is chosen among a few candidate placements by timing the LBS store pattern on each.
 int allocCrowdOutputs(sge_context* c) {
-    size_t verts = (size_t)c->crowd.count * (size_t)c->mesh.vertexCount;
-    size_t stride = c->skinLayout == SGE_LAYOUT_PADDED16 ? 16 : 12;
-    int rc;
-    if ((rc = c->dOutPos.alloc(verts * stride)) != SGE_OK) return rc;
-    if ((rc = c->dOutNrm.alloc(verts * stride)) != SGE_OK) return rc;
-    if ((rc = c->dOutTan.alloc(verts * 16)) != SGE_OK) return rc;
+    const size_t verts = (size_t)c->crowd.count * (size_t)c->mesh.vertexCount;
+    const size_t stride = c->skinLayout == SGE_LAYOUT_PADDED16 ? 16 : 12;
+    const size_t need[3] = {verts * stride, verts * stride, verts * 16};
+    DevBuf* bufs[3] = {&c->dOutPos, &c->dOutNrm, &c->dOutTan};
     c->outLayoutAllocated = c->skinLayout;
+    if (need[0] <= bufs[0]->bytes && need[1] <= bufs[1]->bytes && need[2] <= bufs[2]->bytes && bufs[0]->p) return SGE_OK;
+    const size_t total = need[0] + need[1] + need[2];
+    int attempts = c->placementProbes;
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && total > 0) {
+        for (DevBuf* b : bufs) freeB += b->bytes; // about to be released
+        attempts = (int)std::min<size_t>((size_t)std::max(attempts, 1), std::max<size_t>(freeB / 2 / total, 1));
+    }
+    for (DevBuf* b : bufs) b->release();
+    if (total == 0) return SGE_OK;
+    if (attempts <= 1 || total < ((size_t)256 << 20)) {
+        int rc;
+        for (int k = 0; k < 3; ++k) if ((rc = bufs[k]->alloc(need[k])) != SGE_OK) return rc;
+        return SGE_OK;
+    }
+    struct Candidate { void* p[3]; float ms; };
+    std::vector<Candidate> cands;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    SGE_HIP(hipEventCreate(&e0));
+    SGE_HIP(hipEventCreate(&e1));
+    const float goodMs = (float)((double)verts * (stride == 16 ? 48.0 : 40.0) / 6.5e12 * 1e3); // 6.5 TB/s: a good placement
+    int best = -1;
+    for (int a = 0; a < attempts; ++a) {
+        Candidate cd{{nullptr, nullptr, nullptr}, 1e30f};
+        bool ok = true;
+        for (int k = 0; k < 3 && ok; ++k) ok = hipMalloc(&cd.p[k], need[k]) == hipSuccess;
+        if (!ok) { for (void* q : cd.p) if (q) (void)hipFree(q); (void)hipGetLastError(); break; }
+        launch_store_probe(cd.p[0], cd.p[1], cd.p[2], c->crowd.count, c->mesh.vertexCount, c->skinLayout, c->stream); // warm: first touch
+        SGE_HIP(hipEventRecord(e0, c->stream));
+        for (int r = 0; r < 2; ++r) launch_store_probe(cd.p[0], cd.p[1], cd.p[2], c->crowd.count, c->mesh.vertexCount, c->skinLayout, c->stream);
+        SGE_HIP(hipEventRecord(e1, c->stream));
+        SGE_HIP(hipEventSynchronize(e1));
+        SGE_HIP(hipEventElapsedTime(&cd.ms, e0, e1));
+        cd.ms *= 0.5f;
+        cands.push_back(cd);
+        if (best < 0 || cd.ms < cands[best].ms) best = (int)cands.size() - 1;
+        if (cd.ms <= goodMs) break;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (best < 0) { set_error("out of device memory for the skinned output streams"); return SGE_ERR_DEVICE; }
+    for (int a = 0; a < (int)cands.size(); ++a)
+        if (a != best) for (void* q : cands[a].p) (void)hipFree(q);
+    for (int k = 0; k < 3; ++k) { bufs[k]->p = cands[best].p[k]; bufs[k]->bytes = need[k]; }
+    c->placementMs = cands[best].ms;
+    c->placementTried = (int)cands.size();
+    if (getenv("SGE_DEBUG_PLACEMENT")) {
+        fprintf(stderr, "[sge] output placement: %d candidates, probe ms:", (int)cands.size());
+        for (auto& cd : cands) fprintf(stderr, " %.3f", cd.ms);
+        fprintf(stderr, " -> %.3f (good <= %.3f)\n", cands[best].ms, goodMs);
+    }
     return SGE_OK;
 }
 
@@ -337,6 +394,7 @@ int sge_context_set_option(sge_context* c, int option, int value) {
     case SGE_OPT_PROFILE: c->profile = value != 0; break;
     case SGE_OPT_OVERLAP_SKIN: { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; c->overlapSkin = value != 0; break; }
     case SGE_OPT_HEAVY_THRESHOLD: c->heavyThreshold = value; break;
+    case SGE_OPT_PLACEMENT_PROBES: c->placementProbes = value; break;
     default: set_error("unknown option"); return SGE_ERR_INVALID;
     }
     return SGE_OK;

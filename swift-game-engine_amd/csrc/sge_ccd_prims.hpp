@@ -70,7 +70,7 @@ SGE_HD float segmentSegmentDistanceSq(F3 p1, F3 q1, F3 p2, F3 q2, F3& c1o, F3& c
     const float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);
     const float eps = 1e-6f;
     const bool aDeg = a <= eps, eDeg = e <= eps;
-    const bool both = aDeg && eDeg, onlyA = aDeg && !eDeg, onlyE = !aDeg && eDeg, general = !aDeg && !eDeg;
+    const bool onlyA = aDeg && !eDeg, onlyE = !aDeg && eDeg, general = !aDeg && !eDeg;
     const float c = dot(d1, r), b = dot(d1, d2);
     const float denom = a * e - b * b;
     const bool haveDenom = general && denom != 0;

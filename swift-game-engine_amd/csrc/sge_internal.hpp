@@ -189,6 +189,7 @@ struct SkinLaunch {
     void* outPos; void* outNrm; void* outTan;
 };
 void launch_skin(const SkinLaunch& L, hipStream_t s);
+void launch_store_probe(void* outPos, void* outNrm, void* outTan, int chars, int vertexCount, int dstLayout, hipStream_t s);
 
 void launch_agents_export(const DevCrowd& crowd, sge_agent_state* d_out, hipStream_t s);
 

@@ -19,6 +19,9 @@
 
 namespace sge {
 
+#ifndef SGE_SKIN_UNCOND
+#define SGE_SKIN_UNCOND 2 // influences blended without a `w > 0` test (weights clamped at 0 instead)
+#endif
 #ifndef SGE_SKIN_BLOCK
 #define SGE_SKIN_BLOCK 256
 #endif
@@ -134,9 +137,21 @@ __global__ __launch_bounds__(kSkinBlock) void skin_kernel(SkinLaunch L, int spli
             M.r1.x += m.r1.x * (WGT); M.r1.y += m.r1.y * (WGT); M.r1.z += m.r1.z * (WGT); M.r1.w += m.r1.w * (WGT); \
             M.r2.x += m.r2.x * (WGT); M.r2.y += m.r2.y * (WGT); M.r2.z += m.r2.z * (WGT); M.r2.w += m.r2.w * (WGT); \
         }
+#if SGE_SKIN_UNCOND >= 2
         SGE_BLEND(v.idx.y, w1)
+#else
+        if (v.w.y > 0.0f) SGE_BLEND(v.idx.y, v.w.y)
+#endif
+#if SGE_SKIN_UNCOND >= 3
+        { const float w2 = fmaxf(v.w.z, 0.0f); SGE_BLEND(v.idx.z, w2) }
+#else
         if (v.w.z > 0.0f) SGE_BLEND(v.idx.z, v.w.z)
+#endif
+#if SGE_SKIN_UNCOND >= 4
+        { const float w3 = fmaxf(v.w.w, 0.0f); SGE_BLEND(v.idx.w, w3) }
+#else
         if (v.w.w > 0.0f) SGE_BLEND(v.idx.w, v.w.w)
+#endif
 #undef SGE_BLEND
         const float3 acc = xform(M, p, 1.0f), nAcc = xform(M, n, 0.0f), tAcc = xform(M, tv, 0.0f);
 #endif
@@ -184,6 +199,31 @@ __global__ __launch_bounds__(kSkinBlock) void skin_kernel(SkinLaunch L, int spli
         if (!has2) break;
         gid = g2;
     }
+}
+
+// The LBS kernel's store pattern alone (one workgroup per character, three non-temporal streams): sge_api uses it to
+// compare candidate placements of the output buffers, see allocCrowdOutputs.
+template <int DST_STRIDE>
+__global__ __launch_bounds__(kSkinBlock) void store_probe_kernel(float* outPos, float* outNrm, v4f* outTan, int vertexCount) {
+    const size_t base = (size_t)blockIdx.x * vertexCount;
+    for (int v = threadIdx.x; v < vertexCount; v += kSkinBlock) {
+        const size_t o = base + v;
+        float* op = outPos + o * DST_STRIDE;
+        float* on = outNrm + o * DST_STRIDE;
+        if (DST_STRIDE == 4) {
+            __builtin_nontemporal_store(v4f{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<v4f*>(op));
+            __builtin_nontemporal_store(v4f{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<v4f*>(on));
+        } else {
+            __builtin_nontemporal_store(0.f, op); __builtin_nontemporal_store(0.f, op + 1); __builtin_nontemporal_store(0.f, op + 2);
+            __builtin_nontemporal_store(0.f, on); __builtin_nontemporal_store(0.f, on + 1); __builtin_nontemporal_store(0.f, on + 2);
+        }
+        __builtin_nontemporal_store(v4f{0.f, 0.f, 0.f, 0.f}, outTan + o);
+    }
+}
+void launch_store_probe(void* outPos, void* outNrm, void* outTan, int chars, int vertexCount, int dstLayout, hipStream_t s) {
+    if (chars <= 0 || vertexCount <= 0) return;
+    if (dstLayout == SGE_LAYOUT_PADDED16) hipLaunchKernelGGL((store_probe_kernel<4>), dim3(chars), dim3(kSkinBlock), 0, s, (float*)outPos, (float*)outNrm, (v4f*)outTan, vertexCount);
+    else hipLaunchKernelGGL((store_probe_kernel<3>), dim3(chars), dim3(kSkinBlock), 0, s, (float*)outPos, (float*)outNrm, (v4f*)outTan, vertexCount);
 }
 
 void launch_skin(const SkinLaunch& L, hipStream_t s) {
