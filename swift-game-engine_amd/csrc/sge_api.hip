@@ -64,7 +64,7 @@ struct sge_context {
     int boneCount = 0;
     DevSkeleton sk{};
     std::vector<float> hostSkeletonInvBind; // [B][16] skeleton.invBindModel
-    DevBuf dParent, dDepth, dLeanChain, dBindLocal, dInvBind, dRestT, dRawRestT, dPreRot;
+    DevBuf dParent, dDepth, dLeanChain, dPath, dBindLocal, dInvBind, dRestT, dRawRestT, dPreRot;
     // profiles
     DevProfiles prof{};
     DevBuf dCoeffs, dCoeffCount, dBonePresent;
@@ -353,7 +353,7 @@ void sge_context_destroy(sge_context* c) {
     (void)hipSetDevice(c->device);
     (void)syncAll(c);
     drainEvents(c->evMove); drainEvents(c->evPose); drainEvents(c->evSkin); drainEvents(c->evAgents);
-    DevBuf* bufs[] = {&c->dParent, &c->dDepth, &c->dLeanChain, &c->dBindLocal, &c->dInvBind, &c->dRestT, &c->dRawRestT, &c->dPreRot,
+    DevBuf* bufs[] = {&c->dParent, &c->dDepth, &c->dLeanChain, &c->dPath, &c->dBindLocal, &c->dInvBind, &c->dRestT, &c->dRawRestT, &c->dPreRot,
                       &c->dCoeffs, &c->dCoeffCount, &c->dBonePresent, &c->dMeshPos, &c->dMeshNrm, &c->dMeshTan, &c->dMeshIdx, &c->dMeshWgt,
                       &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dSlotOfRank, &c->dCost, &c->dLists, &c->dListCounts, &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
                       &c->dPalettes, &c->dPoseModel, &c->dPoseLocal, &c->dMoveScratch, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
@@ -422,6 +422,11 @@ int sge_skeleton_upload(sge_context* c, const sge_skeleton_desc* d) {
         for (int b = d->leanIndex; b >= 0; b = d->parent[b]) chain.insert(chain.begin(), b);
     }
     if (chain.empty()) chain.push_back(0);
+    std::vector<int32_t> path((size_t)B * (maxDepth + 1), 0);
+    for (int i = 0; i < B; ++i) {
+        int k = depth[i];
+        for (int b = i; b >= 0; b = d->parent[b]) path[(size_t)i * (maxDepth + 1) + k--] = b;
+    }
     std::vector<float> bind12((size_t)B * 12), pre12((size_t)B * 12);
     for (int i = 0; i < B; ++i) {
         const float* m = d->bindLocal + i * 16;
@@ -441,6 +446,7 @@ int sge_skeleton_upload(sge_context* c, const sge_skeleton_desc* d) {
     if ((rc = upload(c->dParent, d->parent, (size_t)B * 4, s)) != SGE_OK) return rc;
     if ((rc = upload(c->dDepth, depth.data(), (size_t)B * 4, s)) != SGE_OK) return rc;
     if ((rc = upload(c->dLeanChain, chain.data(), chain.size() * 4, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dPath, path.data(), path.size() * 4, s)) != SGE_OK) return rc;
     if ((rc = upload(c->dBindLocal, bind12.data(), bind12.size() * 4, s)) != SGE_OK) return rc;
     if ((rc = upload(c->dRestT, d->restTranslation, (size_t)B * 12, s)) != SGE_OK) return rc;
     if ((rc = upload(c->dRawRestT, d->rawRestTranslation, (size_t)B * 12, s)) != SGE_OK) return rc;
@@ -459,6 +465,7 @@ int sge_skeleton_upload(sge_context* c, const sge_skeleton_desc* d) {
     sk.parent = c->dParent.as<int32_t>();
     sk.depth = c->dDepth.as<int32_t>();
     sk.leanChain = c->dLeanChain.as<int32_t>();
+    sk.path = c->dPath.as<int32_t>();
     sk.bindLocal = c->dBindLocal.as<float>();
     sk.restT = c->dRestT.as<float>();
     sk.rawRestT = c->dRawRestT.as<float>();

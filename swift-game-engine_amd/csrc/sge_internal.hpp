@@ -50,6 +50,7 @@ struct DevSkeleton {
     const int32_t* parent;      // [B]
     const int32_t* depth;       // [B]
     const int32_t* leanChain;   // [leanChainLen]
+    const int32_t* path;        // [B][maxDepth + 1]: bone i's ancestors root first, i itself at position depth[i]
     const float* bindLocal;     // [B][12] affine by column
     const float* invBind;       // [B][16] full 4x4 used for the palette (mesh re-bind applied at upload)
     const float* restT;         // [B][3]

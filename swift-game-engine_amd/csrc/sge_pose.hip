@@ -70,6 +70,14 @@ __device__ __forceinline__ BoneEval evalBone(const DevSkeleton& sk, const DevPro
     F3 restScaled{sk.restT[i * 3], sk.restT[i * 3 + 1], sk.restT[i * 3 + 2]};
     F3 restRaw{sk.rawRestT[i * 3], sk.rawRestT[i * 3 + 1], sk.rawRestT[i * 3 + 2]};
     r.present = pf.bonePresent[prof * B + i] != 0;
+    if (!r.present) {
+        // the profile has no entry for this bone: raw = rest and all angles 0, so t = rest and rot = preRot * I
+        // (what the arithmetic below yields as well, without its six trig evaluations)
+        r.t = restScaled;
+        r.rot = loadAff12(sk.preRot + i * 12);
+        if (i == 0) r.rot = affMul(rootFix, r.rot);
+        return r;
+    }
     const int order = pf.order[prof];
     float raw[3] = {restRaw.x, restRaw.y, restRaw.z};
     float deg[3] = {0.f, 0.f, 0.f};
@@ -261,6 +269,14 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
             if (!sameEval) harmonics(phase4[fromState], pf.order[fromProf], hFrom);
             for (int i = lane; i < B; i += kWave) {
                 BoneEval to = evalBone(sk, pf, toProf, i, hTo, inPlace, rootFix);
+                if (sameEval && !isBlending) {
+                    // one profile, no blend: lerp(t, t) = t and slerp(q, q) = q. The reference still goes matrix ->
+                    // quaternion -> slerp -> matrix, which only re-rounds the rotation (~1e-7); skip the round trip.
+                    Aff loc = to.rot;
+                    loc.c3 = to.t;
+                    storeAff12(sLocal + i * 12, loc);
+                    continue;
+                }
                 BoneEval from = sameEval ? to : evalBone(sk, pf, fromProf, i, hFrom, inPlace, rootFix);
                 F3 t = from.t + (to.t - from.t) * weightTo;
                 Quat fromQuat = quatFromRotation(from.rot);
@@ -374,13 +390,17 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
             }
         }
 
-        // ---- model transforms level by level, then the palette :396-402 ----
-        for (int d = 0; d <= sk.maxDepth; ++d) {
+        // ---- model transforms, then the palette :396-402 ----
+        // model[i] = model[parent] * local[i] unrolls to local[root] * ... * local[i] multiplied left to right; every lane
+        // walks its own bone's ancestor path in that order (the same sequence of products, hence the same bits, as the
+        // reference's parent-before-child loop) — no level-by-level barriers.
+        {
+            const int stride = sk.maxDepth + 1;
             for (int i = lane; i < B; i += kWave) {
-                if (sk.depth[i] != d) continue;
-                int p = sk.parent[i];
-                Aff loc = loadAff12(sLocal + i * 12);
-                Aff mod = p < 0 ? loc : affMul(loadAff12(sModel + p * 12), loc);
+                const int32_t* pth = sk.path + (size_t)i * stride;
+                const int dep = sk.depth[i];
+                Aff mod = loadAff12(sLocal + pth[0] * 12);
+                for (int k = 1; k <= dep; ++k) mod = affMul(mod, loadAff12(sLocal + pth[k] * 12));
                 storeAff12(sModel + i * 12, mod);
             }
             __syncthreads();
