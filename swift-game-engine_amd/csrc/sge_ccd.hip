@@ -40,7 +40,7 @@ constexpr int kStackCap = kTraversalStackCap; // wide nodes pending (each pop ad
 constexpr int kCandCap = 512;
 constexpr int kRangeCap = 128;
 constexpr int kItemCap = 512;
-constexpr int kMaxRays = 4;
+constexpr int kMaxRays = 6;
 constexpr int kRefillIdle = 16;  // idle lanes that trigger a queue top-up while others still march
 
 struct OverlapRec { float depth; F3 position, normal, triNormal; int triIndex, rank; };
@@ -1023,7 +1023,7 @@ struct MoveState {
     // slide
     float baseMoveLen; int haveLast; F3 lastSlideNormal;
     // ground probe
-    CastRec centerHit; int haveCenter; float gDistance; F3 gNormalSum; int sampleK;
+    CastRec centerHit; int haveCenter; float gDistance; F3 gNormalSum; int sampleK, sampled;
     int nearGround, canSnap, gGrounded, gNear;
     int wasGrounded, wasGroundedNear;
     // constants of the launch + the agent sweep result of this slide iteration
@@ -1185,9 +1185,10 @@ __device__ __noinline__ void consumeGroundSample() { // :906-921, in the referen
     const CastRec c = ms.centerHit;
     float combineTol = smax(smax(P.groundSnapSkin, P.skinWidth), 0.05f);
     F3 normalSum = ms.gNormalSum;
+    const int base = ms.sampleK; // 2 when the samples rode along with the centre pass, 0 after a pass of their own
     for (int k = 0; k < 4; ++k) {
-        if (rayHit(k) && sh.rayRec[k].toi <= c.toi + combineTol) {
-            if (dot(sh.rayRec[k].triNormal, c.triNormal) > 0.98f) normalSum = normalSum + sh.rayRec[k].triNormal;
+        if (rayHit(base + k) && sh.rayRec[base + k].toi <= c.toi + combineTol) {
+            if (dot(sh.rayRec[base + k].triNormal, c.triNormal) > 0.98f) normalSum = normalSum + sh.rayRec[base + k].triNormal;
         }
     }
     ms.gNormalSum = normalSum;
@@ -1221,7 +1222,7 @@ __device__ __noinline__ void groundEval() { // :868-894 — decides whether the 
         if (validGroundPoint && (nearGround || canSnap)) {
             ms.gGrounded = 1;
             ms.gNormalSum = centerHit.triNormal;
-            if (centerHit.triNormal.y < 0.98f && (ms.wasGroundedNear || nearGround)) { ms.sampleK = 0; ms.phase = MP_GROUND_SAMPLE; }
+            if (centerHit.triNormal.y < 0.98f && (ms.wasGroundedNear || nearGround)) { ms.phase = MP_GROUND_SAMPLE; ms.sampled = 1; }
         }
     } else {
         ms.haveCenter = 0; // guard failed: GroundProbeResult(hit: nil), canSnap false
@@ -1431,7 +1432,7 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? 4 
         ms.it = 0;
         ms.didResolve = 0; ms.normalSum = F3{0, 0, 0}; ms.normalWeight = 0;
         ms.haveLast = 0; ms.lastSlideNormal = F3{0, 0, 0}; ms.baseMoveLen = 0;
-        ms.haveCenter = 0; ms.gDistance = kFloatMax; ms.gNormalSum = F3{0, 0, 0}; ms.sampleK = 0;
+        ms.haveCenter = 0; ms.gDistance = kFloatMax; ms.gNormalSum = F3{0, 0, 0}; ms.sampleK = 0; ms.sampled = 0;
         ms.nearGround = 0; ms.canSnap = 0; ms.gGrounded = 0; ms.gNear = 0;
     }
     __syncthreads();
@@ -1453,11 +1454,28 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? 4 
             // GroundProbe's snap cast (:844-853) and fall probe (:855-866) share origin, capsule and filters:
             // two rays of one pass. A disabled probe becomes a zero-length ray (= nil, like :987-988).
             doCast = true;
-            sh.rayCount = 2;
             sh.rayFrom[0] = ms.position; sh.rayFrom[1] = ms.position;
             sh.rayDelta[0] = P.snapDistance > 0 ? F3{0, -1, 0} * P.snapDistance : F3{0, 0, 0};
             sh.rayDelta[1] = P.fallProbeDistance > 0 ? F3{0, -1, 0} * P.fallProbeDistance : F3{0, 0, 0};
-        } else if (phase == MP_GROUND_SAMPLE) {
+            // The four offset casts (:898-921) are issued only when the centre hit turns out to be a slope under a character
+            // near the ground (groundEval). A character that stood on a slope last step will almost surely need them again,
+            // so they ride along as rays 2..5 of this pass (casts are pure: unused results are simply dropped); everyone
+            // else casts them in a pass of their own if the condition comes true.
+            const bool spec = ms.wasGroundedNear && P.snapDistance > 0 && K.hint && K.hint[e] != 0;
+            sh.rayCount = spec ? 6 : 2;
+            ms.sampleK = spec ? 2 : 0;
+            if (spec) {
+                const float offset = P.radius * 0.6f;
+                const F3 snapDelta = F3{0, -1, 0} * P.snapDistance;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float ox = k == 0 ? offset : (k == 1 ? -offset : 0.0f);
+                    float oz = k == 2 ? offset : (k == 3 ? -offset : 0.0f);
+                    sh.rayFrom[2 + k] = ms.position + F3{ox, 0, oz};
+                    sh.rayDelta[2 + k] = snapDelta;
+                }
+            }
+        } else if (phase == MP_GROUND_SAMPLE && ms.sampleK == 0) {
             // the four offset casts of :898-921, one pass
             doCast = true;
             sh.rayCount = 4;
@@ -1523,6 +1541,8 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? 4 
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
         // this step's sweep cost decides which kernel takes the character next step
         if (PART == 1 && K.cost && lane == 0) K.cost[e] = HEAVY ? (int)hv.evalSum : (int)v;
+        // did this step need the four offset ground casts? (next step's centre pass then carries them along)
+        if (PART == 1 && K.hint && lane == 0) K.hint[e] = (uint8_t)(ms.sampled != 0);
     }
     if (K.stats) {
         // evals are counted per lane; sum over the wave

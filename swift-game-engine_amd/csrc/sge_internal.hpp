@@ -158,6 +158,7 @@ struct MoveLaunch {
     int platformCount;
     // light / heavy split of part 1 (sge_ccd.hip, "heavy characters"); lists == nullptr: one launch over [first, first+count)
     int* cost;                 // [crowd.count] distance evaluations of each character's last step
+    uint8_t* hint;             // [crowd.count] 1 when the last step needed the four offset ground casts
     int* lists; int* listCounts; // [2][count] indices + [2] lengths, filled by classify_kernel
     int heavyThreshold, heavyCap;
     hipStream_t heavyStream; hipEvent_t evClassified, evHeavyDone;
