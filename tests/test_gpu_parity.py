@@ -484,6 +484,41 @@ def test_heavy_four_wave_kernel_parity(sge, real):
     cpu.close()
 
 
+def test_long_soak_parity(sge):
+    """900 fixed steps (15 simulated seconds) of a mixed crowd with character-vs-character sweeps on the merged real scene,
+    default scheduling (heavy characters in the four-wave kernel, speculative ground samples): the CCD state must still
+    equal the oracle's bit for bit at the end, with intents redirected on the way to keep everybody moving."""
+    gpu = sge.CharacterEngine(0)
+    cpu = ob.oracle_engine()
+    n = 160
+    states = []
+    for e in (gpu, cpu):
+        _, _, st0 = build_scene(sge, e, n, seed=77, mixed=True, agents=True, rings=3, segments=3, asset_scene=("cheese", "semla"), footprint=120.0)
+        states.append(st0)
+    import torch
+    ex = sge.parallel.AgentExchange(gpu, n, 0, 1, torch.device("cuda", 0), None)
+    st = sge.abi.STAGE_ALL & ~sge.abi.STAGE_SKIN
+    rng = np.random.default_rng(5)
+    for s in range(900):
+        if s % 150 == 149:  # turn everybody around: new headings, some stop
+            heading = rng.uniform(0, 2 * np.pi, n)
+            speed = rng.choice([0.0, 4.5, 12.5], n)
+            intents = sge.assets.default_intents(n, np.c_[np.cos(heading) * speed, np.zeros(n), np.sin(heading) * speed].astype(np.float32))
+            for e in (gpu, cpu):
+                e.upload(intents=intents)
+        ex.step(stages=st)  # snapshot exchange (world size 1) + tick with SGE_STAGE_AGENTS
+        ob.tick_mt(cpu, 8, stages=st | sge.abi.STAGE_AGENTS)
+        if s % 100 == 99:
+            gpu.synchronize()
+            compare_states(sge, gpu, cpu, n)
+    d = gpu.download(what=("bodies", "controllers", "locomotion"))
+    assert np.isfinite(d["bodies"]["position"]).all()
+    assert len(np.unique(d["locomotion"]["state"])) >= 3
+    assert gpu.move_stats().overflow == 0
+    gpu.close()
+    cpu.close()
+
+
 def test_full_size_properties(sge):
     """BASELINE.json configs[2] at full size (10k clones x 14,080 vertices vs 71,680 triangles), checked through
     size-independent properties: characters are independent, so an oracle run over a RANDOM SUBSET of the crowd
