@@ -1,35 +1,31 @@
-// Capsule-CCD move-and-slide against the static triangle set, for gfx950.
+// Capsule-CCD move-and-slide against the static and dynamic triangle sets, for gfx950.
 // Replaces, per fixed step and per character:
 //   PhysicsIntentSystem (controller branch)   Game/Systems.swift:205-250
 //   GravitySystem                             Game/Systems.swift:596-620
 //   KinematicMoveStopSystem.fixedUpdate       Game/Systems.swift:1823-1902
-//     DepenetrationResolver :734-808, resolveKinematicSweep :1658-1765,
+//     PlatformCarry :644-732, DepenetrationResolver :734-808, resolveKinematicSweep :1658-1765,
 //     SlideResolver.resolveHit :1229-1375, GroundProbe/GroundSnap/SlopeFriction :826-1021,
 //     DefaultContactCachePolicy/ContactManifoldCache :1102-1205, AgentSweepSolver :1053-1091
-//   CollisionQuery.capsuleCast* / capsuleOverlapAll   Game/CollisionQuery.swift:96-159, 852-1283
-//   sweepCapsuleTriangle / refineTOI / segmentTriangleDistance  Game/CollisionQuery.swift:1285-1573
+//   CollisionQuery.raycast / capsuleCast* / capsuleOverlap / capsuleOverlapAll   Game/CollisionQuery.swift:85-159, 768-1283
+//   sweepCapsuleTriangle / refineTOI / segmentTriangleDistance  Game/CollisionQuery.swift:1285-1573 (sge_ccd_prims.hpp)
 //
-// Mapping: ONE WAVEFRONT PER CHARACTER (64-thread workgroups). The per-character
-// state machine (depenetration -> slide iterations -> ground probe -> snap ->
-// friction -> write-back) is wave-uniform; each BVH query inside it is
-// wave-cooperative:
-//   * traversal: an LDS stack of node indices, up to 64 nodes popped and AABB-tested
-//     per step (one per lane), children / leaf triangles appended with ballot +
-//     prefix-popcount compaction;
-//   * candidates: batches of <= 64 triangles, one per lane. The reference's result
-//     depends on its right-child-first visit order only through strict `<`
-//     tie-breaks and capsuleOverlapAll's "first maxHits"; every triangle carries its
-//     visit rank, so lanes may run in any order and the wave reduces on
-//     (toi, rank) / selects by rank;
-//   * sweep: the reference's conservative advancement + 10-step bisection + final
-//     contact evaluation is rescheduled as a per-lane state machine in which every
-//     loop trip performs exactly one segmentTriangleDistance evaluation, so lanes in
-//     different phases stay convergent on the expensive code. A lane stops early
-//     once its last safe t exceeds the best accepted TOI of the wave (its hit could
-//     no longer win the strict `<`), which is what makes the 200-unit fall probe
-//     cheap.
-// Compiled with -ffp-contract=off; float32 arithmetic is IEEE and in the oracle's
-// order, so TOIs, normals and the discrete contact state match bit for bit.
+// Mapping: ONE WAVEFRONT PER CHARACTER (64-thread workgroups; the few characters whose previous step was very
+// expensive get a 256-thread workgroup, see "heavy characters"). The per-character state machine (platform carry ->
+// depenetration -> slide iterations -> ground probe -> snap -> friction -> write-back) is wave-uniform and lives in
+// LDS; each BVH query inside it is wave-cooperative:
+//   * traversal: a wide BVH (64 entries per node, cut out of the reference's binary tree) — one step pops a node and
+//     tests its 64 entries, one per lane, or scans a range of <= 64 triangles; survivors are compacted into LDS lists
+//     with ballot + prefix-popcount. Static and dynamic sets share the arrays: a traversal starts from both roots;
+//   * candidates: the reference's result depends on its right-child-first visit order only through strict `<`
+//     tie-breaks and capsuleOverlapAll's "first maxHits"; every triangle carries its visit rank (dynamic set offset
+//     by the static count), so lanes may run in any order and the wave reduces on (toi, rank) / selects by rank;
+//   * sweep: conservative advancement + 10-step bisection + final contact evaluation run as a per-lane state machine
+//     in which every loop trip performs exactly one segmentTriangleDistance evaluation, so lanes in different phases
+//     stay convergent on the expensive code; lanes stream — each pulls the next (ray, triangle) work item from an LDS
+//     queue as soon as its own is finished. A lane stops early once its last safe t exceeds the best accepted TOI of its
+//     ray (its hit could no longer win the strict `<`), which is what makes the 200-unit fall probe cheap.
+// Compiled with -ffp-contract=off; float32 arithmetic is IEEE and in the oracle's order, so TOIs, normals and the
+// discrete contact state match bit for bit.
 #include "sge_internal.hpp"
 #include "sge_ccd_prims.hpp"
 

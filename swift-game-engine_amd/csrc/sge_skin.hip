@@ -2,12 +2,11 @@
 // `skinningKernel` (Game/RayTracing.metalinc:737-776) and the per-job dispatch of
 // RTSkinningEncoder.encode (Game/RTSkinningEncoder.swift:27-56).
 //
-// Mapping: one thread per vertex, 256-thread workgroups (4 wavefronts), grid =
-// characters x ceil(V/256) so every workgroup belongs to exactly one character.
-// The character's bone palette (<= 256 x 3 float4 rows, 3.1 KB for the 65-bone
-// Y-Bot) is staged once per workgroup in LDS; source streams are SoA and read
-// coalesced (they are shared by all clones and stay L2-resident); the three output
-// streams are written coalesced and dominate HBM traffic (40 B/vertex packed).
+// Mapping: one 256-thread workgroup (4 wavefronts) per character — small crowds split a character over several —
+// one thread per vertex, walking the vertex stream 256 at a time with the next chunk's source attributes in flight.
+// The character's bone palette (<= 256 x 3 float4 rows, 3.1 KB for the 65-bone Y-Bot) is staged once per workgroup
+// in LDS; source streams are SoA and read coalesced (they are shared by all clones and stay L2-resident); the three
+// output streams are written coalesced with non-temporal stores and are the HBM traffic (40 B/vertex packed).
 //
 // Arithmetic: the reference accumulates acc += (palette[idx_j] * v).xyz * w_j over the influences with w_j > 0;
 // by linearity this kernel blends the matrices first and transforms once (build with -DSGE_SKIN_PER_INFLUENCE for the

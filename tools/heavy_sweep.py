@@ -6,11 +6,12 @@ abi = sge.abi
 eng = sge.CharacterEngine(0)
 ybot = sge.assets.YBotAssets()
 sge.crowd.upload_character_assets(eng, ybot, rings=3, segments=3)
-scene = sge.crowd.upload_asset_scene(eng, ("cheese",))
+synthetic = "--synthetic" in sys.argv
+scene = sge.crowd.upload_terrain(eng) if synthetic else sge.crowd.upload_asset_scene(eng, ("cheese",))
 n = 10000
 state = sge.crowd.spawn_crowd(eng, ybot, n, scene)
 st = abi.STAGE_INTENT | abi.STAGE_GRAVITY | abi.STAGE_MOVE
-for thr in [int(x) for x in sys.argv[1:]] or [-1, 8000, 4000, 2000, 1000, 500]:
+for thr in [int(x) for x in sys.argv[1:] if not x.startswith("--")] or [-1, 8000, 4000, 2000, 1000, 500]:
     eng.upload(**state)
     eng.set_option(abi.OPT_HEAVY_THRESHOLD, thr)
     for _ in range(140):
