@@ -239,3 +239,128 @@ def test_tangents_helper(sge, cpu):
     assert np.allclose(t[:3], [[1, 0, 0, -1]] * 3) and np.array_equal(t[3], [1, 0, 0, 1])
     t16 = cpu.compute_tangents(pos, nrm, uv, np.array([0, 1, 2], np.uint16))
     assert np.array_equal(t, t16)
+
+
+def _blend_expected(local_from, local_to, w, parent, lean_index=-1, run_lean_weight=0.0):
+    """float64 restatement of ProceduralPoseSystem.swift:185-220 on reference-tool locals: lerp the translations, slerp the
+    rotations (scipy, shortest arc), yaw-stable root (:206-215), run lean (:369-393); then the parent-before-child model
+    product."""
+    from scipy.spatial.transform import Rotation, Slerp
+
+    B = local_from.shape[0]
+    A = local_from.reshape(B, 4, 4).transpose(0, 2, 1)  # column-major 16 -> math matrices
+    Bm = local_to.reshape(B, 4, 4).transpose(0, 2, 1)
+    out = np.zeros((B, 4, 4))
+    for i in range(B):
+        ra, rb = A[i, :3, :3], Bm[i, :3, :3]
+        t = A[i, :3, 3] + (Bm[i, :3, 3] - A[i, :3, 3]) * w
+        if i == 0:
+            yaw = np.arctan2(ra[0, 2], ra[2, 2])
+            yq = Rotation.from_euler("y", yaw).as_matrix()
+            pa, pb = yq.T @ ra, yq.T @ rb
+            r = yq @ Slerp([0, 1], Rotation.from_matrix([pa, pb]))(w).as_matrix()
+        else:
+            r = Slerp([0, 1], Rotation.from_matrix([ra, rb]))(w).as_matrix()
+        out[i] = np.eye(4)
+        out[i, :3, :3], out[i, :3, 3] = r, t
+    def chain(loc):
+        model = np.zeros_like(loc)
+        for i in range(B):
+            model[i] = loc[i] if parent[i] < 0 else model[parent[i]] @ loc[i]
+        return model
+
+    model = chain(out)
+    if run_lean_weight > 0.001 and lean_index >= 0:
+        # the chest's right axis taken into its parent's space, a 10-degree * weight turn about it applied on the left
+        right_world = model[lean_index][:3, 0] / np.linalg.norm(model[lean_index][:3, 0])
+        p = parent[lean_index]
+        right_local = Rotation.from_matrix(model[p][:3, :3]).inv().apply(right_world) if p >= 0 else right_world
+        lean = np.eye(4)
+        lean[:3, :3] = Rotation.from_rotvec(right_local * np.radians(10.0) * run_lean_weight).as_matrix()
+        out[lean_index] = lean @ out[lean_index]
+        model = chain(out)
+    to16 = lambda m: m.transpose(0, 2, 1).reshape(B, 16)  # noqa: E731
+    return to16(out), to16(model)
+
+
+@pytest.mark.parametrize("case", [("Walking", 2, "Running", 4, 0.3), ("Running", 1, "Walking", 3, 0.65), ("Walking", 5, "Idle", 2, 0.5),
+                                  ("Running", 4, "FallingIdle", 0, 0.85), ("Idle", 3, "Running", 1, 0.1)])
+def test_locomotion_blend_matches_reference_tool_plus_slerp(sge, ybot, cpu, golden, case):
+    """Pins the blending branch (P6): from/to locals come from the reference's own fit_motion.py (golden, float64); the blend
+    between them is restated in float64 with scipy's slerp and compared with the oracle's float32 simd restatement."""
+    abi = sge.abi
+    from_name, ia, to_name, ib, blend_t = case
+    state_of = {"Idle": abi.LOCO_IDLE, "Walking": abi.LOCO_WALK, "Running": abi.LOCO_RUN, "FallingIdle": abi.LOCO_FALLING}
+    cpu.upload_skeleton(ybot)
+    cpu.upload_profiles(ybot.profiles)
+    cpu.resize(1)
+    L = sge.assets.default_locomotion(1, ybot)
+    fs, ts = state_of[from_name], state_of[to_name]
+    L["fromState"], L["state"] = fs, ts
+    L["flags"] |= abi.LOCO_IS_BLENDING
+    phases = golden["phases"]
+    for s, name, k in ((fs, from_name, ia), (ts, to_name, ib)):
+        L["time"][0, s] = np.float32(phases[k]) * np.float32(ybot.profiles[ybot.profile_index(name)]["cycleDuration"])
+    if ts == abi.LOCO_IDLE:           # weightTo = 1 - clamp(idleInertia) (:93-96)
+        L["idleInertia"] = 1.0 - blend_t
+        w = np.float64(np.float32(1.0) - np.float32(L["idleInertia"][0]))
+    else:                             # smootherstep of blendT (:98-99)
+        L["blendT"] = blend_t
+        t = np.float64(np.float32(blend_t))
+        w = t * t * t * (t * (t * 6 - 15) + 10)
+    cpu.upload(bodies=sge.assets.default_bodies(1, np.zeros((1, 3))), params=sge.assets.default_controller_params(1),
+               controllers=sge.assets.default_controller_state(1), intents=sge.assets.default_intents(1),
+               locomotion=L, actions=sge.assets.default_actions(1))
+    cpu.tick(dt=0.0, stages=abi.STAGE_POSE)
+    _, mod, loc = cpu.palettes(model=True, local=True)
+    run_w = w if ts == abi.LOCO_RUN else (1.0 - w if fs == abi.LOCO_RUN else 0.0)   # :103-113
+    exp_local, exp_model = _blend_expected(golden[f"{from_name}.local"][ia], golden[f"{to_name}.local"][ib], w, ybot.parent,
+                                           ybot.lean_index, run_w)
+    scale = np.abs(exp_model).max()
+    assert np.abs(loc[0] - exp_local).max() <= 2e-5 * scale, np.abs(loc[0] - exp_local).max()
+    assert np.abs(mod[0] - exp_model).max() <= 2e-5 * scale, np.abs(mod[0] - exp_model).max()
+    after = cpu.download(what=("locomotion",))["locomotion"]
+    assert after["flags"][0] & abi.LOCO_IS_BLENDING                    # dt = 0: still mid-blend
+
+
+@pytest.mark.parametrize("case", [("Walking", 1, 3, 0.4), ("Idle", 4, 2, 1.0), ("Running", 2, 5, 0.25)])
+def test_action_layer_matches_reference_tool_plus_slerp(sge, ybot, cpu, golden, case):
+    """Pins the action layer (P8, ProceduralPoseSystem.swift:286-338): base locomotion pose and the StandingDodgeBackward pose
+    come from the reference's fit_motion.py (golden); their per-bone lerp / slerp by the action weight is restated in float64."""
+    abi = sge.abi
+    base_name, ia, ib, weight = case
+    state_of = {"Idle": abi.LOCO_IDLE, "Walking": abi.LOCO_WALK, "Running": abi.LOCO_RUN}
+    cpu.upload_skeleton(ybot)
+    cpu.upload_profiles(ybot.profiles)
+    cpu.resize(1)
+    phases = golden["phases"]
+    L = sge.assets.default_locomotion(1, ybot)
+    st = state_of[base_name]
+    L["state"], L["fromState"] = st, st
+    L["time"][0, st] = np.float32(phases[ia]) * np.float32(ybot.profiles[ybot.profile_index(base_name)]["cycleDuration"])
+    A = sge.assets.default_actions(1, ybot, present=True)
+    k = ybot.profile_index("StandingDodgeBackward")
+    A["profile"] = k
+    A["flags"] = abi.ACTION_PRESENT | abi.ACTION_ACTIVE | abi.ACTION_IN_PLACE
+    A["weight"] = weight
+    A["time"] = np.float32(phases[ib]) * np.float32(ybot.profiles[k]["cycleDuration"])
+    cpu.upload(bodies=sge.assets.default_bodies(1, np.zeros((1, 3))), params=sge.assets.default_controller_params(1),
+               controllers=sge.assets.default_controller_state(1), intents=sge.assets.default_intents(1), locomotion=L, actions=A)
+    cpu.tick(dt=0.0, stages=abi.STAGE_POSE)
+    _, mod, loc = cpu.palettes(model=True, local=True)
+    w = float(np.float32(weight))
+    run_w = (1.0 if st == abi.LOCO_RUN else 0.0) * (1.0 - w)                      # runLeanWeight *= (1 - w), :297
+    base, act = golden[f"{base_name}.local"][ia].copy(), golden["StandingDodgeBackward.local"][ib]
+    B = base.shape[0]
+    from scipy.spatial.transform import Rotation, Slerp
+    exp = np.zeros((B, 4, 4))
+    for i in range(B):
+        a, b = base[i].reshape(4, 4).T, act[i].reshape(4, 4).T
+        exp[i] = np.eye(4)
+        exp[i, :3, 3] = a[:3, 3] + (b[:3, 3] - a[:3, 3]) * w
+        exp[i, :3, :3] = Slerp([0, 1], Rotation.from_matrix([a[:3, :3], b[:3, :3]]))(w).as_matrix()
+    exp16 = exp.transpose(0, 2, 1).reshape(B, 16)
+    el, em = _blend_expected(exp16, exp16, 0.0, ybot.parent, ybot.lean_index, run_w)   # model chain (+ the scaled run lean)
+    scale = np.abs(em).max()
+    assert np.abs(loc[0] - el).max() <= 2e-5 * scale, np.abs(loc[0] - el).max()
+    assert np.abs(mod[0] - em).max() <= 2e-5 * scale, np.abs(mod[0] - em).max()
