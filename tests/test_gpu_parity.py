@@ -461,13 +461,15 @@ def test_heavy_four_wave_kernel_parity(sge, real):
     n = 96
     for e in (gpu, cpu):
         if real:
-            build_scene(sge, e, n, seed=9, mixed=True, rings=3, segments=3, asset_scene=("cheese", "mirror"))
+            build_scene(sge, e, n, seed=9, mixed=True, rings=3, segments=3, agents=True, asset_scene=("cheese", "mirror"))
         else:
             build_scene(sge, e, n, terrain_cells=(56, 40), seed=31, mixed=True, rings=3, segments=3, agents=True)
+    import torch
+    ex = sge.parallel.AgentExchange(gpu, n, 0, 1, torch.device("cuda", 0), None)   # character-vs-character sweeps on (world size 1)
     st = sge.abi.STAGE_ALL & ~sge.abi.STAGE_SKIN
     for s in range(140):
-        gpu.tick(stages=st)
-        ob.tick_mt(cpu, 8, stages=st)
+        ex.step(stages=st)
+        ob.tick_mt(cpu, 8, stages=st | sge.abi.STAGE_AGENTS)
         if s in (0, 1, 2, 10, 60, 139):
             gpu.synchronize()
             compare_states(sge, gpu, cpu, n)
@@ -476,8 +478,8 @@ def test_heavy_four_wave_kernel_parity(sge, real):
     # and back to the one-wave kernel mid-run
     gpu.set_option(sge.abi.OPT_HEAVY_THRESHOLD, -1)
     for s in range(20):
-        gpu.tick(stages=st)
-        ob.tick_mt(cpu, 8, stages=st)
+        ex.step(stages=st)
+        ob.tick_mt(cpu, 8, stages=st | sge.abi.STAGE_AGENTS)
     gpu.synchronize()
     compare_states(sge, gpu, cpu, n)
     gpu.close()
