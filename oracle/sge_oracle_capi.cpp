@@ -322,6 +322,9 @@ int sgeo_tick_mt(sgeo_world* h, const sge_tick_desc* d, int32_t threads) {
     int first = d->first, count = d->count;
     if (count == 0) { first = 0; count = (int)w.bodies.size(); }
     if (first < 0 || (size_t)(first + count) > w.bodies.size()) return SGE_ERR_INVALID;
+    // the same state errors as the product (sge_tick): stages that need assets which were never uploaded
+    if (count > 0 && (d->stages & SGE_STAGE_POSE) && (w.skeleton.boneCount == 0 || w.profiles.empty())) return SGE_ERR_STATE;
+    if (count > 0 && (d->stages & SGE_STAGE_SKIN) && w.mesh.vertexCount == 0) return SGE_ERR_STATE;
     std::vector<AgentSweepState> agents;
     int selfOffset = 0;
     const bool useAgents = (d->stages & SGE_STAGE_AGENTS) != 0;
