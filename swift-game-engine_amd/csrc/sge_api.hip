@@ -52,7 +52,7 @@ struct sge_context {
     hipStream_t skinStream = nullptr;
     hipEvent_t evPoseDone = nullptr, evSkinDone = nullptr;
     hipStream_t heavyStream = nullptr; // part 1 of the move stage for the step's heavy characters
-    hipEvent_t evClassified = nullptr, evHeavyDone = nullptr;
+    hipEvent_t evClassified = nullptr, evHeavyDone = nullptr, evTablesCopied = nullptr;
     int placementProbes = 8;   // candidate placements of the skinned output streams compared at allocation time
     float placementMs = 0; int placementTried = 0;
     int heavyThreshold = 4000; // distance evaluations in a character's last step above which it takes the 4-wave kernel; < 0: off
@@ -74,7 +74,7 @@ struct sge_context {
     // collision
     HostCollision hostCol, hostDyn; // StaticTriMesh.staticSet / dynamicSet (CollisionQuery.swift:710-711)
     DevCollision col{};
-    DevBuf dWide, dTris, dMaterials, dBinNodes[2], dSlotOfRank, dPlatforms, dRayQueries, dRayOut, dCost, dHint, dLists, dListCounts;
+    DevBuf dWide, dTris, dMaterials, dBinNodes[2], dSlotOfRank, dPlatforms, dRayQueries, dRayOut, dCost, dHint, dLists, dListCounts, dJobTable, dBlockJob;
     int platformCount = 0;
     // crowd
     DevCrowd crowd{};
@@ -343,7 +343,8 @@ sge_context* sge_context_create(int device_index) {
         hipEventCreateWithFlags(&c->evSkinDone, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithPriority(&c->heavyStream, hipStreamNonBlocking, prGreatest) != hipSuccess ||
         hipEventCreateWithFlags(&c->evClassified, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->evHeavyDone, hipEventDisableTiming) != hipSuccess) { set_error("stream/event creation failed"); delete c; return nullptr; }
+        hipEventCreateWithFlags(&c->evHeavyDone, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evTablesCopied, hipEventDisableTiming) != hipSuccess) { set_error("stream/event creation failed"); delete c; return nullptr; }
     if (c->dStats.alloc((size_t)kStatShards * 64) != SGE_OK || hipMemsetAsync(c->dStats.p, 0, (size_t)kStatShards * 64, c->stream) != hipSuccess) { delete c; return nullptr; }
     return c;
 }
@@ -355,7 +356,7 @@ void sge_context_destroy(sge_context* c) {
     drainEvents(c->evMove); drainEvents(c->evPose); drainEvents(c->evSkin); drainEvents(c->evAgents);
     DevBuf* bufs[] = {&c->dParent, &c->dDepth, &c->dLeanChain, &c->dPath, &c->dBindLocal, &c->dInvBind, &c->dRestT, &c->dRawRestT, &c->dPreRot,
                       &c->dCoeffs, &c->dCoeffCount, &c->dBonePresent, &c->dMeshPos, &c->dMeshNrm, &c->dMeshTan, &c->dMeshIdx, &c->dMeshWgt,
-                      &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dSlotOfRank, &c->dCost, &c->dHint, &c->dLists, &c->dListCounts, &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
+                      &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dSlotOfRank, &c->dCost, &c->dHint, &c->dJobTable, &c->dBlockJob, &c->dLists, &c->dListCounts, &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
                       &c->dPalettes, &c->dPoseModel, &c->dPoseLocal, &c->dMoveScratch, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
                       &c->dCellCursor, &c->dAgentMinMax, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats};
     for (DevBuf* b : bufs) b->release();
@@ -364,6 +365,7 @@ void sge_context_destroy(sge_context* c) {
     if (c->skinStream) (void)hipStreamDestroy(c->skinStream);
     if (c->evClassified) (void)hipEventDestroy(c->evClassified);
     if (c->evHeavyDone) (void)hipEventDestroy(c->evHeavyDone);
+    if (c->evTablesCopied) (void)hipEventDestroy(c->evTablesCopied);
     if (c->heavyStream) (void)hipStreamDestroy(c->heavyStream);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
@@ -568,10 +570,43 @@ int sge_skinning_encode(sge_context* c, void* d_outPositions, void* d_outNormals
     if (!c || !d_outPositions || !d_outNormals || !d_outTangents || (job_count > 0 && !jobs)) { set_error("sge_skinning_encode: bad argument"); return SGE_ERR_INVALID; }
     (void)hipSetDevice(c->device);
     { int rcj = joinSkin(c); if (rcj != SGE_OK) return rcj; }
-    for (int j = 0; j < job_count; ++j) { // RTSkinningEncoder.swift:37-54
+    for (int j = 0; j < job_count; ++j)
+        if (jobs[j].vertexCount > 0 && (jobs[j].paletteCount <= 0 || jobs[j].paletteCount > SGE_MAX_BONES)) { set_error("paletteCount out of range"); return SGE_ERR_INVALID; }
+    if (job_count > 1) {
+        // the reference dispatches once per job (RTSkinningEncoder.swift:37-54); here the whole list is one launch over a
+        // device-side job table, workgroups of up to vertsPerBlock vertices each
+        long long totalVerts = 0;
+        for (int j = 0; j < job_count; ++j) totalVerts += jobs[j].vertexCount > 0 ? jobs[j].vertexCount : 0;
+        if (totalVerts == 0) return SGE_OK;
+        long long vpb = (totalVerts / 8192 + 255) / 256 * 256;
+        const int vertsPerBlock = (int)std::min<long long>(std::max<long long>(vpb, 256), 256 * 64);
+        std::vector<SkinJobDev> table;
+        std::vector<int2> blockJob;
+        for (int j = 0; j < job_count; ++j) {
+            const sge_skinning_job& J = jobs[j];
+            if (J.vertexCount <= 0) continue;
+            const int idx = (int)table.size();
+            table.push_back(SkinJobDev{J.d_sourcePositions, J.d_sourceNormals, J.d_sourceTangents, J.d_sourceBoneIndices, J.d_sourceBoneWeights,
+                                       reinterpret_cast<const float*>(J.d_palette), J.paletteCount, J.vertexCount, (long long)J.dstBaseVertex,
+                                       J.sourceLayout == SGE_LAYOUT_PADDED16 ? 4 : 3, 0});
+            for (int v = 0; v < J.vertexCount; v += vertsPerBlock) blockJob.push_back(make_int2(idx, v));
+        }
+        int rc;
+        if ((rc = upload(c->dJobTable, table.data(), table.size() * sizeof(SkinJobDev), c->stream)) != SGE_OK) return rc;
+        if ((rc = upload(c->dBlockJob, blockJob.data(), blockJob.size() * sizeof(int2), c->stream)) != SGE_OK) return rc;
+        SGE_HIP(hipEventRecord(c->evTablesCopied, c->stream));
+        {
+            Bracket br(c, &c->evSkin);
+            launch_skin_jobs(c->dJobTable.as<SkinJobDev>(), c->dBlockJob.as<int2>(), (int)blockJob.size(), vertsPerBlock, out_layout,
+                             d_outPositions, d_outNormals, d_outTangents, c->stream);
+        }
+        SGE_HIP(hipGetLastError());
+        SGE_HIP(hipEventSynchronize(c->evTablesCopied)); // the host tables go out of scope; the kernel itself stays asynchronous
+        return SGE_OK;
+    }
+    for (int j = 0; j < job_count; ++j) {
         const sge_skinning_job& J = jobs[j];
         if (J.vertexCount <= 0) continue;
-        if (J.paletteCount <= 0 || J.paletteCount > SGE_MAX_BONES) { set_error("paletteCount out of range"); return SGE_ERR_INVALID; }
         SkinLaunch L{J.d_sourcePositions, J.d_sourceNormals, J.d_sourceTangents, J.d_sourceBoneIndices, J.d_sourceBoneWeights,
                      reinterpret_cast<const float*>(J.d_palette), J.paletteCount, J.vertexCount, 1, (long long)J.dstBaseVertex,
                      J.sourceLayout, out_layout, d_outPositions, d_outNormals, d_outTangents};

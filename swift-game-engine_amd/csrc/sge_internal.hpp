@@ -191,6 +191,16 @@ struct SkinLaunch {
     void* outPos; void* outNrm; void* outTan;
 };
 void launch_skin(const SkinLaunch& L, hipStream_t s);
+// one record per RTSkinningJob of a batched encode (device copy)
+struct SkinJobDev {
+    const void* srcPos; const void* srcNrm; const void* srcTan; const void* srcIdx; const void* srcWgt;
+    const float* palette;
+    int paletteCount, vertexCount;
+    long long dstBaseVertex;
+    int srcStride, pad;
+};
+void launch_skin_jobs(const SkinJobDev* d_jobs, const int2* d_blockJob, int blocks, int vertsPerBlock, int dstLayout,
+                      void* outPos, void* outNrm, void* outTan, hipStream_t s);
 void launch_store_probe(void* outPos, void* outNrm, void* outTan, int chars, int vertexCount, int dstLayout, hipStream_t s);
 
 void launch_agents_export(const DevCrowd& crowd, sge_agent_state* d_out, hipStream_t s);

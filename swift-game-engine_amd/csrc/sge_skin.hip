@@ -70,15 +70,10 @@ __device__ __forceinline__ VertexIn loadVertex(const SkinLaunch& L, int gid) {
 // One workgroup = one character (or 1/splits of its vertices): the palette is staged once,
 // then the 256 threads walk the vertex stream 256 at a time with the next chunk's source
 // attributes already in flight while the current chunk is transformed and stored.
+// The work of one workgroup: vertices [vBegin, vEnd) of character `c` of launch L (palette L.palettes[c]).
 template <int SRC_STRIDE, int DST_STRIDE>
-__global__ __launch_bounds__(kSkinBlock) void skin_kernel(SkinLaunch L, int splits, int vertsPerSplit) {
-    __shared__ float4 pal[SGE_MAX_BONES * 3];
-    const int c = blockIdx.x / splits;
-    const int sp = blockIdx.x - c * splits;
+__device__ __forceinline__ void skinRange(const SkinLaunch& L, const int c, const int vBegin, const int vEnd, float4* pal) {
     const int tid = threadIdx.x;
-
-    const int vBegin = sp * vertsPerSplit;
-    const int vEnd = min(L.vertexCount, vBegin + vertsPerSplit);
     int gid = vBegin + tid;
     VertexIn cur{};
     if (gid < vEnd) cur = loadVertex<SRC_STRIDE>(L, gid);
@@ -198,6 +193,38 @@ __global__ __launch_bounds__(kSkinBlock) void skin_kernel(SkinLaunch L, int spli
         if (!has2) break;
         gid = g2;
     }
+}
+
+template <int SRC_STRIDE, int DST_STRIDE>
+__global__ __launch_bounds__(kSkinBlock) void skin_kernel(SkinLaunch L, int splits, int vertsPerSplit) {
+    __shared__ float4 pal[SGE_MAX_BONES * 3];
+    const int c = blockIdx.x / splits;
+    const int sp = blockIdx.x - c * splits;
+    const int vBegin = sp * vertsPerSplit;
+    skinRange<SRC_STRIDE, DST_STRIDE>(L, c, vBegin, min(L.vertexCount, vBegin + vertsPerSplit), pal);
+}
+
+// RTSkinningEncoder.encode over a heterogeneous job list (RTSkinningEncoder.swift:37-54 dispatches once per job): ONE launch.
+// blockJob[b] = (job, first vertex) of workgroup b; every job keeps its own source streams, palette and destination offset.
+template <int DST_STRIDE>
+__global__ __launch_bounds__(kSkinBlock) void skin_jobs_kernel(const SkinJobDev* jobs, const int2* blockJob, int vertsPerBlock,
+                                                               void* outPos, void* outNrm, void* outTan) {
+    __shared__ float4 pal[SGE_MAX_BONES * 3];
+    const int2 bj = blockJob[blockIdx.x];
+    const SkinJobDev J = jobs[bj.x];
+    SkinLaunch L{J.srcPos, J.srcNrm, J.srcTan, J.srcIdx, J.srcWgt, J.palette, J.paletteCount, J.vertexCount, 1, J.dstBaseVertex,
+                 J.srcStride == 4 ? SGE_LAYOUT_PADDED16 : SGE_LAYOUT_PACKED, DST_STRIDE == 4 ? SGE_LAYOUT_PADDED16 : SGE_LAYOUT_PACKED,
+                 outPos, outNrm, outTan};
+    const int vEnd = min(J.vertexCount, bj.y + vertsPerBlock);
+    if (J.srcStride == 4) skinRange<4, DST_STRIDE>(L, 0, bj.y, vEnd, pal);
+    else skinRange<3, DST_STRIDE>(L, 0, bj.y, vEnd, pal);
+}
+
+void launch_skin_jobs(const SkinJobDev* d_jobs, const int2* d_blockJob, int blocks, int vertsPerBlock, int dstLayout,
+                      void* outPos, void* outNrm, void* outTan, hipStream_t s) {
+    if (blocks <= 0) return;
+    if (dstLayout == SGE_LAYOUT_PADDED16) hipLaunchKernelGGL((skin_jobs_kernel<4>), dim3(blocks), dim3(kSkinBlock), 0, s, d_jobs, d_blockJob, vertsPerBlock, outPos, outNrm, outTan);
+    else hipLaunchKernelGGL((skin_jobs_kernel<3>), dim3(blocks), dim3(kSkinBlock), 0, s, d_jobs, d_blockJob, vertsPerBlock, outPos, outNrm, outTan);
 }
 
 // The LBS kernel's store pattern alone (one workgroup per character, three non-temporal streams): sge_api uses it to

@@ -158,6 +158,22 @@ class CharacterEngine:
         self.mesh = dict(mesh, **keep)
         return self.mesh
 
+    def skinning_encode(self, out_positions, out_normals, out_tangents, out_layout, jobs):
+        """RTSkinningEncoder.encode: out_* are device pointers (ints) on the product, host arrays' pointers on the oracle;
+        jobs: list of dict(sourcePositions, sourceNormals, sourceTangents, sourceBoneIndices, sourceBoneWeights, palette (pointers),
+        paletteCount, vertexCount, dstBaseVertex, sourceLayout). Asynchronous on the context's stream."""
+        arr = (abi.SkinningJob * max(len(jobs), 1))()
+        for k, j in enumerate(jobs):
+            arr[k] = abi.SkinningJob(j["sourcePositions"], j["sourceNormals"], j["sourceTangents"], j["sourceBoneIndices"],
+                                     j["sourceBoneWeights"], j["palette"], j["paletteCount"], j["vertexCount"], j["dstBaseVertex"],
+                                     j.get("sourceLayout", abi.LAYOUT_PACKED))
+        if self.t.is_product:
+            self._call("skinning_encode", C.c_void_p(out_positions), C.c_void_p(out_normals), C.c_void_p(out_tangents), int(out_layout), arr, len(jobs))
+        else:
+            rc = self.t.lib.sgeo_skinning_encode(C.c_void_p(out_positions), C.c_void_p(out_normals), C.c_void_p(out_tangents), arr, len(jobs))
+            if rc != abi.SGE_OK:
+                raise SgeError("skinning_encode failed")
+
     # -- collision world --------------------------------------------------- #
     def rebuild_static(self, entities):
         """entities: list of dict(positions [V][3], indices u32, modelMatrix [16] (default identity),

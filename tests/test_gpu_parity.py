@@ -521,6 +521,86 @@ def test_long_soak_parity(sge):
     cpu.close()
 
 
+@pytest.mark.parametrize("out_layout", ["packed", "padded16"])
+def test_skinning_encode_job_list(sge, out_layout):
+    """RTSkinningEncoder.encode over a heterogeneous job list (B3): different meshes, bone counts, palettes, source layouts
+    and destination offsets in one call — one launch on the GPU — against the oracle's per-job loop; then the one-job form."""
+    import torch
+
+    A = sge.abi
+    gpu = sge.CharacterEngine(0)
+    cpu = ob.oracle_engine()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(12)
+    counts = [1, 255, 256, 257, 5000, 33, 12345]
+    bones = [3, 65, 17, 256, 65, 1, 40]
+    padded_src = [False, True, False, False, True, False, True]
+    base, total = [], 0
+    for v in counts:
+        total += int(rng.integers(0, 5))            # gaps between the jobs' destination ranges
+        base.append(total)
+        total += v
+    host_jobs, dev_jobs, keep = [], [], []
+    for v, b, pad in zip(counts, bones, padded_src):
+        pos = rng.normal(0, 1, (v, 3)).astype(np.float32)
+        nrm = rng.normal(0, 1, (v, 3)).astype(np.float32)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        tan = np.c_[rng.normal(0, 1, (v, 3)), rng.choice([-1.0, 1.0], v)].astype(np.float32)
+        idx = rng.integers(0, b, (v, 4)).astype(np.uint16)
+        wgt = rng.uniform(0, 1, (v, 4)).astype(np.float32)
+        wgt[rng.uniform(size=(v, 4)) < 0.4] = 0
+        wgt[:, 0] = np.maximum(wgt[:, 0], 0.05)
+        wgt[::17, 3] = -0.25                          # a negative weight is skipped like a zero one (`w > 0`)
+        wgt /= np.maximum(wgt, 0).sum(1, keepdims=True)
+        pal = np.tile(np.eye(4, dtype=np.float32).reshape(16), (b, 1))
+        pal[:, :12] += rng.normal(0, 0.4, (b, 12)).astype(np.float32)
+        pal[:, [3, 7, 11]] = 0
+        host = {"sourcePositions": pos, "sourceNormals": nrm, "sourceTangents": tan, "sourceBoneIndices": idx, "sourceBoneWeights": wgt, "palette": pal}
+        keep.append(host)
+        host_jobs.append(dict({k: a.ctypes.data for k, a in host.items()}, paletteCount=b, vertexCount=v, dstBaseVertex=base[len(host_jobs)]))
+        on_dev = {}
+        for k, a in host.items():
+            src = a
+            if pad and k in ("sourcePositions", "sourceNormals"):
+                src = np.zeros((v, 4), np.float32)
+                src[:, :3] = a
+            on_dev[k] = torch.from_numpy(np.ascontiguousarray(src)).to(dev)
+        keep.append(on_dev)
+        dev_jobs.append(dict({k: t.data_ptr() for k, t in on_dev.items()}, paletteCount=b, vertexCount=v, dstBaseVertex=base[len(dev_jobs)],
+                             sourceLayout=A.LAYOUT_PADDED16 if pad else A.LAYOUT_PACKED))
+    stride = 4 if out_layout == "padded16" else 3
+    layout = A.LAYOUT_PADDED16 if out_layout == "padded16" else A.LAYOUT_PACKED
+    ref = [np.full((total, 3), 7.0, np.float32), np.full((total, 3), 7.0, np.float32), np.full((total, 4), 7.0, np.float32)]
+    cpu.skinning_encode(ref[0].ctypes.data, ref[1].ctypes.data, ref[2].ctypes.data, A.LAYOUT_PACKED, host_jobs)
+
+    def run(jobs):
+        out = [torch.full((total, stride), 7.0, dtype=torch.float32, device=dev), torch.full((total, stride), 7.0, dtype=torch.float32, device=dev),
+               torch.full((total, 4), 7.0, dtype=torch.float32, device=dev)]
+        gpu.skinning_encode(out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), layout, jobs)
+        gpu.synchronize()
+        return [o.cpu().numpy() for o in out]
+
+    got = run(dev_jobs)
+    scale = np.abs(ref[0]).max()
+    assert np.abs(got[0][:, :3] - ref[0]).max() <= REL * scale
+    assert np.abs(got[1][:, :3] - ref[1]).max() <= 2e-5 and np.abs(got[2] - ref[2]).max() <= 2e-5
+    gaps = np.ones(total, bool)
+    for v, b0 in zip(counts, base):
+        gaps[b0:b0 + v] = False
+    assert (got[0][gaps] == 7.0).all() and (got[2][gaps] == 7.0).all()     # nothing written between the jobs
+    # one job at a time (the single-launch-per-job path) gives the same numbers
+    one = run(dev_jobs[4:5])
+    sl = slice(base[4], base[4] + counts[4])
+    assert np.abs(one[0][sl, :3] - ref[0][sl]).max() <= REL * scale and (one[0][: base[4]] == 7.0).all()
+    # empty list and zero-vertex jobs are no-ops (RTSkinningEncoder.swift:32-35)
+    untouched = run([])
+    assert (untouched[0] == 7.0).all()
+    untouched = run([dict(dev_jobs[1], vertexCount=0), dict(dev_jobs[2], vertexCount=0)])
+    assert (untouched[0] == 7.0).all()
+    gpu.close()
+    cpu.close()
+
+
 def test_full_size_properties(sge):
     """BASELINE.json configs[2] at full size (10k clones x 14,080 vertices vs 71,680 triangles), checked through
     size-independent properties: characters are independent, so an oracle run over a RANDOM SUBSET of the crowd
