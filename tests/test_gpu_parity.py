@@ -601,6 +601,49 @@ def test_skinning_encode_job_list(sge, out_layout):
     cpu.close()
 
 
+def test_context_buffers_and_caller_stream(sge):
+    """sge_crowd_buffers / sge_skinned_mesh_buffers / sge_context_set_stream: a caller builds RTSkinningJobs over the
+    context's own device buffers (the way RTGeometryCache.makeSkinningJob would) and runs everything on its own stream."""
+    import torch
+
+    A = sge.abi
+    gpu = sge.CharacterEngine(0)
+    lib, h = gpu.t.lib, gpu.h
+    n = 6
+    ybot, _, _ = build_scene(sge, gpu, n, terrain_cells=(16, 12), rings=5, segments=6)
+    V, B = gpu.vertex_count, gpu.bone_count
+    stream = torch.cuda.Stream(device=0)
+    assert lib.sge_context_set_stream(h, C.c_void_p(stream.cuda_stream)) == 0
+    for _ in range(5):
+        gpu.tick()
+    stream.synchronize()
+    expect = [a.copy() for a in gpu.skinned()]
+    pal, op, on, ot = (C.c_void_p() for _ in range(4))
+    assert lib.sge_crowd_buffers(h, C.byref(pal), C.byref(op), C.byref(on), C.byref(ot)) == 0
+    src = [C.c_void_p() for _ in range(5)]
+    assert lib.sge_skinned_mesh_buffers(h, *[C.byref(p) for p in src]) == 0
+    assert all(p.value for p in (pal, op, on, ot, *src))
+    # wipe the outputs, then re-skin every character through the job-list entry point, in reverse order
+    dev = torch.device("cuda", 0)
+    with torch.cuda.stream(stream):
+        scratch = [torch.zeros((n * V, 3), dtype=torch.float32, device=dev), torch.zeros((n * V, 3), dtype=torch.float32, device=dev),
+                   torch.zeros((n * V, 4), dtype=torch.float32, device=dev)]
+    jobs = [dict(sourcePositions=src[0].value, sourceNormals=src[1].value, sourceTangents=src[2].value, sourceBoneIndices=src[3].value,
+                 sourceBoneWeights=src[4].value, palette=pal.value + c * B * 64, paletteCount=B, vertexCount=V, dstBaseVertex=c * V)
+            for c in reversed(range(n))]
+    gpu.skinning_encode(scratch[0].data_ptr(), scratch[1].data_ptr(), scratch[2].data_ptr(), A.LAYOUT_PACKED, jobs)
+    stream.synchronize()
+    got = [t.cpu().numpy() for t in scratch]
+    for g, e in zip(got, expect):
+        assert np.abs(g - e).max() <= 1e-6 * max(np.abs(e).max(), 1.0)
+    # back to the context's own stream
+    assert lib.sge_context_set_stream(h, None) == 0
+    gpu.tick(dt=0.0, stages=A.STAGE_SKIN)
+    gpu.synchronize()
+    assert np.abs(gpu.skinned()[0] - expect[0]).max() <= 1e-6 * np.abs(expect[0]).max()
+    gpu.close()
+
+
 def test_full_size_properties(sge):
     """BASELINE.json configs[2] at full size (10k clones x 14,080 vertices vs 71,680 triangles), checked through
     size-independent properties: characters are independent, so an oracle run over a RANDOM SUBSET of the crowd
