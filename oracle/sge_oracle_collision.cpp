@@ -1,14 +1,14 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see sge_oracle_math.h).
 //
-// CPU float32 restatement of Game/CollisionQuery.swift (static set only; the
-// dynamic set / refit path, CollisionQuery.swift:419-462,528-575, is row f4 of
-// SURVEY.md §8 and not part of the benchmark configs):
-//   TriangleMeshSet.rebuild            :331-417
-//   BVH.build + helpers                :577-706
-//   capsuleCastCombined / capsuleCastBVH   :980-1117
-//   capsuleOverlapAll / capsuleOverlapBVHAll :852-882, :1201-1283
-//   sweepCapsuleTriangle / refineTOI   :1285-1394
-//   segmentTriangleDistance and helpers :1396-1573
+// CPU float32 restatement of Game/CollisionQuery.swift, static and dynamic triangle sets:
+//   TriangleMeshSet.rebuild / updateTransforms  :331-417, :419-462
+//   BVH.build + helpers / BVH.refit             :577-706, :528-575
+//   raycast / raycastBVH / rayTriangle / rayAABB :768-785, :916-978, :1575-1631
+//   capsuleCastCombined / capsuleCastBVH / chooseNearest   :980-1117, :909-914
+//   capsuleOverlap / capsuleOverlapBVH          :830-850, :1119-1199
+//   capsuleOverlapAll / capsuleOverlapBVHAll    :852-882, :1201-1283
+//   sweepCapsuleTriangle / refineTOI            :1285-1394
+//   segmentTriangleDistance and helpers         :1396-1573
 // Parity unpinned: the reference holds no test or golden vector for any of it
 // (GameTests/GameTests.swift:12-16 is empty); tests pin this file with analytic
 // known answers and brute-force cross-checks instead.

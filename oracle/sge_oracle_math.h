@@ -11,7 +11,9 @@
 // algorithms with a FIXED operation order and NO fused multiply-add
 // (build with -ffp-contract=off). Last-bit agreement with a Mac is therefore
 // "parity unpinned"; the pose chain is additionally pinned in float64 against
-// the reference's own Tools/FitMotion/fit_motion.py (tests/golden/).
+// the reference's own Tools/FitMotion/fit_motion.py (tests/golden/), and the
+// quaternion path (matrix -> quaternion, slerp, yaw-stable root, run lean, action
+// layer) against those vectors blended with scipy's slerp (tests/test_oracle_golden.py).
 //
 // Conventions: matrices are column-major 4x4 (columns[c][r]) exactly like
 // simd::float4x4; quaternions are stored (ix, iy, iz, r) like simd_quatf.

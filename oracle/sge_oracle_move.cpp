@@ -11,8 +11,8 @@
 //   SlideResolver.resolveHit / HitSelector   :1207-1399
 //   KinematicMoveStopSystem.fixedUpdate      :1823-1902 (+ helpers :1592-1821)
 //   PhysicsWritebackSystem (rotation part)   :2249-2267
-// PlatformCarry (:644-732) returns .zero when there are no kinematic platforms,
-// which is the case for every benchmark config; it is not restated (row f4).
+//   PlatformCarry.computeDelta               :644-732 (over the step's sge_platform_state list; meshWorldAABB :627-642
+//                                            is taken once per platform by the caller, sgeo_mesh_world_aabb)
 // Entity iteration order in the reference is Swift Dictionary order
 // (World.swift:99-117); here it is ascending character index.
 // Parity unpinned (no reference tests); see DESIGN.md.

@@ -10,11 +10,8 @@ for n in (1, 16, 256, 2048):
     sge.crowd.upload_character_assets(eng, ybot)
     terrain = sge.crowd.upload_terrain(eng)
     sge.crowd.spawn_crowd(eng, ybot, n, terrain)
-    for opt in (0, 1):
-        if opt and not hasattr(abi, "OPT_GRAPH"):
-            continue
-        if hasattr(abi, "OPT_GRAPH"):
-            eng.set_option(abi.OPT_GRAPH, opt)
+    for opt in (4000, 0):
+        eng.set_option(abi.OPT_HEAVY_THRESHOLD, opt)
         for _ in range(150):
             eng.tick()
         eng.synchronize()
@@ -27,5 +24,5 @@ for n in (1, 16, 256, 2048):
             eng.tick()
         eng.synchronize()
         t2 = time.perf_counter()
-        print("n %5d graph %d: tick+sync %.1f us/step, pipelined %.1f us/step" % (n, opt, (t1 - t0) / 300 * 1e6, (t2 - t1) / 300 * 1e6), flush=True)
+        print("n %5d heavy-threshold %d: tick+sync %.1f us/step, pipelined %.1f us/step" % (n, opt, (t1 - t0) / 300 * 1e6, (t2 - t1) / 300 * 1e6), flush=True)
     eng.close()
