@@ -3,7 +3,8 @@
  *
  * This is the drop-in boundary for ONE hot path of kelian343/swift-game-engine:
  * MotionProfile pose evaluation + bone palette, 4-weight linear-blend skinning,
- * and capsule-CCD move-and-slide against static triangle meshes.  The reference
+ * and capsule-CCD move-and-slide against the static and dynamic triangle sets of
+ * CollisionQuery (kinematic-platform carry included).  The reference
  * has no FFI layer; each entry point below names the Swift surface it replaces
  * (paths relative to the reference checkout).  A Swift host binds these through
  * a module map; tests and bench.py bind them with ctypes.
