@@ -74,7 +74,7 @@ struct sge_context {
     // collision
     HostCollision hostCol, hostDyn; // StaticTriMesh.staticSet / dynamicSet (CollisionQuery.swift:710-711)
     DevCollision col{};
-    DevBuf dWide, dTris, dMaterials, dBinNodes[2], dSlotOfRank, dPlatforms, dRayQueries, dRayOut, dCost, dHint, dLists, dListCounts, dJobTable, dBlockJob;
+    DevBuf dWide, dTris, dMaterials, dBinNodes[2], dSlotOfRank, dPlatforms, dRayQueries, dRayOut, dCost, dHint, dHeavyFlags, dLists, dListCounts, dJobTable, dBlockJob;
     int platformCount = 0;
     // crowd
     DevCrowd crowd{};
@@ -356,7 +356,7 @@ void sge_context_destroy(sge_context* c) {
     drainEvents(c->evMove); drainEvents(c->evPose); drainEvents(c->evSkin); drainEvents(c->evAgents);
     DevBuf* bufs[] = {&c->dParent, &c->dDepth, &c->dLeanChain, &c->dPath, &c->dBindLocal, &c->dInvBind, &c->dRestT, &c->dRawRestT, &c->dPreRot,
                       &c->dCoeffs, &c->dCoeffCount, &c->dBonePresent, &c->dMeshPos, &c->dMeshNrm, &c->dMeshTan, &c->dMeshIdx, &c->dMeshWgt,
-                      &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dSlotOfRank, &c->dCost, &c->dHint, &c->dJobTable, &c->dBlockJob, &c->dLists, &c->dListCounts, &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
+                      &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dSlotOfRank, &c->dCost, &c->dHint, &c->dHeavyFlags, &c->dJobTable, &c->dBlockJob, &c->dLists, &c->dListCounts, &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
                       &c->dPalettes, &c->dPoseModel, &c->dPoseLocal, &c->dMoveScratch, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
                       &c->dCellCursor, &c->dAgentMinMax, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats};
     for (DevBuf* b : bufs) b->release();
@@ -897,6 +897,7 @@ int sge_characters_resize(sge_context* c, int32_t count) {
     SGE_ZALLOC(c->dMoveScratch, N * (size_t)kMoveScratchBytes);
     SGE_ZALLOC(c->dCost, N * sizeof(int));
     SGE_ZALLOC(c->dHint, N);
+    SGE_ZALLOC(c->dHeavyFlags, N);
     SGE_ZALLOC(c->dLists, 2 * N * sizeof(int));
     SGE_ZALLOC(c->dListCounts, 2 * sizeof(int));
     if (c->storePoseDebug) { SGE_ZALLOC(c->dPoseModel, N * B * 64); SGE_ZALLOC(c->dPoseLocal, N * B * 64); }
@@ -1003,7 +1004,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         }
         MoveLaunch L{c->crowd, c->col, c->agents, d->dt, d->gravity[0], d->gravity[1], d->gravity[2], st, first, count,
                      c->dStats.as<unsigned long long>(), c->dMoveScratch.p, c->dPlatforms.as<sge_platform_state>(), c->platformCount,
-                     c->dCost.as<int>(), c->dHint.as<uint8_t>(), c->heavyThreshold >= 0 ? c->dLists.as<int>() : nullptr, c->dListCounts.as<int>(),
+                     c->dCost.as<int>(), c->dHint.as<uint8_t>(), c->heavyThreshold >= 0 ? c->dLists.as<int>() : nullptr, c->dListCounts.as<int>(), c->dHeavyFlags.as<uint8_t>(),
                      c->heavyThreshold, 2048, c->heavyStream, c->evClassified, c->evHeavyDone, nullptr, nullptr};
         if (!(st & SGE_STAGE_AGENTS) || c->agents.nx == 0) L.agents.all = nullptr;
         Bracket br(c, &c->evMove);

@@ -1327,6 +1327,21 @@ static_assert(sizeof(MoveState) <= kMoveScratchBytes, "MoveLaunch::scratch strid
 //   PART 0  intent, gravity, VelocityGate, contact-cache decay and the pre-sweep depenetration (overlap queries only)
 //   PART 1  the slide iterations, the ground probe and the write-back (cast passes only)
 // The LDS-resident MoveState crosses the boundary through K.scratch (256 B per character).
+// XCD-aware character order (workgroup b runs on XCD b % 8; give each XCD a contiguous eighth of the range so that
+// neighbouring characters share an L2): measured -0.6 % on the synthetic terrain, whose BVH fits every L2 anyway, and +3 % on
+// the merged real scene, where it also piles the expensive neighbours onto one XCD. Off.
+#ifndef SGE_XCD_REMAP
+#define SGE_XCD_REMAP 0
+#endif
+__device__ __forceinline__ int xcdRemap(int b, int n) {
+#if SGE_XCD_REMAP
+    const int x = b & 7, j = b >> 3, q = n >> 3, r = n & 7;
+    return x * q + (x < r ? x : r) + j;
+#else
+    return b;
+#endif
+}
+
 template <int PART, bool AGENTS, bool HEAVY = false>
 #ifndef SGE_MOVE_WAVES1
 #define SGE_MOVE_WAVES1 4
@@ -1334,7 +1349,8 @@ template <int PART, bool AGENTS, bool HEAVY = false>
 __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? 4 : (HEAVY ? 1 : SGE_MOVE_WAVES1)) void move_kernel(MoveLaunch K) {
     // PART 1 may run over an index list (light / heavy characters of this step, see classify_kernel)
     if (PART == 1 && K.list && (int)blockIdx.x >= *K.listCount) return;
-    const int e = (PART == 1 && K.list) ? K.list[blockIdx.x] : K.first + (int)blockIdx.x;
+    const int e = (PART == 1 && K.list) ? K.list[blockIdx.x] : K.first + xcdRemap((int)blockIdx.x, K.count);
+    if (PART == 1 && !K.list && K.heavyFlags && K.heavyFlags[e]) return; // this character runs in the four-wave launch
     const int lane = laneId();
     WaveStats st{0, 0, 0, 0, 0, 0};
     const DevCollision& col = K.col;
@@ -1562,20 +1578,21 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? 4 
     }
 }
 
-// Sorts this step's characters into the one-wave list and the four-wave list by last step's sweep cost.
-// lists: [2][count] (light, heavy); counts: [2], zeroed before the launch. Order inside a list is arbitrary (atomics);
-// results do not depend on it.
-__global__ void classify_kernel(const int* cost, int first, int count, int threshold, int heavyCap, int* lists, int* counts) {
+// Picks this step's heavy characters by last step's sweep cost: flags[e] = 1 and an entry in the heavy list (at most
+// heavyCap; the rest stay with the one-wave launch). counts[1] is zeroed before the launch; list order is arbitrary
+// (atomics) and results do not depend on it.
+__global__ void classify_kernel(const int* cost, int first, int count, int threshold, int heavyCap, int* lists, int* counts,
+                                uint8_t* flags) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const int e = first + i;
-    bool heavy = cost[e] > threshold;
-    if (heavy) {
+    uint8_t heavy = 0;
+    if (cost[e] > threshold) {
         int pos = atomicAdd(&counts[1], 1);
-        if (pos < heavyCap) { lists[count + pos] = e; return; }
-        atomicSub(&counts[1], 1);
+        if (pos < heavyCap) { lists[count + pos] = e; heavy = 1; }
+        else atomicSub(&counts[1], 1);
     }
-    lists[atomicAdd(&counts[0], 1)] = e;
+    flags[e] = heavy;
 }
 
 void launch_move(const MoveLaunch& L, hipStream_t s) {
@@ -1584,14 +1601,16 @@ void launch_move(const MoveLaunch& L, hipStream_t s) {
     if (!(L.stages & SGE_STAGE_MOVE)) return;
     const bool agents = (L.stages & SGE_STAGE_AGENTS) && L.agents.all;
     if (!L.lists) {
-        if (agents) hipLaunchKernelGGL((move_kernel<1, true>), dim3(L.count), dim3(kWave), 0, s, L);
-        else hipLaunchKernelGGL((move_kernel<1, false>), dim3(L.count), dim3(kWave), 0, s, L);
+        MoveLaunch N = L;
+        N.heavyFlags = nullptr;
+        if (agents) hipLaunchKernelGGL((move_kernel<1, true>), dim3(L.count), dim3(kWave), 0, s, N);
+        else hipLaunchKernelGGL((move_kernel<1, false>), dim3(L.count), dim3(kWave), 0, s, N);
         return;
     }
     // heavy characters first, on their own stream, so that their long single-character sweeps overlap the rest
     (void)hipMemsetAsync(L.listCounts, 0, 2 * sizeof(int), s);
     hipLaunchKernelGGL(classify_kernel, dim3((L.count + 255) / 256), dim3(256), 0, s, L.cost, L.first, L.count, L.heavyThreshold,
-                       L.heavyCap, L.lists, L.listCounts);
+                       L.heavyCap, L.lists, L.listCounts, L.heavyFlags);
     (void)hipEventRecord(L.evClassified, s);
     (void)hipStreamWaitEvent(L.heavyStream, L.evClassified, 0);
     MoveLaunch H = L;
@@ -1600,10 +1619,8 @@ void launch_move(const MoveLaunch& L, hipStream_t s) {
     if (agents) hipLaunchKernelGGL((move_kernel<1, true, true>), dim3(heavyGrid), dim3(kWave * kHeavyWaves), 0, L.heavyStream, H);
     else hipLaunchKernelGGL((move_kernel<1, false, true>), dim3(heavyGrid), dim3(kWave * kHeavyWaves), 0, L.heavyStream, H);
     (void)hipEventRecord(L.evHeavyDone, L.heavyStream);
-    MoveLaunch G = L;
-    G.list = L.lists; G.listCount = L.listCounts;
-    if (agents) hipLaunchKernelGGL((move_kernel<1, true>), dim3(L.count), dim3(kWave), 0, s, G);
-    else hipLaunchKernelGGL((move_kernel<1, false>), dim3(L.count), dim3(kWave), 0, s, G);
+    if (agents) hipLaunchKernelGGL((move_kernel<1, true>), dim3(L.count), dim3(kWave), 0, s, L); // skips flagged characters
+    else hipLaunchKernelGGL((move_kernel<1, false>), dim3(L.count), dim3(kWave), 0, s, L);
     (void)hipStreamWaitEvent(s, L.evHeavyDone, 0);
 }
 
