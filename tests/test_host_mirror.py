@@ -1,0 +1,29 @@
+"""The C++ host mirror (swift-game-engine_amd/host/sge_host.hpp): it must compile against the public header and link
+against the product library (CPU check), and behave on a GPU (tests/cpp/host_mirror_smoke.cpp)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "swift-game-engine_amd")
+SRC = os.path.join(ROOT, "tests", "cpp", "host_mirror_smoke.cpp")
+
+
+def build(tmp_path, sge):
+    exe = str(tmp_path / "host_mirror_smoke")
+    cmd = ["g++", "-std=c++17", "-Wall", "-Wextra", SRC, "-I" + os.path.join(ROOT, "include"), "-L" + PKG, "-lsge_amd",
+           "-Wl,-rpath," + PKG, "-o", exe]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_host_mirror_compiles_and_links(tmp_path, sge):
+    assert os.path.exists(build(tmp_path, sge))
+
+
+@pytest.mark.gpu
+def test_host_mirror_on_gpu(tmp_path, sge):
+    out = subprocess.run([build(tmp_path, sge)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "host mirror smoke ok" in out.stdout
