@@ -131,8 +131,11 @@ __device__ __forceinline__ int groundedNextState(int current, float speed, const
 #define SGE_POSE_WAVES 1
 #endif
 __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch K) {
-    __shared__ float sLocal[SGE_MAX_BONES * 12];
-    __shared__ float sModel[SGE_MAX_BONES * 12];
+    // local and model matrices of this character's bones, 12 floats each: sized by the launch for the skeleton's bone count
+    // (a fixed SGE_MAX_BONES-sized array would cap the CU at 6 workgroups for a 65-bone rig)
+    extern __shared__ float sPose[];
+    float* const sLocal = sPose;
+    float* const sModel = sPose + (size_t)K.sk.boneCount * 12;
     const int e = K.first + blockIdx.x;
     const int lane = threadIdx.x;
     const DevSkeleton& sk = K.sk;
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
 
 void launch_pose(const PoseLaunch& L, hipStream_t s) {
     if (L.count <= 0) return;
-    hipLaunchKernelGGL(pose_kernel, dim3(L.count), dim3(kWave), 0, s, L);
+    hipLaunchKernelGGL(pose_kernel, dim3(L.count), dim3(kWave), (size_t)L.sk.boneCount * 12 * 2 * sizeof(float), s, L);
 }
 
 } // namespace sge
