@@ -228,7 +228,7 @@ enum {
     SGE_OPT_SKIN_LAYOUT = 2,      /* SGE_LAYOUT_* for the skinned output streams */
     SGE_OPT_PROFILE = 3,          /* 1: bracket every kernel with HIP events */
     SGE_OPT_HEAVY_THRESHOLD = 5,  /* distance evaluations in a character's previous step above which its slide / ground
-                                   * pass runs in the four-wave kernel (default 4000; 0: every character that swept
+                                   * pass runs in the 8-wavefront kernel (default 4000; 0: every character that swept
                                    * anything; < 0: always the one-wave kernel). Scheduling only: results are identical. */
     SGE_OPT_PLACEMENT_PROBES = 6, /* how many candidate placements of the skinned output streams are timed when they are
                                    * (re)allocated; the fastest is kept (default 8, stops early at 6.5 TB/s; <= 1: take the

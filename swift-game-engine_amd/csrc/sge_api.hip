@@ -55,7 +55,7 @@ struct sge_context {
     hipEvent_t evClassified = nullptr, evHeavyDone = nullptr, evTablesCopied = nullptr;
     int placementProbes = 8;   // candidate placements of the skinned output streams compared at allocation time
     float placementMs = 0; int placementTried = 0;
-    int heavyThreshold = 4000; // distance evaluations in a character's last step above which it takes the 4-wave kernel; < 0: off
+    int heavyThreshold = 4000; // distance evaluations in a character's last step above which it takes the multi-wave kernel; < 0: off
     bool skinPending = false, overlapSkin = false, customStream = false;
     // options
     bool storePoseDebug = false, profile = false;

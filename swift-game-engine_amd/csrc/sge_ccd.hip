@@ -10,7 +10,7 @@
 //   sweepCapsuleTriangle / refineTOI / segmentTriangleDistance  Game/CollisionQuery.swift:1285-1573 (sge_ccd_prims.hpp)
 //
 // Mapping: ONE WAVEFRONT PER CHARACTER (64-thread workgroups; the few characters whose previous step was very
-// expensive get a 256-thread workgroup, see "heavy characters"). The per-character state machine (platform carry ->
+// expensive get a 512-thread workgroup, see "heavy characters"). The per-character state machine (platform carry ->
 // depenetration -> slide iterations -> ground probe -> snap -> friction -> write-back) is wave-uniform and lives in
 // LDS; each BVH query inside it is wave-cooperative:
 //   * traversal: a wide BVH (64 entries per node, cut out of the reference's binary tree) — one step pops a node and
@@ -179,23 +179,23 @@ enum { PH_MARCH = 0, PH_REFINE = 1, PH_FINAL = 2, PH_DONE = 3 };
 // one capsuleCastCombined (CollisionQuery.swift:980-1009)
 __device__ __forceinline__ bool rayHit(int r) { return (unsigned)(sh.rayKey[r] & 0xffffffffull) != 0xffffffffu; }
 
-// ---- heavy characters: four wavefronts sweep one character's work items --------------------------------------------
+// ---- heavy characters: eight wavefronts sweep one character's work items --------------------------------------------
 // A capsule falling beside a wall meets hundreds of triangles that each crawl through up to 256 dependent advancement
 // steps; one wavefront then needs a thousand trips for a single query while the rest of the GPU idles. Characters whose
-// previous step was that expensive run in a 256-thread workgroup: wave 0 executes the step exactly as the one-wave kernel
-// does, and whenever a cast has gathered its work items the other three waves join the sweep (items are handed out through an
+// previous step was that expensive run in a 512-thread workgroup: wave 0 executes the step exactly as the one-wave kernel
+// does, and whenever a cast has gathered its work items the other seven waves join the sweep (items are handed out through an
 // LDS cursor; the result is still the minimum (toi, visit rank) key, so the answer is bit-identical). The helper waves
 // otherwise sit in a loop matching wave 0's barriers.
 enum { HCMD_NONE = 0, HCMD_MARCH = 1, HCMD_EXIT = 2 };
 #ifndef SGE_HEAVY_WAVES
-#define SGE_HEAVY_WAVES 4
+#define SGE_HEAVY_WAVES 8
 #endif
 constexpr int kHeavyWaves = SGE_HEAVY_WAVES;
 constexpr int kHeavyItemCap = 2048;
 struct HeavyShared {
     int items[kHeavyItemCap];
     int cursor, count, cmd;
-    unsigned evalSum; // distance evaluations of the current step over all four waves (the cost the classifier reads)
+    unsigned evalSum; // distance evaluations of the current step over all the workgroup's waves (the cost the classifier reads)
     float radius, halfHeight, minNormalY;
     int blockingOnly, hasMinNormalY;
 };
@@ -297,7 +297,7 @@ __device__ __forceinline__ void heavyMarch(const DevCollision& col, WaveStats& s
     st.evals += evals >> 6; // per-lane convention of WaveStats: the kernel epilogue sums over the 64 lanes
 }
 
-// Waves 1..3 of a heavy workgroup: match every barrier of wave 0, join the sweeps it announces, leave on HCMD_EXIT.
+// Waves 1..7 of a heavy workgroup: match every barrier of wave 0, join the sweeps it announces, leave on HCMD_EXIT.
 // The iteration bound is a safety net only (a finished wave no longer takes part in barriers).
 __device__ __forceinline__ void heavyHelperLoop(const DevCollision& col, WaveStats& st) {
     for (int guard = 0; guard < (1 << 22); ++guard) {
@@ -359,7 +359,7 @@ __device__ __forceinline__ void waveCastRays(const DevCollision& col, float radi
     __syncthreads();
 
     if constexpr (HEAVY) {
-        // wave 0 of a heavy workgroup: gather work items in chunks, let all four waves sweep each chunk
+        // wave 0 of a heavy workgroup: gather work items in chunks, let all eight waves sweep each chunk
         if (lane == 0) {
             hv.radius = radius; hv.halfHeight = halfHeight; hv.minNormalY = minNormalY;
             hv.blockingOnly = blockingOnly ? 1 : 0; hv.hasMinNormalY = hasMinNormalY ? 1 : 0;
@@ -1350,7 +1350,7 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? 4 
     // PART 1 may run over an index list (light / heavy characters of this step, see classify_kernel)
     if (PART == 1 && K.list && (int)blockIdx.x >= *K.listCount) return;
     const int e = (PART == 1 && K.list) ? K.list[blockIdx.x] : K.first + xcdRemap((int)blockIdx.x, K.count);
-    if (PART == 1 && !K.list && K.heavyFlags && K.heavyFlags[e]) return; // this character runs in the four-wave launch
+    if (PART == 1 && !K.list && K.heavyFlags && K.heavyFlags[e]) return; // this character runs in the multi-wave launch
     const int lane = laneId();
     WaveStats st{0, 0, 0, 0, 0, 0};
     const DevCollision& col = K.col;

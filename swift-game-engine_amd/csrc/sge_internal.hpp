@@ -160,7 +160,7 @@ struct MoveLaunch {
     int* cost;                 // [crowd.count] distance evaluations of each character's last step
     uint8_t* hint;             // [crowd.count] 1 when the last step needed the four offset ground casts
     int* lists; int* listCounts; // heavy list at lists[count..], its length at listCounts[1] (classify_kernel)
-    uint8_t* heavyFlags;         // [crowd.count] 1: taken by the four-wave launch this step
+    uint8_t* heavyFlags;         // [crowd.count] 1: taken by the multi-wave launch this step
     int heavyThreshold, heavyCap;
     hipStream_t heavyStream; hipEvent_t evClassified, evHeavyDone;
     const int* list; const int* listCount; // what a part-1 launch iterates over (set by launch_move)

@@ -453,7 +453,7 @@ def test_kinematic_platforms_tick_parity(sge):
 
 @pytest.mark.parametrize("real", [False, True])
 def test_heavy_four_wave_kernel_parity(sge, real):
-    """SGE_OPT_HEAVY_THRESHOLD = 0 sends every character through the four-wave kernel from its second step on (the
+    """SGE_OPT_HEAVY_THRESHOLD = 0 sends every character through the multi-wave kernel from its second step on (the
     default sends only the expensive ones): scheduling must not change a single bit of the result."""
     gpu = sge.CharacterEngine(0)
     cpu = ob.oracle_engine()
@@ -488,7 +488,7 @@ def test_heavy_four_wave_kernel_parity(sge, real):
 
 def test_long_soak_parity(sge):
     """900 fixed steps (15 simulated seconds) of a mixed crowd with character-vs-character sweeps on the merged real scene,
-    default scheduling (heavy characters in the four-wave kernel, speculative ground samples): the CCD state must still
+    default scheduling (heavy characters in the multi-wave kernel, speculative ground samples): the CCD state must still
     equal the oracle's bit for bit at the end, with intents redirected on the way to keep everybody moving."""
     gpu = sge.CharacterEngine(0)
     cpu = ob.oracle_engine()
