@@ -233,6 +233,8 @@ enum {
     SGE_OPT_PLACEMENT_PROBES = 6, /* how many candidate placements of the skinned output streams are timed when they are
                                    * (re)allocated; the fastest is kept (default 8, stops early at 6.5 TB/s; <= 1: take the
                                    * first). Takes effect at the next sge_characters_resize / layout change. */
+    SGE_OPT_FUSE_BLAS_REFIT = 7,  /* 1: a tick with both SGE_STAGE_SKIN and SGE_STAGE_BLAS_REFIT folds the refit into the LBS
+                                   * kernel (the boxes are reduced from the positions while they are still in registers) */
     SGE_OPT_OVERLAP_SKIN = 4      /* 1: run the skin stage on a second stream so that it overlaps the next
                                      step's move stage (ignored on a caller-provided stream) */
 };
@@ -519,6 +521,7 @@ enum {
     SGE_STAGE_WRITEBACK = 1u << 6,  /* PhysicsWritebackSystem (rotation), Systems.swift:2249-2267 */
     SGE_STAGE_SKIN = 1u << 7,       /* RTSkinningEncoder.encode over the crowd */
     SGE_STAGE_AGENTS = 1u << 8,     /* capsule-capsule sweep vs the imported agent set, Systems.swift:1053-1091 */
+    SGE_STAGE_BLAS_REFIT = 1u << 9, /* RTAccelerationBuilder dynamic-slice refit, RTAccelerationBuilder.swift:113-145 (not in SGE_STAGE_ALL) */
     SGE_STAGE_ALL_FIXED = 0x7Fu,
     SGE_STAGE_ALL = 0xFFu
 };
@@ -570,6 +573,101 @@ typedef struct sge_move_stats {
     uint64_t sweepTrips;       /* wave-wide trips of the sweep loop (one distance evaluation per active lane each) */
 } sge_move_stats;
 int sge_move_stats_read(sge_context* ctx, sge_move_stats* out, int reset);
+
+/* ------------------------------------------------------------------------- */
+/* Skinned-geometry acceleration structures — the step after skinning:        */
+/* Game/RTAccelerationBuilder.swift:75-145 (one primitive acceleration        */
+/* structure per skinned item: built once with usage .refit, refitted every   */
+/* frame from the dynamic vertex buffer with options .vertexData), and the    */
+/* raytraceKernel's reads of the skinned streams at a hit                     */
+/* (Game/RayTracing.metalinc:242-296).                                        */
+/*                                                                            */
+/* Metal's acceleration structure is opaque; here it is a 64-wide BVH (one    */
+/* wavefront tests one wide node, one entry per lane): triangles are grouped   */
+/* into clusters of <= SGE_BLAS_CLUSTER in a spatial order, an entry is the    */
+/* box of one cluster or of one child wide node. The clones of the crowd share */
+/* one topology (they share the mesh); what a refit produces per character is  */
+/* the entries' boxes, float[entryCount + 1][6] = (min xyz, max xyz), the last  */
+/* row being the box of the whole character.                                   */
+/* ------------------------------------------------------------------------- */
+#define SGE_BLAS_WIDTH 64   /* entries per wide node */
+#define SGE_BLAS_CLUSTER 64 /* triangles per leaf entry */
+
+typedef struct sge_blas_info {
+    int32_t triangleCount;
+    int32_t clusterCount;   /* leaf entries */
+    int32_t entryCount;     /* leaf + inner entries */
+    int32_t wideCount;      /* wide nodes; node 0 is the root */
+    int32_t levels;         /* depth of the wide tree (1 = the root holds only clusters) */
+    int32_t incidenceCount; /* sum over vertices of the clusters they belong to */
+} sge_blas_info;
+
+/* Host helper (no context): the topology sge_blas_build derives from a mesh, for inspection and tests. Every
+ * output pointer may be NULL; call once for `info`, then with arrays of these sizes:
+ *   entry_link        [entryCount][2]  (a, b): a >= 0: child wide node, b = 0; a < 0: cluster of slots [~a, ~a + b)
+ *   wide_first        [wideCount + 1]  entries of wide node w = [wide_first[w], wide_first[w + 1]), at most SGE_BLAS_WIDTH;
+ *                                      children come after their parent
+ *   wide_parent_entry [wideCount]      the entry whose box is the union of wide node w's entries (-1 for the root)
+ *   slot_triangle     [triangleCount]  primitive id (triangle of the index buffer) at every slot
+ *   vertex_entry_start[vertexCount+1], vertex_entries [incidenceCount]: the clusters every vertex belongs to (CSR) */
+int sge_blas_topology(const float* positions, int32_t vertex_count, const uint32_t* indices, int32_t index_count,
+                      sge_blas_info* info, int32_t* entry_link, int32_t* wide_first, int32_t* wide_parent_entry,
+                      uint32_t* slot_triangle, int32_t* vertex_entry_start, int32_t* vertex_entries);
+
+/* encoder.build (RTAccelerationBuilder.swift:75-112) for the crowd's shared skinned mesh: `indices` is the item's
+ * slice of dynamicIndexBuffer (RTGeometryCache.swift:289-296; uint16 sources widened as there). The topology comes
+ * from the uploaded source positions; needs sge_skinned_mesh_upload first. */
+int sge_blas_build(sge_context* ctx, const uint32_t* indices, int32_t index_count);
+int sge_blas_info_get(sge_context* ctx, sge_blas_info* info);
+
+/* encoder.refit(..., options: .vertexData) (RTAccelerationBuilder.swift:113-145) for characters [first, first+count)
+ * over the context's skinned positions. Asynchronous; also runs as SGE_STAGE_BLAS_REFIT of sge_tick, after the skin
+ * stage. With SGE_OPT_FUSE_BLAS_REFIT the skin stage of the same tick produces the boxes itself and the skinned
+ * positions are not read back. */
+int sge_blas_refit(sge_context* ctx, int32_t first, int32_t count);
+/* The same over caller-owned device buffers: d_positions in `layout`, character k at vertex first_vertex + k * vertexCount;
+ * d_bounds receives [count][entryCount + 1][6]. */
+int sge_blas_refit_buffers(sge_context* ctx, const void* d_positions, int32_t layout, int64_t first_vertex,
+                           int32_t count, void* d_bounds);
+/* float [count][entryCount + 1][6] */
+int sge_blas_bounds_download(sge_context* ctx, int32_t first, int32_t count, float* bounds);
+int sge_blas_buffers(sge_context* ctx, void** d_bounds, void** d_indices);
+
+/* MTLAccelerationStructureInstanceDescriptor.transformationMatrix = item.modelMatrix
+ * (RTAccelerationBuilder.swift:168-185): column-major 4x4 per character; identity until uploaded. */
+int sge_blas_instances_upload(sge_context* ctx, int32_t first, int32_t count, const float* model_matrices);
+
+/* `ray` of the raytraceKernel (RayTracing.metalinc:231-235) against ONE instance. 48 bytes. */
+typedef struct sge_blas_ray {
+    float origin[3];
+    float minDistance;
+    float direction[3];
+    float maxDistance;
+    int32_t instance; /* character index */
+    int32_t _pad[3];
+} sge_blas_ray;
+
+/* What the kernel derives from a triangle hit (RayTracing.metalinc:246-296) before materials and lights:
+ * primitive_id, distance, triangle_barycentric_coord, the geometric normal of the world-space triangle flipped
+ * against the ray, and the interpolated shading frame (nW, tW, bW) from the skinned normal / tangent streams.
+ * 64 bytes. */
+typedef struct sge_blas_hit {
+    int32_t hit;       /* intersection_type::triangle */
+    int32_t primitive; /* hit.primitive_id: triangle of the index buffer */
+    float distance;
+    float bary[2];     /* weights of the triangle's second and third vertex */
+    float geomNormal[3];
+    float normal[3];
+    float tangent[3];
+    float bitangent[3];
+} sge_blas_hit;
+
+/* Closest hit of every ray against its instance's refitted structure. Host arrays; synchronous. Ties on distance
+ * go to the smaller primitive id. */
+int sge_blas_intersect_batch(sge_context* ctx, const sge_blas_ray* rays, int32_t count, sge_blas_hit* hits);
+
+/* HIP-event time of the refit launches since the last reset (SGE_OPT_PROFILE). */
+int sge_blas_profile_read(sge_context* ctx, double* refit_ms, int64_t* refit_launches, int reset);
 
 #ifdef __cplusplus
 }

@@ -104,6 +104,9 @@ struct World {
     std::vector<float> outPositions, outNormals, outTangents;
     // kinematic platforms of this step (PlatformCarry.computeDelta inputs, Systems.swift:644-732)
     std::vector<sge_platform_state> platforms;
+    // the skinned item's slice of dynamicIndexBuffer + per-character instance matrices (RTAccelerationBuilder.swift:75-185)
+    std::vector<uint32_t> blasIndices;
+    std::vector<float> blasInstances; // [N][16], missing rows = identity
     // agents (start-of-step snapshot over ALL ranks' characters)
     std::vector<sge_agent_state> importedAgents;
     int agentSelfOffset = 0;
@@ -119,6 +122,8 @@ void skin_characters(World& w, int first, int count);
 void skinning_kernel(int vertexCount, const float* pos, const float* nrm, const float* tan,
                      const uint16_t* idx, const float* wts, const M4* palette,
                      float* outPos, float* outNrm, float* outTan, int dstBaseVertex);
+// blas.cpp: scan over every triangle of the index buffer (RayTracing.metalinc:242-296)
+void blas_intersect(const World& w, const sge_blas_ray& ray, sge_blas_hit& hit);
 // move.cpp
 void intent_fixed_update(World& w, int first, int count, float dt);
 void gravity_fixed_update(World& w, int first, int count, float dt, V3 gravity);

@@ -290,6 +290,18 @@ int sgeo_skinned_download(sgeo_world* h, int64_t firstVertex, int64_t count, flo
     return SGE_OK;
 }
 
+// Oracle-only: overwrite the skinned streams (tests feed both sides the same vertices before comparing what a ray sees).
+int sgeo_skinned_upload(sgeo_world* h, int64_t firstVertex, int64_t count, const float* pos, const float* nrm, const float* tan) {
+    if (!h || firstVertex < 0 || count < 0) return SGE_ERR_INVALID;
+    const size_t total = h->w.bodies.size() * (size_t)h->w.mesh.vertexCount;
+    if ((size_t)(firstVertex + count) > total) return SGE_ERR_INVALID;
+    if (h->w.outPositions.size() < total * 3) { h->w.outPositions.resize(total * 3); h->w.outNormals.resize(total * 3); h->w.outTangents.resize(total * 4); }
+    if (pos) std::memcpy(&h->w.outPositions[firstVertex * 3], pos, count * 12);
+    if (nrm) std::memcpy(&h->w.outNormals[firstVertex * 3], nrm, count * 12);
+    if (tan) std::memcpy(&h->w.outTangents[firstVertex * 4], tan, count * 16);
+    return SGE_OK;
+}
+
 // RTSkinningEncoder.encode with host pointers (packed layouts)
 int sgeo_skinning_encode(float* outPos, float* outNrm, float* outTan, const sge_skinning_job* jobs, int32_t jobCount) {
     for (int j = 0; j < jobCount; ++j) {
@@ -399,6 +411,35 @@ int sgeo_move_stats_read(sgeo_world* h, sge_move_stats* out, int reset) {
     out->traversalSteps = 0;
     out->sweepTrips = 0;
     if (reset) h->stats = QueryStats();
+    return SGE_OK;
+}
+
+// ---- the step after skinning: index slice + instance matrices + brute-force closest hit (sge_oracle_blas.cpp) ----
+int sgeo_blas_build(sgeo_world* h, const uint32_t* indices, int32_t index_count) {
+    if (!h || !indices || index_count <= 0 || index_count % 3 != 0) return SGE_ERR_INVALID;
+    if (h->w.mesh.vertexCount == 0) return SGE_ERR_STATE;
+    for (int i = 0; i < index_count; ++i)
+        if (indices[i] >= (uint32_t)h->w.mesh.vertexCount) return SGE_ERR_INVALID;
+    h->w.blasIndices.assign(indices, indices + index_count);
+    return SGE_OK;
+}
+
+int sgeo_blas_instances_upload(sgeo_world* h, int32_t first, int32_t count, const float* m) {
+    if (!h || !m || first < 0 || count < 0 || (size_t)(first + count) > h->w.bodies.size()) return SGE_ERR_INVALID;
+    const size_t N = h->w.bodies.size();
+    if (h->w.blasInstances.size() != N * 16) {
+        h->w.blasInstances.assign(N * 16, 0.0f);
+        for (size_t i = 0; i < N; ++i) for (int k = 0; k < 4; ++k) h->w.blasInstances[i * 16 + k * 5] = 1.0f;
+    }
+    std::memcpy(&h->w.blasInstances[(size_t)first * 16], m, (size_t)count * 64);
+    return SGE_OK;
+}
+
+int sgeo_blas_intersect_batch(sgeo_world* h, const sge_blas_ray* rays, int32_t count, sge_blas_hit* hits) {
+    if (!h || count < 0 || (count > 0 && (!rays || !hits))) return SGE_ERR_INVALID;
+    if (h->w.blasIndices.empty() || h->w.bodies.empty()) return SGE_ERR_STATE;
+    if (h->w.outPositions.size() < h->w.bodies.size() * (size_t)h->w.mesh.vertexCount * 3) return SGE_ERR_STATE;
+    for (int i = 0; i < count; ++i) blas_intersect(h->w, rays[i], hits[i]);
     return SGE_OK;
 }
 

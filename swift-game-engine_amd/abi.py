@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-SGE_OK = 0
+SGE_OK, SGE_ERR_INVALID, SGE_ERR_DEVICE, SGE_ERR_STATE, SGE_ERR_CAPACITY = 0, 1, 2, 3, 4
 SGE_MAX_COEFFS = 17
 SGE_MAX_PLATFORMS = 64
 SET_STATIC, SET_DYNAMIC = 0, 1
@@ -35,9 +35,12 @@ CAST, CAST_BLOCKING, CAST_GROUND = 0, 1, 2
 # stages
 STAGE_INTENT, STAGE_GRAVITY, STAGE_MOVE, STAGE_LOCOMOTION = 1, 2, 4, 8
 STAGE_ACTION, STAGE_POSE, STAGE_WRITEBACK, STAGE_SKIN, STAGE_AGENTS = 16, 32, 64, 128, 256
+STAGE_BLAS_REFIT = 512
 STAGE_ALL_FIXED, STAGE_ALL = 0x7F, 0xFF
 # options
 OPT_STORE_POSE_DEBUG, OPT_SKIN_LAYOUT, OPT_PROFILE, OPT_OVERLAP_SKIN, OPT_HEAVY_THRESHOLD, OPT_PLACEMENT_PROBES = 1, 2, 3, 4, 5, 6
+OPT_FUSE_BLAS_REFIT = 7
+BLAS_WIDTH, BLAS_CLUSTER = 64, 64
 LAYOUT_PACKED, LAYOUT_PADDED16 = 0, 1
 
 f32, f64, i32, u32, u8, u16, i64, u64 = (C.c_float, C.c_double, C.c_int32, C.c_uint32, C.c_uint8,
@@ -144,6 +147,21 @@ class RaycastHit(C.Structure):
                 ("material", SurfaceMaterial)]
 
 
+class BlasInfo(C.Structure):
+    _fields_ = [("triangleCount", i32), ("clusterCount", i32), ("entryCount", i32), ("wideCount", i32), ("levels", i32),
+                ("incidenceCount", i32)]
+
+
+class BlasRay(C.Structure):
+    _fields_ = [("origin", f32 * 3), ("minDistance", f32), ("direction", f32 * 3), ("maxDistance", f32), ("instance", i32),
+                ("_pad", i32 * 3)]
+
+
+class BlasHit(C.Structure):
+    _fields_ = [("hit", i32), ("primitive", i32), ("distance", f32), ("bary", f32 * 2), ("geomNormal", f32 * 3),
+                ("normal", f32 * 3), ("tangent", f32 * 3), ("bitangent", f32 * 3)]
+
+
 class PlatformState(C.Structure):
     _fields_ = [("aabbMin", f32 * 3), ("aabbMax", f32 * 3), ("delta", f32 * 3), ("kinematic", u32), ("hasAABB", u32),
                 ("_pad", u32)]
@@ -209,6 +227,10 @@ raycast_hit_dtype = np.dtype([("hit", "<i4"), ("distance", "<f4"), ("position", 
                               ("triangleIndex", "<i4"), ("material", material_dtype)])
 platform_dtype = np.dtype([("aabbMin", "<f4", 3), ("aabbMax", "<f4", 3), ("delta", "<f4", 3), ("kinematic", "<u4"),
                            ("hasAABB", "<u4"), ("_pad", "<u4")])
+blas_ray_dtype = np.dtype([("origin", "<f4", 3), ("minDistance", "<f4"), ("direction", "<f4", 3), ("maxDistance", "<f4"),
+                           ("instance", "<i4"), ("_pad", "<i4", 3)])
+blas_hit_dtype = np.dtype([("hit", "<i4"), ("primitive", "<i4"), ("distance", "<f4"), ("bary", "<f4", 2),
+                           ("geomNormal", "<f4", 3), ("normal", "<f4", 3), ("tangent", "<f4", 3), ("bitangent", "<f4", 3)])
 overlap_hit_dtype = np.dtype([("depth", "<f4"), ("position", "<f4", 3), ("normal", "<f4", 3),
                               ("triangleNormal", "<f4", 3), ("triangleIndex", "<i4"), ("material", material_dtype)])
 bvh_node_dtype = np.dtype([("boundsMin", "<f4", 3), ("boundsMax", "<f4", 3), ("left", "<i4"), ("right", "<i4"),
@@ -217,7 +239,8 @@ for _dt, _cls in ((body_dtype, BodyState), (params_dtype, ControllerParams), (co
                   (intent_dtype, MoveIntent), (locomotion_dtype, LocomotionState), (action_dtype, ActionState),
                   (agent_dtype, AgentState), (query_dtype, CapsuleQuery), (cast_hit_dtype, CapsuleCastHit),
                   (overlap_hit_dtype, CapsuleOverlapHit), (bvh_node_dtype, BVHNode), (ray_query_dtype, RayQuery),
-                  (raycast_hit_dtype, RaycastHit), (platform_dtype, PlatformState)):
+                  (raycast_hit_dtype, RaycastHit), (platform_dtype, PlatformState), (blas_ray_dtype, BlasRay),
+                  (blas_hit_dtype, BlasHit)):
     assert _dt.itemsize == C.sizeof(_cls), (_cls.__name__, _dt.itemsize)
 
 # Every symbol include/sge_amd.h declares: name -> (restype, argtypes)
@@ -261,6 +284,16 @@ PROTOTYPES = {
     "sge_agents_import": (C.c_int, [VP, VP, i32, i32]),
     "sge_profile_read": (C.c_int, [VP, P(StageTimes), C.c_int]),
     "sge_move_stats_read": (C.c_int, [VP, P(MoveStats), C.c_int]),
+    "sge_blas_topology": (C.c_int, [VP, i32, VP, i32, P(BlasInfo), VP, VP, VP, VP, VP, VP]),
+    "sge_blas_build": (C.c_int, [VP, VP, i32]),
+    "sge_blas_info_get": (C.c_int, [VP, P(BlasInfo)]),
+    "sge_blas_refit": (C.c_int, [VP, i32, i32]),
+    "sge_blas_refit_buffers": (C.c_int, [VP, VP, i32, i64, i32, VP]),
+    "sge_blas_bounds_download": (C.c_int, [VP, i32, i32, VP]),
+    "sge_blas_buffers": (C.c_int, [VP, P(VP), P(VP)]),
+    "sge_blas_instances_upload": (C.c_int, [VP, i32, i32, VP]),
+    "sge_blas_intersect_batch": (C.c_int, [VP, VP, i32, VP]),
+    "sge_blas_profile_read": (C.c_int, [VP, P(C.c_double), P(i64), C.c_int]),
 }
 
 LIB_NAME = "libsge_amd.so"
@@ -285,6 +318,13 @@ def bind(lib, prefix="sge_", names=None):
 def load_library(path=None):
     """Loads the HIP product library. No fallback: a missing build is an error."""
     path = path or library_path()
+    # PyTorch wheels bundle their own copy of the HIP / HSA runtimes and open them by path: if this library (linked against
+    # /opt/rocm's) is loaded first, a later `import torch` brings a second runtime into the process, which then finds no
+    # GPU. Loading torch first makes both share one runtime (same sonames). torch is plumbing here, not a dependency.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")

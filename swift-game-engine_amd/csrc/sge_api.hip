@@ -86,9 +86,17 @@ struct sge_context {
     DevBuf dCellStart, dCellItems, dCellCursor, dAgentMinMax;
     // scratch for batched queries
     DevBuf dQueries, dCastOut, dOverlapOut, dCounts;
+    // skinned-geometry acceleration structure (RTAccelerationBuilder.swift:75-145)
+    std::vector<float> hostMeshPos; // source positions as uploaded: the topology is built from them
+    HostBlas hostBlas;
+    DevBlas blas{};
+    bool fuseBlas = false;
+    int blasBoundsChars = 0;
+    DevBuf dBlasEntryLink, dBlasWideFirst, dBlasWideParent, dBlasWideLevel, dBlasSlotIdx, dBlasSlotTri, dBlasVtxStart, dBlasVtxEntries,
+           dBlasIndices, dBlasBounds, dBlasInstances, dBlasRays, dBlasHits, dBlasTileStart, dBlasChunkCluster, dBlasChunkIds;
     // stats / profiling
     DevBuf dStats;
-    Events evMove, evPose, evSkin, evAgents;
+    Events evMove, evPose, evSkin, evAgents, evBlas;
 };
 
 namespace {
@@ -207,6 +215,23 @@ int allocCrowdOutputs(sge_context* c) {
         fprintf(stderr, "[sge] output placement: %d candidates, probe ms:", (int)cands.size());
         for (auto& cd : cands) fprintf(stderr, " %.3f", cd.ms);
         fprintf(stderr, " -> %.3f (good <= %.3f)\n", cands[best].ms, goodMs);
+    }
+    return SGE_OK;
+}
+
+// Per-character buffers of the acceleration structure: boxes (zeroed until the first refit) and instance matrices (identity).
+int ensureBlasBuffers(sge_context* c) {
+    if (c->blas.entryCount == 0 || c->crowd.count == 0) return SGE_OK;
+    const size_t N = (size_t)c->crowd.count, rowBytes = (size_t)(c->blas.entryCount + 1) * 24;
+    int rc;
+    if ((rc = c->dBlasBounds.alloc(N * rowBytes)) != SGE_OK) return rc;
+    SGE_HIP(hipMemsetAsync(c->dBlasBounds.p, 0, N * rowBytes, c->stream));
+    if (c->blasBoundsChars != c->crowd.count) {
+        std::vector<float> ident(N * 16, 0.0f);
+        for (size_t i = 0; i < N; ++i) ident[i * 16] = ident[i * 16 + 5] = ident[i * 16 + 10] = ident[i * 16 + 15] = 1.0f;
+        if ((rc = upload(c->dBlasInstances, ident.data(), N * 64, c->stream)) != SGE_OK) return rc;
+        SGE_HIP(hipStreamSynchronize(c->stream));
+        c->blasBoundsChars = c->crowd.count;
     }
     return SGE_OK;
 }
@@ -386,6 +411,7 @@ int sge_synchronize(sge_context* c) {
 }
 
 int sge_context_set_option(sge_context* c, int option, int value) {
+    if (c && option == SGE_OPT_FUSE_BLAS_REFIT) { c->fuseBlas = value != 0; return SGE_OK; }
     if (!c) return SGE_ERR_INVALID;
     switch (option) {
     case SGE_OPT_STORE_POSE_DEBUG: c->storePoseDebug = value != 0; break;
@@ -549,6 +575,9 @@ int sge_skinned_mesh_upload(sge_context* c, const sge_skinned_mesh_desc* d) {
     SGE_HIP(hipStreamSynchronize(s));
     c->mesh = DevMesh{d->vertexCount, c->dMeshPos.as<float>(), c->dMeshNrm.as<float>(), c->dMeshTan.as<float>(),
                       c->dMeshIdx.as<uint16_t>(), c->dMeshWgt.as<float>()};
+    c->hostMeshPos.assign(d->positions, d->positions + V * 3);
+    c->hostBlas = HostBlas{}; // a new mesh invalidates the acceleration structure built for the old one
+    c->blas = DevBlas{};
     if (c->crowd.count > 0) return allocCrowdOutputs(c);
     return SGE_OK;
 }
@@ -907,6 +936,7 @@ int sge_characters_resize(sge_context* c, int32_t count) {
                         c->dLoco.as<sge_locomotion_state>(), c->dActions.as<sge_action_state>(), c->dPalettes.as<float>(),
                         c->storePoseDebug ? c->dPoseModel.as<float>() : nullptr, c->storePoseDebug ? c->dPoseLocal.as<float>() : nullptr};
     if (c->mesh.vertexCount > 0 && (rc = allocCrowdOutputs(c)) != SGE_OK) return rc;
+    if ((rc = ensureBlasBuffers(c)) != SGE_OK) return rc;
     SGE_HIP(hipStreamSynchronize(c->stream));
     return SGE_OK;
 }
@@ -1041,9 +1071,147 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
             Bracket br(c, &c->evSkin, ss);
             launch_skin(L, ss);
         }
+        if (st & SGE_STAGE_BLAS_REFIT) { // RTAccelerationBuilder.build is enqueued right behind the skinning encoder (RayTracingScene.swift:35-43)
+            if (c->blas.entryCount == 0) { set_error("SGE_STAGE_BLAS_REFIT needs sge_blas_build"); return SGE_ERR_STATE; }
+            Bracket br(c, &c->evBlas, ss);
+            int rc = launch_blas_refit(c->blas, c->dOutPos.p, c->skinLayout, (long long)first * c->mesh.vertexCount, count,
+                                       c->dBlasBounds.as<float>() + (size_t)first * (c->blas.entryCount + 1) * 6, ss);
+            if (rc != SGE_OK) return rc;
+        }
         if (overlap) { SGE_HIP(hipEventRecord(c->evSkinDone, c->skinStream)); c->skinPending = true; }
+    } else if (st & SGE_STAGE_BLAS_REFIT) {
+        int rc = sge_blas_refit(c, first, count);
+        if (rc != SGE_OK) return rc;
     }
     SGE_HIP(hipGetLastError());
+    return SGE_OK;
+}
+
+// ---- skinned-geometry acceleration structure ------------------------------------------------
+int sge_blas_build(sge_context* c, const uint32_t* indices, int32_t index_count) {
+    if (!c || !indices || index_count <= 0) { set_error("sge_blas_build: bad argument"); return SGE_ERR_INVALID; }
+    if (c->mesh.vertexCount == 0) { set_error("sge_blas_build needs sge_skinned_mesh_upload"); return SGE_ERR_STATE; }
+    (void)hipSetDevice(c->device);
+    { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; }
+    std::string err;
+    HostBlas hb;
+    if (!hb.build(c->hostMeshPos.data(), c->mesh.vertexCount, indices, index_count, err)) { set_error(err); return SGE_ERR_INVALID; }
+    int rc;
+    hipStream_t s = c->stream;
+    if ((rc = upload(c->dBlasEntryLink, hb.entryLink.data(), hb.entryLink.size() * 4, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dBlasWideFirst, hb.wideFirst.data(), hb.wideFirst.size() * 4, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dBlasWideParent, hb.wideParentEntry.data(), hb.wideParentEntry.size() * 4, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dBlasWideLevel, hb.wideLevelStart.data(), hb.wideLevelStart.size() * 4, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dBlasSlotIdx, hb.slotIndices.data(), hb.slotIndices.size() * 4, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dBlasSlotTri, hb.slotTriangle.data(), hb.slotTriangle.size() * 4, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dBlasVtxStart, hb.vertexEntryStart.data(), hb.vertexEntryStart.size() * 4, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dBlasVtxEntries, hb.vertexEntries.data(), hb.vertexEntries.size() * 4, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dBlasIndices, indices, (size_t)index_count * 4, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dBlasTileStart, hb.tileChunkStart.data(), hb.tileChunkStart.size() * 4, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dBlasChunkCluster, hb.chunkCluster.data(), hb.chunkCluster.size() * 4, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dBlasChunkIds, hb.chunkIds.data(), hb.chunkIds.size() * 2, s)) != SGE_OK) return rc;
+    SGE_HIP(hipStreamSynchronize(s));
+    c->hostBlas = std::move(hb);
+    const HostBlas& h = c->hostBlas;
+    c->blas = DevBlas{h.entryCount(), h.wideCount(), h.triCount, h.vertexCount, h.clusterCount, h.levels,
+                      c->dBlasEntryLink.as<int2>(), c->dBlasWideFirst.as<int>(), c->dBlasWideParent.as<int>(), c->dBlasWideLevel.as<int>(),
+                      c->dBlasSlotIdx.as<uint32_t>(), c->dBlasSlotTri.as<uint32_t>(), c->dBlasVtxStart.as<int>(), c->dBlasVtxEntries.as<int>(),
+                      h.tileVerts, h.tileCount, c->dBlasTileStart.as<int>(), c->dBlasChunkCluster.as<int>(), c->dBlasChunkIds.as<uint16_t>()};
+    c->blasBoundsChars = 0;
+    return ensureBlasBuffers(c);
+}
+
+int sge_blas_info_get(sge_context* c, sge_blas_info* info) {
+    if (!c || !info) { set_error("sge_blas_info_get: bad argument"); return SGE_ERR_INVALID; }
+    if (c->blas.entryCount == 0) { set_error("no acceleration structure built"); return SGE_ERR_STATE; }
+    const HostBlas& h = c->hostBlas;
+    *info = sge_blas_info{h.triCount, h.clusterCount, h.entryCount(), h.wideCount(), h.levels, (int32_t)h.vertexEntries.size()};
+    return SGE_OK;
+}
+
+int sge_blas_refit(sge_context* c, int32_t first, int32_t count) {
+    SGE_RANGE_CHECK();
+    if (c->blas.entryCount == 0) { set_error("sge_blas_refit needs sge_blas_build"); return SGE_ERR_STATE; }
+    if (count == 0) return SGE_OK;
+    (void)hipSetDevice(c->device);
+    { int rcj = joinSkin(c); if (rcj != SGE_OK) return rcj; }
+    Bracket br(c, &c->evBlas);
+    int rc = launch_blas_refit(c->blas, c->dOutPos.p, c->outLayoutAllocated, (long long)first * c->mesh.vertexCount, count,
+                               c->dBlasBounds.as<float>() + (size_t)first * (c->blas.entryCount + 1) * 6, c->stream);
+    if (rc != SGE_OK) return rc;
+    SGE_HIP(hipGetLastError());
+    return SGE_OK;
+}
+
+int sge_blas_refit_buffers(sge_context* c, const void* d_positions, int32_t layout, int64_t first_vertex, int32_t count, void* d_bounds) {
+    if (!c || !d_positions || !d_bounds || count < 0 || first_vertex < 0 || (layout != SGE_LAYOUT_PACKED && layout != SGE_LAYOUT_PADDED16)) {
+        set_error("sge_blas_refit_buffers: bad argument");
+        return SGE_ERR_INVALID;
+    }
+    if (c->blas.entryCount == 0) { set_error("sge_blas_refit_buffers needs sge_blas_build"); return SGE_ERR_STATE; }
+    (void)hipSetDevice(c->device);
+    { int rcj = joinSkin(c); if (rcj != SGE_OK) return rcj; }
+    Bracket br(c, &c->evBlas);
+    int rc = launch_blas_refit(c->blas, d_positions, layout, (long long)first_vertex, count, reinterpret_cast<float*>(d_bounds), c->stream);
+    if (rc != SGE_OK) return rc;
+    SGE_HIP(hipGetLastError());
+    return SGE_OK;
+}
+
+int sge_blas_bounds_download(sge_context* c, int32_t first, int32_t count, float* bounds) {
+    SGE_RANGE_CHECK();
+    if (!bounds) { set_error("sge_blas_bounds_download: bad argument"); return SGE_ERR_INVALID; }
+    if (c->blas.entryCount == 0) { set_error("no acceleration structure built"); return SGE_ERR_STATE; }
+    (void)hipSetDevice(c->device);
+    { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; }
+    const size_t row = (size_t)(c->blas.entryCount + 1) * 24;
+    SGE_HIP(hipMemcpy(bounds, reinterpret_cast<const char*>(c->dBlasBounds.p) + (size_t)first * row, (size_t)count * row, hipMemcpyDeviceToHost));
+    return SGE_OK;
+}
+
+int sge_blas_buffers(sge_context* c, void** d_bounds, void** d_indices) {
+    if (!c || c->blas.entryCount == 0) { set_error("no acceleration structure built"); return SGE_ERR_STATE; }
+    if (d_bounds) *d_bounds = c->dBlasBounds.p;
+    if (d_indices) *d_indices = c->dBlasIndices.p;
+    return SGE_OK;
+}
+
+int sge_blas_instances_upload(sge_context* c, int32_t first, int32_t count, const float* model_matrices) {
+    SGE_RANGE_CHECK();
+    if (!model_matrices) { set_error("sge_blas_instances_upload: bad argument"); return SGE_ERR_INVALID; }
+    if (c->blas.entryCount == 0) { set_error("sge_blas_instances_upload needs sge_blas_build"); return SGE_ERR_STATE; }
+    (void)hipSetDevice(c->device);
+    SGE_HIP(hipMemcpyAsync(c->dBlasInstances.as<float>() + (size_t)first * 16, model_matrices, (size_t)count * 64, hipMemcpyHostToDevice, c->stream));
+    SGE_HIP(hipStreamSynchronize(c->stream));
+    return SGE_OK;
+}
+
+int sge_blas_intersect_batch(sge_context* c, const sge_blas_ray* rays, int32_t count, sge_blas_hit* hits) {
+    if (!c || count < 0 || (count > 0 && (!rays || !hits))) { set_error("sge_blas_intersect_batch: bad argument"); return SGE_ERR_INVALID; }
+    if (c->blas.entryCount == 0 || c->crowd.count == 0) { set_error("sge_blas_intersect_batch needs sge_blas_build and characters"); return SGE_ERR_STATE; }
+    if (count == 0) return SGE_OK;
+    (void)hipSetDevice(c->device);
+    { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; }
+    int rc;
+    if ((rc = upload(c->dBlasRays, rays, (size_t)count * sizeof(sge_blas_ray), c->stream)) != SGE_OK) return rc;
+    if ((rc = c->dBlasHits.alloc((size_t)count * sizeof(sge_blas_hit))) != SGE_OK) return rc;
+    BlasTrace T{c->blas, c->dOutPos.p, c->dOutNrm.p, c->dOutTan.as<float>(), c->dBlasIndices.as<uint32_t>(), c->outLayoutAllocated,
+                c->dBlasBounds.as<float>(), c->dBlasInstances.as<float>(), c->crowd.count};
+    launch_blas_intersect(T, c->dBlasRays.as<sge_blas_ray>(), count, c->dBlasHits.as<sge_blas_hit>(), c->stream);
+    SGE_HIP(hipGetLastError());
+    SGE_HIP(hipMemcpyAsync(hits, c->dBlasHits.p, (size_t)count * sizeof(sge_blas_hit), hipMemcpyDeviceToHost, c->stream));
+    SGE_HIP(hipStreamSynchronize(c->stream));
+    return SGE_OK;
+}
+
+int sge_blas_profile_read(sge_context* c, double* ms, int64_t* launches, int reset) {
+    if (!c) return SGE_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    int rc = drainEvents(c->evBlas);
+    if (rc != SGE_OK) return rc;
+    if (ms) *ms = c->evBlas.ms;
+    if (launches) *launches = c->evBlas.launches;
+    if (reset) { c->evBlas.ms = 0; c->evBlas.launches = 0; }
     return SGE_OK;
 }
 

@@ -1,0 +1,323 @@
+// Skinned-geometry acceleration structures for gfx950: the per-frame refit the reference issues right after skinning
+// (RTAccelerationBuilder.swift:113-145, `encoder.refit(... options: .vertexData)` per dynamic slice) and the reads the
+// raytraceKernel makes of the skinned streams at a hit (RayTracing.metalinc:242-296).
+//
+// Layout (include/sge_amd.h, HostBlas::build): a 64-wide BVH whose topology is shared by all clones of the mesh; what
+// changes per character and per frame is one box per entry, float[entryCount + 1][6].
+//
+// blas_refit_kernel — one workgroup per character. The skinned positions are read ONCE, coalesced, in vertex order, a
+// tile of ~4k vertices at a time into LDS; the routing "vertex -> the clusters it belongs to" (1.6 clusters per vertex
+// on the Y-Bot) is a schedule built once with the topology and shared by all clones: per tile, the vertices of every
+// cluster that reaches into it, in chunks of 16. A 16-lane group gathers a chunk's vertices from LDS, reduces with DPP
+// row shifts and folds the result into the cluster's row of an LDS table; no triangle ever gathers its three vertices from
+// HBM. The inner entries are then reduced level by level from LDS, one wavefront per wide node, and the whole table is
+// written out coalesced. HBM traffic per character: 12 B (16 B padded) per vertex in, 24 B per entry out; the index
+// buffer is not read at all. (A first version folded every vertex into its clusters with LDS atomics: 4.5 ms for 10k
+// Y-Bots, bound by the LDS atomic rate of about one lane per clock per CU.)
+//
+// blas_intersect_kernel — one wavefront per ray: a lane tests one entry's box per step, then one triangle of a
+// cluster per lane; the closest hit is the wave minimum of (distance, primitive id), so the answer does not depend on
+// the visiting order and equals a brute-force scan of the index buffer.
+#include "sge_internal.hpp"
+
+namespace sge {
+
+constexpr int kWave = 64;
+
+// min / max over the 16 lanes of a DPP row: an inclusive scan with row_shr 1, 2, 4, 8 leaves the result in lane 15 of the
+// row. Lanes whose source falls outside the row are not written by the DPP form and keep their own value. The six chains
+// are interleaved, so a register is read again only five instructions after it was written (DPP needs two wait states).
+#define SGE_DPP6(CTRL)                                                                          \
+    asm volatile("v_min_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(mnx));   \
+    asm volatile("v_min_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(mny));   \
+    asm volatile("v_min_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(mnz));   \
+    asm volatile("v_max_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(mxx));   \
+    asm volatile("v_max_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(mxy));   \
+    asm volatile("v_max_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(mxz));
+
+__device__ __forceinline__ float waveMinF(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, kWave)); return v; }
+__device__ __forceinline__ float waveMaxF(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave)); return v; }
+
+// One workgroup per character. LDS: tab[c * rows + row] (c = 0..2 minima, 3..5 maxima), then one tile of positions as
+// X[], Y[], Z[]. Per tile: the workgroup's registers already hold the tile (its loads were issued a tile earlier and
+// completed behind the previous tile's work); they are written to LDS, the next tile's loads are issued, and every
+// 16-lane group then takes chunks — up to 16 vertices of this tile that belong to one cluster — reads them from LDS,
+// reduces across its lanes and folds the result into the cluster's row with LDS float atomics (one lane, six values).
+// Nothing in the chunk loop depends on a previous load: chunk c of the tile sits at a computable address.
+template <int STRIDE>
+__global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, const float* __restrict__ positions, long long firstVertex,
+                                                                     float* __restrict__ bounds) {
+    extern __shared__ float lds[];
+    const int rows = B.entryCount + 1, tid = threadIdx.x;
+    float* tab = lds;
+    float* X = lds + rows * 6;
+    float* Y = X + B.tileVerts;
+    float* Z = Y + B.tileVerts;
+    const float inf = __builtin_inff();
+    for (int i = tid; i < rows * 6; i += kBlasRefitBlock) tab[i] = i < rows * 3 ? inf : -inf;
+    const float* P = positions + (size_t)(firstVertex + (long long)blockIdx.x * B.vertexCount) * STRIDE;
+    const int sub = tid & 15, group = tid >> 4;
+    constexpr int kGroups = kBlasRefitBlock / 16, kPerThread = kBlasTileVerts / kBlasRefitBlock, kBatch = 16;
+    float px[kPerThread], py[kPerThread], pz[kPerThread];
+    auto fetch = [&](int tile) {
+        const int base = tile * B.tileVerts, nv = min(B.tileVerts, B.vertexCount - base);
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            const int v = min(tid + k * kBlasRefitBlock, nv - 1); // past the end: reload the last vertex (never stored), no branch
+            const float* p = P + (size_t)(base + v) * STRIDE;
+            if (STRIDE == 4) { const float4 q = *reinterpret_cast<const float4*>(p); px[k] = q.x; py[k] = q.y; pz[k] = q.z; }
+            else { px[k] = p[0]; py[k] = p[1]; pz[k] = p[2]; }
+        }
+    };
+    fetch(0);
+    for (int tile = 0; tile < B.tileCount; ++tile) {
+        const int nv = min(B.tileVerts, B.vertexCount - tile * B.tileVerts);
+        __syncthreads(); // the previous tile's chunks have read X/Y/Z (first tile: the table is initialised)
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            const int v = tid + k * kBlasRefitBlock;
+            if (v < nv) { X[v] = px[k]; Y[v] = py[k]; Z[v] = pz[k]; }
+        }
+        __syncthreads();
+        // This group's chunks of the tile: c0, c0 + kGroups, ... Their ids and clusters are loaded kBatch at a time BEFORE the
+        // next tile's positions are requested: memory loads retire in order, so the chunk loop then waits only for its own
+        // (early) loads while the next tile's stay in flight behind it.
+        const int cEnd = B.tileChunkStart[tile + 1], cLast = B.tileChunkStart[B.tileCount] - 1;
+        int c0 = B.tileChunkStart[tile] + group;
+        bool first = true;
+        do {
+            int id[kBatch], cluster[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const int c = min(c0 + k * kGroups, cLast); // past the end: a valid chunk, loaded but not used
+                id[k] = B.chunkIds[(size_t)c * 16 + sub];
+                cluster[k] = B.chunkCluster[c];
+            }
+            if (first && tile + 1 < B.tileCount) fetch(tile + 1);
+            first = false;
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                if (c0 + k * kGroups < cEnd) {
+                    float mnx = X[id[k]], mny = Y[id[k]], mnz = Z[id[k]];
+                    float mxx = mnx, mxy = mny, mxz = mnz;
+                    asm volatile("s_nop 1" : "+v"(mnx), "+v"(mny), "+v"(mnz), "+v"(mxx), "+v"(mxy), "+v"(mxz));
+                    SGE_DPP6("row_shr:1") SGE_DPP6("row_shr:2") SGE_DPP6("row_shr:4") SGE_DPP6("row_shr:8")
+                    if (sub == 15) {
+                        float* r = tab + cluster[k];
+                        __hip_atomic_fetch_min(r, mnx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_min(r + rows, mny, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_min(r + 2 * rows, mnz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_max(r + 3 * rows, mxx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_max(r + 4 * rows, mxy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_max(r + 5 * rows, mxz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+            c0 += kBatch * kGroups;
+        } while (c0 < cEnd);
+    }
+    // inner entries from their wide nodes, deepest level first, one wavefront per wide node; then the table goes out
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
+    constexpr int kWaves = kBlasRefitBlock / kWave;
+    for (int lvl = B.levels - 1; lvl >= 0; --lvl) {
+        __syncthreads();
+        for (int w = B.wideLevelStart[lvl] + wave; w < B.wideLevelStart[lvl + 1]; w += kWaves) {
+            const int first = B.wideFirst[w], n = B.wideFirst[w + 1] - first;
+            const int parent = B.wideParentEntry[w];
+            const int dst = parent < 0 ? B.entryCount : parent;
+            for (int c = 0; c < 6; ++c) {
+                float k = lane < n ? tab[c * rows + first + lane] : (c < 3 ? inf : -inf);
+                k = c < 3 ? waveMinF(k) : waveMaxF(k);
+                if (lane == 0) tab[c * rows + dst] = k;
+            }
+        }
+    }
+    __syncthreads();
+    float* out = bounds + (size_t)blockIdx.x * rows * 6;
+    for (int i = tid; i < rows * 6; i += kBlasRefitBlock) {
+        const int row = i / 6, c = i - row * 6;
+        out[i] = tab[c * rows + row];
+    }
+}
+
+int launch_blas_refit(const DevBlas& B, const void* positions, int layout, long long firstVertex, int chars, float* bounds, hipStream_t s) {
+    if (chars <= 0) return SGE_OK;
+    const size_t lds = blasRefitLdsBytes(B.entryCount, B.tileVerts);
+    static bool attrSet = false;
+    if (!attrSet) {
+        SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blas_refit_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlasMaxLdsBytes));
+        SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blas_refit_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlasMaxLdsBytes));
+        attrSet = true;
+    }
+    if (layout == SGE_LAYOUT_PADDED16)
+        hipLaunchKernelGGL((blas_refit_kernel<4>), dim3(chars), dim3(kBlasRefitBlock), lds, s, B, reinterpret_cast<const float*>(positions), firstVertex, bounds);
+    else
+        hipLaunchKernelGGL((blas_refit_kernel<3>), dim3(chars), dim3(kBlasRefitBlock), lds, s, B, reinterpret_cast<const float*>(positions), firstVertex, bounds);
+    return SGE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// closest hit of one ray against one character
+// ---------------------------------------------------------------------------
+// Moller-Trumbore as the engine's own rayTriangle (CollisionQuery.swift:1575-1601), also returning the barycentrics
+__device__ __forceinline__ bool rayTriangleUV(F3 origin, F3 direction, F3 v0, F3 v1, F3 v2, float eps, float& tOut, float& uOut, float& vOut) {
+    F3 e1 = v1 - v0, e2 = v2 - v0;
+    F3 pvec = cross(direction, e2);
+    float det = dot(e1, pvec);
+    if (fabsf(det) < eps) return false;
+    float invDet = 1.0f / det;
+    F3 tvec = origin - v0;
+    float u = dot(tvec, pvec) * invDet;
+    if (u < 0 || u > 1) return false;
+    F3 qvec = cross(tvec, e1);
+    float v = dot(direction, qvec) * invDet;
+    if (v < 0 || (u + v) > 1) return false;
+    float t = dot(e2, qvec) * invDet;
+    if (!(t >= 0)) return false;
+    tOut = t + 0.0f; // -0 -> +0
+    uOut = u;
+    vOut = v;
+    return true;
+}
+
+struct Inv3 { F3 r0, r1, r2; float ok; }; // rows of the inverse of the 3x3 part
+__device__ __forceinline__ Inv3 inverse3(const Aff& m) {
+    const F3 a = m.c0, b = m.c1, c = m.c2;
+    const F3 bc = cross(b, c), ca = cross(c, a), ab = cross(a, b);
+    const float det = dot(a, bc);
+    const float r = 1.0f / det;
+    return Inv3{bc * r, ca * r, ab * r, det};
+}
+__device__ __forceinline__ F3 mul3(const Inv3& m, F3 v) { return F3{dot(m.r0, v), dot(m.r1, v), dot(m.r2, v)}; }
+
+template <int STRIDE>
+__device__ __forceinline__ F3 loadP(const float* base, uint32_t i) { const float* p = base + (size_t)i * STRIDE; return F3{p[0], p[1], p[2]}; }
+
+constexpr int kBlasStack = 256;
+
+template <int STRIDE>
+__global__ __launch_bounds__(kWave) void blas_intersect_kernel(BlasTrace T, const sge_blas_ray* rays, int n, sge_blas_hit* hits) {
+    __shared__ int stack[kBlasStack];
+    const int lane = threadIdx.x;
+    const sge_blas_ray R = rays[blockIdx.x];
+    const DevBlas& B = T.blas;
+    sge_blas_hit H{};
+    H.primitive = -1;
+    if (R.instance < 0 || R.instance >= T.chars) { if (lane == 0) hits[blockIdx.x] = H; return; }
+    const float* Mf = T.instances + (size_t)R.instance * 16;
+    const Aff M{F3{Mf[0], Mf[1], Mf[2]}, F3{Mf[4], Mf[5], Mf[6]}, F3{Mf[8], Mf[9], Mf[10]}, F3{Mf[12], Mf[13], Mf[14]}};
+    const Inv3 Mi = inverse3(M);
+    const F3 wo{R.origin[0], R.origin[1], R.origin[2]}, wd{R.direction[0], R.direction[1], R.direction[2]};
+    const F3 o = mul3(Mi, wo - M.c3), d = mul3(Mi, wd);
+    const F3 inv{d.x != 0 ? 1.0f / d.x : kFloatMax, d.y != 0 ? 1.0f / d.y : kFloatMax, d.z != 0 ? 1.0f / d.z : kFloatMax};
+    const float tMin = smax(R.minDistance, 0.0f);
+    const size_t vbase = (size_t)R.instance * B.vertexCount;
+    const float* P = reinterpret_cast<const float*>(T.positions) + vbase * STRIDE;
+    const float* boxes = T.bounds + (size_t)R.instance * (B.entryCount + 1) * 6;
+
+    // best = (distance bits, primitive id); distances are >= 0, so their bit patterns order like the values
+    unsigned long long best = ((unsigned long long)__float_as_uint(R.maxDistance) << 32) | 0xffffffffull;
+    float bestU = 0, bestV = 0;
+    bool found = false;
+    int sp = 0;
+    if (lane == 0) stack[0] = 0;
+    sp = 1;
+    __syncthreads();
+    while (sp > 0) {
+        const int w = stack[sp - 1];
+        --sp;
+        __syncthreads();
+        const int first = B.wideFirst[w], cnt = B.wideFirst[w + 1] - first;
+        bool pass = false;
+        int2 link = make_int2(0, 0);
+        if (lane < cnt) {
+            const float* bx = boxes + (size_t)(first + lane) * 6;
+            link = B.entryLink[first + lane];
+            // slab test (CollisionQuery.swift:1603-1630 form), widened: a box is only skipped when it is clearly behind the best hit
+            float t0 = (bx[0] - o.x) * inv.x, t1 = (bx[3] - o.x) * inv.x;
+            float lo = fminf(t0, t1), hi = fmaxf(t0, t1);
+            t0 = (bx[1] - o.y) * inv.y; t1 = (bx[4] - o.y) * inv.y;
+            lo = fmaxf(lo, fminf(t0, t1)); hi = fminf(hi, fmaxf(t0, t1));
+            t0 = (bx[2] - o.z) * inv.z; t1 = (bx[5] - o.z) * inv.z;
+            lo = fmaxf(lo, fminf(t0, t1)); hi = fminf(hi, fmaxf(t0, t1));
+            const float bestT = __uint_as_float((unsigned)(best >> 32));
+            const float slack = 1e-3f * fmaxf(fabsf(lo), fabsf(hi)) + 1e-4f;
+            pass = (lo - slack <= hi + slack) && (hi + slack >= tMin) && (lo - slack <= bestT);
+        }
+        const unsigned long long inner = __ballot(pass && link.x >= 0), leaves = __ballot(pass && link.x < 0);
+        if (pass && link.x >= 0) {
+            const int at = sp + __popcll(inner & ((1ull << lane) - 1));
+            if (at < kBlasStack) stack[at] = link.x;
+        }
+        sp = min(sp + __popcll(inner), kBlasStack);
+        unsigned long long m = leaves;
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int firstSlot = ~__shfl(link.x, src, kWave), count = __shfl(link.y, src, kWave);
+            unsigned long long key = ~0ull;
+            float u = 0, v = 0;
+            if (lane < count) {
+                const uint32_t* ix = B.slotIndices + (size_t)(firstSlot + lane) * 3;
+                const F3 v0 = loadP<STRIDE>(P, ix[0]), v1 = loadP<STRIDE>(P, ix[1]), v2 = loadP<STRIDE>(P, ix[2]);
+                float t;
+                if (rayTriangleUV(o, d, v0, v1, v2, 1e-6f, t, u, v) && t >= tMin && t <= R.maxDistance)
+                    key = ((unsigned long long)__float_as_uint(t) << 32) | B.slotTriangle[firstSlot + lane];
+            }
+            unsigned long long k = key;
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned lo32 = __shfl_xor((unsigned)k, off, kWave), hi32 = __shfl_xor((unsigned)(k >> 32), off, kWave);
+                const unsigned long long other = ((unsigned long long)hi32 << 32) | lo32;
+                k = other < k ? other : k;
+            }
+            if (k != ~0ull && k < best) {
+                best = k;
+                found = true;
+                const int winner = __ffsll((long long)__ballot(key == k)) - 1;
+                bestU = __shfl(u, winner, kWave);
+                bestV = __shfl(v, winner, kWave);
+            }
+        }
+        __syncthreads();
+    }
+    if (lane != 0) return;
+    if (found) {
+        const uint32_t prim = (uint32_t)best;
+        const float t = __uint_as_float((unsigned)(best >> 32));
+        const uint32_t* ix = T.indices + (size_t)prim * 3;
+        const uint32_t i0 = ix[0], i1 = ix[1], i2 = ix[2];
+        // RayTracing.metalinc:258-268
+        const F3 w0 = affMulPoint(M, loadP<STRIDE>(P, i0)), w1 = affMulPoint(M, loadP<STRIDE>(P, i1)), w2 = affMulPoint(M, loadP<STRIDE>(P, i2));
+        F3 N = normalize(cross(w1 - w0, w2 - w0));
+        if (dot(N, wd) > 0.0f) N = -N;
+        // :283-300
+        const float* NB = reinterpret_cast<const float*>(T.normals) + vbase * STRIDE;
+        const float* TB = T.tangents + vbase * 4;
+        const float bx = bestU, by = bestV, bw = 1.0f - bx - by;
+        const F3 n0 = loadP<STRIDE>(NB, i0), n1 = loadP<STRIDE>(NB, i1), n2 = loadP<STRIDE>(NB, i2);
+        const float* q0 = TB + (size_t)i0 * 4; const float* q1 = TB + (size_t)i1 * 4; const float* q2 = TB + (size_t)i2 * 4;
+        const F3 nObj = normalize((n0 * bw + n1 * bx) + n2 * by);
+        float t4[4];
+        for (int k = 0; k < 4; ++k) t4[k] = (q0[k] * bw + q1[k] * bx) + q2[k] * by;
+        const float r4 = 1.0f / sqrtf(((t4[0] * t4[0] + t4[1] * t4[1]) + t4[2] * t4[2]) + t4[3] * t4[3]);
+        const F3 tObj = normalize(F3{t4[0] * r4, t4[1] * r4, t4[2] * r4});
+        const float tw = t4[3] * r4;
+        const F3 nW = normalize((M.c0 * nObj.x + M.c1 * nObj.y) + M.c2 * nObj.z);
+        const F3 tW = normalize((M.c0 * tObj.x + M.c1 * tObj.y) + M.c2 * tObj.z);
+        const F3 bW = normalize(cross(nW, tW) * tw);
+        H.hit = 1; H.primitive = (int32_t)prim; H.distance = t; H.bary[0] = bx; H.bary[1] = by;
+        H.geomNormal[0] = N.x; H.geomNormal[1] = N.y; H.geomNormal[2] = N.z;
+        H.normal[0] = nW.x; H.normal[1] = nW.y; H.normal[2] = nW.z;
+        H.tangent[0] = tW.x; H.tangent[1] = tW.y; H.tangent[2] = tW.z;
+        H.bitangent[0] = bW.x; H.bitangent[1] = bW.y; H.bitangent[2] = bW.z;
+    }
+    hits[blockIdx.x] = H;
+}
+
+void launch_blas_intersect(const BlasTrace& T, const sge_blas_ray* d_rays, int n, sge_blas_hit* d_hits, hipStream_t s) {
+    if (n <= 0) return;
+    if (T.layout == SGE_LAYOUT_PADDED16) hipLaunchKernelGGL((blas_intersect_kernel<4>), dim3(n), dim3(kWave), 0, s, T, d_rays, n, d_hits);
+    else hipLaunchKernelGGL((blas_intersect_kernel<3>), dim3(n), dim3(kWave), 0, s, T, d_rays, n, d_hits);
+}
+
+} // namespace sge

@@ -311,6 +311,160 @@ void HostCollision::buildWide() {
     }
 }
 
+// ---------------------------------------------------------------------------
+// HostBlas::build — topology of the skinned-geometry acceleration structure (RTAccelerationBuilder.swift:75-112 builds
+// one per skinned item; Metal's result is opaque, so the layout is this library's own): triangles are split at the
+// centroid median of the widest centroid axis, left halves rounded up to whole clusters of 64, until a range holds
+// <= 64 triangles (a cluster); the binary tree is then cut into 64-entry wide nodes, top down, every wide node expanding
+// its largest entries until each holds at most 64^(levels below - 1) clusters. Deterministic: ties on the centroid go
+// to the smaller triangle index, triangles inside a cluster are ordered by index.
+// ---------------------------------------------------------------------------
+bool HostBlas::build(const float* pos, int V, const uint32_t* idx, int indexCount, std::string& err) {
+    *this = HostBlas{};
+    if (!pos || !idx || V <= 0 || indexCount < 3 || indexCount % 3 != 0) { err = "blas: needs positions and a non-empty triangle list"; return false; }
+    const int T = indexCount / 3;
+    for (int i = 0; i < indexCount; ++i)
+        if (idx[i] >= (uint32_t)V) { err = "blas: vertex index out of range"; return false; }
+    std::vector<float> cen((size_t)T * 3);
+    for (int t = 0; t < T; ++t)
+        for (int k = 0; k < 3; ++k)
+            cen[(size_t)t * 3 + k] = ((pos[(size_t)idx[t * 3] * 3 + k] + pos[(size_t)idx[t * 3 + 1] * 3 + k]) + pos[(size_t)idx[t * 3 + 2] * 3 + k]) * (1.0f / 3.0f);
+    std::vector<int> order(T);
+    for (int t = 0; t < T; ++t) order[t] = t;
+    struct BNode { int begin, end, left, right; };
+    std::vector<BNode> nodes;
+    nodes.reserve((size_t)T / 16 + 8);
+    // explicit stack: (node index) to split
+    nodes.push_back(BNode{0, T, -1, -1});
+    std::vector<int> todo{0};
+    while (!todo.empty()) {
+        const int ni = todo.back();
+        todo.pop_back();
+        const int begin = nodes[ni].begin, end = nodes[ni].end, n = end - begin;
+        if (n <= SGE_BLAS_CLUSTER) { std::sort(order.begin() + begin, order.begin() + end); continue; }
+        float mn[3] = {kFloatMax, kFloatMax, kFloatMax}, mx[3] = {-kFloatMax, -kFloatMax, -kFloatMax};
+        for (int s = begin; s < end; ++s)
+            for (int k = 0; k < 3; ++k) {
+                const float c = cen[(size_t)order[s] * 3 + k];
+                if (c < mn[k]) mn[k] = c;
+                if (c > mx[k]) mx[k] = c;
+            }
+        int axis = 0;
+        if (mx[1] - mn[1] > mx[axis] - mn[axis]) axis = 1;
+        if (mx[2] - mn[2] > mx[axis] - mn[axis]) axis = 2;
+        const int clusters = (n + SGE_BLAS_CLUSTER - 1) / SGE_BLAS_CLUSTER;
+        const int leftCount = (clusters + 1) / 2 * SGE_BLAS_CLUSTER;
+        std::nth_element(order.begin() + begin, order.begin() + begin + leftCount, order.begin() + end, [&](int a, int b) {
+            const float ca = cen[(size_t)a * 3 + axis], cb = cen[(size_t)b * 3 + axis];
+            return ca < cb || (ca == cb && a < b);
+        });
+        const int l = (int)nodes.size();
+        nodes.push_back(BNode{begin, begin + leftCount, -1, -1});
+        nodes.push_back(BNode{begin + leftCount, end, -1, -1});
+        nodes[ni].left = l;
+        nodes[ni].right = l + 1;
+        todo.push_back(l);
+        todo.push_back(l + 1);
+    }
+    auto clustersOf = [&](int ni) { return (nodes[ni].end - nodes[ni].begin + SGE_BLAS_CLUSTER - 1) / SGE_BLAS_CLUSTER; };
+
+    // cut into wide nodes, breadth first (children are numbered after all nodes of their parent's level)
+    struct Pending { int binary, parentEntry; };
+    std::vector<Pending> level{Pending{0, -1}}, next;
+    wideFirst.push_back(0);
+    wideLevelStart.push_back(0);
+    int wideTotal = 1; // wide nodes numbered so far (including the ones waiting in `level` / `next`)
+    while (!level.empty()) {
+        next.clear();
+        for (const Pending& pn : level) {
+            long long target = 1;
+            while (target * SGE_BLAS_WIDTH < clustersOf(pn.binary)) target *= SGE_BLAS_WIDTH;
+            std::vector<int> ents{pn.binary};
+            while (true) {
+                int pick = -1;
+                for (int k = 0; k < (int)ents.size(); ++k)
+                    if (nodes[ents[k]].left >= 0 && clustersOf(ents[k]) > target && (pick < 0 || clustersOf(ents[k]) > clustersOf(ents[pick]))) pick = k;
+                if (pick < 0) break;
+                const int b = ents[pick];
+                ents[pick] = nodes[b].left;
+                ents.insert(ents.begin() + pick + 1, nodes[b].right);
+            }
+            if ((int)ents.size() > SGE_BLAS_WIDTH) { err = "blas: internal error, wide node overflow"; return false; }
+            wideParentEntry.push_back(pn.parentEntry);
+            for (int b : ents) {
+                const int e = entryCount();
+                if (nodes[b].left < 0) {
+                    entryLink.push_back(~nodes[b].begin);
+                    entryLink.push_back(nodes[b].end - nodes[b].begin);
+                    ++clusterCount;
+                } else {
+                    entryLink.push_back(wideTotal++);
+                    entryLink.push_back(0);
+                    next.push_back(Pending{b, e});
+                }
+            }
+            wideFirst.push_back(entryCount());
+        }
+        wideLevelStart.push_back((int)wideParentEntry.size());
+        ++levels;
+        level.swap(next);
+    }
+    tileCount = (V + kBlasTileVerts - 1) / kBlasTileVerts;
+    tileVerts = ((V + tileCount - 1) / tileCount + 63) / 64 * 64;
+    tileCount = (V + tileVerts - 1) / tileVerts;
+    if (blasRefitLdsBytes(entryCount(), tileVerts) > kBlasMaxLdsBytes) { err = "blas: mesh too large (more than ~250k triangles per character)"; return false; }
+
+    triCount = T;
+    vertexCount = V;
+    slotTriangle.resize(T);
+    slotIndices.resize((size_t)T * 3);
+    for (int s = 0; s < T; ++s) {
+        slotTriangle[s] = (uint32_t)order[s];
+        for (int k = 0; k < 3; ++k) slotIndices[(size_t)s * 3 + k] = idx[(size_t)order[s] * 3 + k];
+    }
+    // vertex -> clusters (sorted, unique)
+    std::vector<std::pair<int, int>> inc; // (vertex, entry)
+    inc.reserve((size_t)T * 3);
+    for (int e = 0; e < entryCount(); ++e) {
+        if (entryLink[e * 2] >= 0) continue;
+        const int first = ~entryLink[e * 2], cnt = entryLink[e * 2 + 1];
+        for (int s = first; s < first + cnt; ++s)
+            for (int k = 0; k < 3; ++k) inc.emplace_back((int)slotIndices[(size_t)s * 3 + k], e);
+    }
+    std::sort(inc.begin(), inc.end());
+    inc.erase(std::unique(inc.begin(), inc.end()), inc.end());
+    vertexEntryStart.assign((size_t)V + 1, 0);
+    vertexEntries.resize(inc.size());
+    for (size_t i = 0; i < inc.size(); ++i) { vertexEntryStart[(size_t)inc[i].first + 1]++; vertexEntries[i] = inc[i].second; }
+    for (int v = 0; v < V; ++v) vertexEntryStart[(size_t)v + 1] += vertexEntryStart[v];
+
+    // refit schedule (see HostBlas): per tile, the (cluster, vertices of the tile in it) pairs cut into chunks of 16
+    std::vector<std::vector<uint16_t>> bucket(entryCount());
+    std::vector<int> touched;
+    tileChunkStart.assign(1, 0);
+    for (int tile = 0; tile < tileCount; ++tile) {
+        const int base = tile * tileVerts, end = std::min(V, base + tileVerts);
+        touched.clear();
+        for (int v = base; v < end; ++v)
+            for (int j = vertexEntryStart[v]; j < vertexEntryStart[(size_t)v + 1]; ++j) {
+                const int e = vertexEntries[j];
+                if (bucket[e].empty()) touched.push_back(e);
+                bucket[e].push_back((uint16_t)(v - base));
+            }
+        std::sort(touched.begin(), touched.end());
+        for (int e : touched) {
+            const std::vector<uint16_t>& ids = bucket[e];
+            for (size_t k = 0; k < ids.size(); k += 16) {
+                chunkCluster.push_back(e);
+                for (size_t j = 0; j < 16; ++j) chunkIds.push_back(k + j < ids.size() ? ids[k + j] : ids[k]);
+            }
+            bucket[e].clear();
+        }
+        tileChunkStart.push_back((int)chunkCluster.size());
+    }
+    return true;
+}
+
 } // namespace sge
 
 using namespace sge;
@@ -384,6 +538,22 @@ int sge_mesh_tangents_compute(int32_t vCount, const float* positions, const floa
         float w = dot(cross(n, t), tan2[i]) < 0.0f ? -1.0f : 1.0f;
         o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = w;
     }
+    return SGE_OK;
+}
+
+int sge_blas_topology(const float* positions, int32_t vertex_count, const uint32_t* indices, int32_t index_count,
+                      sge_blas_info* info, int32_t* entry_link, int32_t* wide_first, int32_t* wide_parent_entry,
+                      uint32_t* slot_triangle, int32_t* vertex_entry_start, int32_t* vertex_entries) {
+    HostBlas hb;
+    std::string err;
+    if (!hb.build(positions, vertex_count, indices, index_count, err)) { set_error(err); return SGE_ERR_INVALID; }
+    if (info) *info = sge_blas_info{hb.triCount, hb.clusterCount, hb.entryCount(), hb.wideCount(), hb.levels, (int32_t)hb.vertexEntries.size()};
+    if (entry_link) std::memcpy(entry_link, hb.entryLink.data(), hb.entryLink.size() * 4);
+    if (wide_first) std::memcpy(wide_first, hb.wideFirst.data(), hb.wideFirst.size() * 4);
+    if (wide_parent_entry) std::memcpy(wide_parent_entry, hb.wideParentEntry.data(), hb.wideParentEntry.size() * 4);
+    if (slot_triangle) std::memcpy(slot_triangle, hb.slotTriangle.data(), hb.slotTriangle.size() * 4);
+    if (vertex_entry_start) std::memcpy(vertex_entry_start, hb.vertexEntryStart.data(), hb.vertexEntryStart.size() * 4);
+    if (vertex_entries) std::memcpy(vertex_entries, hb.vertexEntries.data(), hb.vertexEntries.size() * 4);
     return SGE_OK;
 }
 

@@ -148,6 +148,50 @@ struct HostCollision {
     void reboundWide();
 };
 
+// ---- skinned-geometry acceleration structure (sge_host.cpp builds, sge_blas.hip refits / traverses) ---- //
+// Topology shared by every clone of the mesh; see include/sge_amd.h for the meaning of the arrays.
+struct HostBlas {
+    int triCount = 0, vertexCount = 0, clusterCount = 0, levels = 0;
+    std::vector<int> entryLink;          // [E][2]
+    std::vector<int> wideFirst;          // [W + 1]
+    std::vector<int> wideParentEntry;    // [W]
+    std::vector<int> wideLevelStart;     // [levels + 1]: wide nodes are numbered level by level (breadth first)
+    std::vector<uint32_t> slotTriangle;  // [T]
+    std::vector<uint32_t> slotIndices;   // [T][3]: vertex indices of the triangle at every slot
+    std::vector<int> vertexEntryStart, vertexEntries; // CSR vertex -> clusters
+    // refit schedule: the vertex stream is cut into tiles of tileVerts vertices; a chunk = up to 16 vertices of ONE tile
+    // that belong to ONE cluster (ids local to the tile, padded by repeating the first), the work of one 16-lane group
+    int tileVerts = 0, tileCount = 0;
+    std::vector<int> tileChunkStart;     // [tileCount + 1]
+    std::vector<int> chunkCluster;       // [chunkCount] leaf entry
+    std::vector<uint16_t> chunkIds;      // [chunkCount][16]
+    int entryCount() const { return (int)entryLink.size() / 2; }
+    int wideCount() const { return (int)wideParentEntry.size(); }
+    // false + message when the mesh cannot be handled
+    bool build(const float* positions, int vertexCount, const uint32_t* indices, int indexCount, std::string& err);
+};
+
+struct DevBlas {
+    int entryCount, wideCount, triCount, vertexCount, clusterCount, levels;
+    const int2* entryLink;
+    const int* wideFirst;
+    const int* wideParentEntry;
+    const int* wideLevelStart;
+    const uint32_t* slotIndices;
+    const uint32_t* slotTriangle;
+    const int* vertexEntryStart;
+    const int* vertexEntries;
+    int tileVerts, tileCount;
+    const int* tileChunkStart;
+    const int* chunkCluster;
+    const uint16_t* chunkIds;
+};
+constexpr int kBlasRefitBlock = 512;
+constexpr int kBlasTileVerts = 4096; // vertices staged in LDS at a time (48 KB): kBlasRefitBlock threads x 8
+// LDS of the refit kernel: the box table, six floats per row, (entryCount + 1) rows, + one tile of positions (SoA)
+inline size_t blasRefitLdsBytes(int entryCount, int tileVerts) { return (size_t)(entryCount + 1) * 24 + (size_t)tileVerts * 12; }
+constexpr size_t kBlasMaxLdsBytes = 144 * 1024; // of the CU's 160 KB
+
 // ---- kernel launchers ----------------------------------------------------- //
 struct MoveLaunch {
     DevCrowd crowd; DevCollision col; DevAgents agents;
@@ -205,5 +249,19 @@ void launch_skin_jobs(const SkinJobDev* d_jobs, const int2* d_blockJob, int bloc
 void launch_store_probe(void* outPos, void* outNrm, void* outTan, int chars, int vertexCount, int dstLayout, hipStream_t s);
 
 void launch_agents_export(const DevCrowd& crowd, sge_agent_state* d_out, hipStream_t s);
+
+// boxes of `chars` characters: character k reads vertices [firstVertex + k * vertexCount, +vertexCount) of `positions`
+// (layout SGE_LAYOUT_*) and writes bounds[k][entryCount + 1][6]
+int launch_blas_refit(const DevBlas& B, const void* positions, int layout, long long firstVertex, int chars, float* bounds, hipStream_t s);
+struct BlasTrace {
+    DevBlas blas;
+    const void* positions; const void* normals; const float* tangents; // skinned streams of the crowd
+    const uint32_t* indices; // [T][3] in primitive order (the item's slice of dynamicIndexBuffer)
+    int layout;
+    const float* bounds;     // [chars][entryCount + 1][6]
+    const float* instances;  // [chars][16] model matrices
+    int chars;
+};
+void launch_blas_intersect(const BlasTrace& T, const sge_blas_ray* d_rays, int n, sge_blas_hit* d_hits, hipStream_t s);
 
 } // namespace sge

@@ -331,6 +331,71 @@ class CharacterEngine:
         d.first, d.count = first, count
         self._call("tick", C.byref(d))
 
+    # -- skinned-geometry acceleration structure (RTAccelerationBuilder.swift:75-145) -- #
+    @staticmethod
+    def blas_topology(positions, indices, lib=None):
+        """Host helper (no GPU): the wide-BVH topology sge_blas_build derives from a mesh -> dict of arrays + 'info'."""
+        lib = lib or abi.load_library()
+        pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        idx = np.ascontiguousarray(indices, np.uint32).reshape(-1)
+        info = abi.BlasInfo()
+        args = (ptr(pos), pos.shape[0], ptr(idx), idx.shape[0], C.byref(info))
+        if lib.sge_blas_topology(*args, None, None, None, None, None, None) != abi.SGE_OK:
+            raise SgeError("blas_topology failed: " + lib.sge_last_error().decode())
+        out = {"info": info,
+               "entryLink": np.zeros((info.entryCount, 2), np.int32), "wideFirst": np.zeros(info.wideCount + 1, np.int32),
+               "wideParentEntry": np.zeros(info.wideCount, np.int32), "slotTriangle": np.zeros(info.triangleCount, np.uint32),
+               "vertexEntryStart": np.zeros(pos.shape[0] + 1, np.int32), "vertexEntries": np.zeros(info.incidenceCount, np.int32)}
+        rc = lib.sge_blas_topology(*args, ptr(out["entryLink"]), ptr(out["wideFirst"]), ptr(out["wideParentEntry"]),
+                                   ptr(out["slotTriangle"]), ptr(out["vertexEntryStart"]), ptr(out["vertexEntries"]))
+        if rc != abi.SGE_OK:
+            raise SgeError("blas_topology failed")
+        return out
+
+    def blas_build(self, indices):
+        """encoder.build for the crowd's shared mesh; indices = the item's slice of the dynamic index buffer."""
+        idx = np.ascontiguousarray(indices, np.uint32).reshape(-1)
+        self._call("blas_build", ptr(idx), idx.shape[0])
+        self.blas_indices = idx
+        if self.t.is_product:
+            info = abi.BlasInfo()
+            self._call("blas_info_get", C.byref(info))
+            self.blas_info = info
+            return info
+        return None
+
+    def blas_refit(self, first=0, count=None):
+        """encoder.refit(options: .vertexData) over the context's skinned positions. Asynchronous."""
+        self._call("blas_refit", first, self.count - first if count is None else count)
+
+    def blas_bounds(self, first=0, count=None):
+        count = self.count - first if count is None else count
+        out = np.zeros((count, self.blas_info.entryCount + 1, 6), np.float32)
+        self._call("blas_bounds_download", first, count, ptr(out))
+        return out
+
+    def blas_instances(self, model_matrices, first=0):
+        m = np.ascontiguousarray(model_matrices, np.float32).reshape(-1, 16)
+        self._call("blas_instances_upload", first, m.shape[0], ptr(m))
+
+    def blas_intersect(self, origins, directions, instances, min_distance=0.001, max_distance=1e6):
+        """`isect.intersect(ray, accel)` restricted to one instance per ray + the kernel's reads at the hit -> blas_hit_dtype."""
+        o = np.asarray(origins, np.float32).reshape(-1, 3)
+        r = np.zeros(o.shape[0], abi.blas_ray_dtype)
+        r["origin"] = o
+        r["direction"] = np.asarray(directions, np.float32).reshape(-1, 3)
+        r["minDistance"] = min_distance
+        r["maxDistance"] = max_distance
+        r["instance"] = instances
+        out = np.zeros(r.shape[0], abi.blas_hit_dtype)
+        self._call("blas_intersect_batch", ptr(r), r.shape[0], ptr(out))
+        return out
+
+    def blas_profile(self, reset=True):
+        ms, n = C.c_double(0), C.c_int64(0)
+        self._call("blas_profile_read", C.byref(ms), C.byref(n), int(reset))
+        return ms.value, n.value
+
     # -- agents (config 5) -------------------------------------------------- #
     def agents_export(self, out_ptr):
         """Packs this engine's characters as AgentSweepState[count] at `out_ptr`

@@ -18,7 +18,10 @@ abi = _pkg.abi
 
 _SKIP = {"sge_context_create", "sge_context_destroy", "sge_last_error", "sge_abi_version", "sge_context_set_stream",
          "sge_synchronize", "sge_context_set_option", "sge_skinning_encode", "sge_crowd_buffers",
-         "sge_skinned_mesh_buffers", "sge_profile_read"}
+         "sge_skinned_mesh_buffers", "sge_profile_read",
+         # the acceleration structure is the product's own layout; the oracle only scans the index buffer
+         "sge_blas_topology", "sge_blas_info_get", "sge_blas_refit", "sge_blas_refit_buffers", "sge_blas_bounds_download",
+         "sge_blas_buffers", "sge_blas_profile_read"}
 
 
 def build_oracle():
@@ -47,6 +50,8 @@ def load_oracle():
         lib.sgeo_tick_mt.argtypes = [C.c_void_p, C.POINTER(abi.TickDesc), C.c_int32]
         lib.sgeo_skinning_encode.restype = C.c_int
         lib.sgeo_skinning_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(abi.SkinningJob), C.c_int32]
+        lib.sgeo_skinned_upload.restype = C.c_int
+        lib.sgeo_skinned_upload.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -71,6 +76,14 @@ class OracleTable:
 
 def oracle_engine():
     return _pkg.CharacterEngine(table=OracleTable())
+
+
+def skinned_upload(engine, positions, normals, tangents, first_vertex=0):
+    """Oracle-only: overwrite the oracle's skinned streams (packed [n][3], [n][3], [n][4])."""
+    import numpy as np
+    p, n, t = (np.ascontiguousarray(a, np.float32) for a in (positions, normals, tangents))
+    rc = engine.t.lib.sgeo_skinned_upload(engine.h, first_vertex, p.shape[0], abi.ptr(p), abi.ptr(n), abi.ptr(t))
+    assert rc == 0, rc
 
 
 def tick_mt(engine, threads, dt=1.0 / 60.0, stages=None, gravity=(0.0, -98.0, 0.0), first=0, count=0):

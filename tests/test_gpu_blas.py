@@ -1,0 +1,225 @@
+"""GPU parity tests of the step after skinning: the per-frame refit of the skinned characters'
+acceleration structures (RTAccelerationBuilder.swift:113-145) and what a ray reads at a hit (RayTracing.metalinc:242-296).
+
+Bars: the refitted boxes are EXACT (min / max of float32 vertices) against a numpy scan of the index buffer; the closest
+hit of a ray (hit / miss, primitive id) is EXACT against the oracle's scan over every triangle on the SAME skinned
+vertices, distances / barycentrics / shading frame within 1e-6 (same IEEE arithmetic on both sides).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from blas_ref import expected_bounds
+from scenes import build_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(sge, eng, n, real, **kw):
+    if real:
+        return build_scene(sge, eng, n, terrain_cells=(24, 16), real_mesh=True, **kw)
+    return build_scene(sge, eng, n, terrain_cells=(24, 16), rings=9, segments=8, **kw)
+
+
+def _topology(sge, eng):
+    return sge.CharacterEngine.blas_topology(eng.mesh["positions"], eng.mesh["indices"])
+
+
+@pytest.mark.parametrize("real", [False, True])
+@pytest.mark.parametrize("layout", ["packed", "padded16"])
+def test_refit_boxes_are_exact(sge, real, layout):
+    gpu = sge.CharacterEngine(0)
+    try:
+        n = 5 if real else 9
+        gpu.set_option(sge.abi.OPT_SKIN_LAYOUT, sge.abi.LAYOUT_PADDED16 if layout == "padded16" else sge.abi.LAYOUT_PACKED)
+        _scene(sge, gpu, n, real, mixed=True)
+        info = gpu.blas_build(gpu.mesh["indices"])
+        topo = _topology(sge, gpu)
+        assert (info.entryCount, info.wideCount, info.clusterCount) == (topo["info"].entryCount, topo["info"].wideCount, topo["info"].clusterCount)
+        V = gpu.vertex_count
+        for step in range(3):
+            gpu.tick(stages=sge.abi.STAGE_ALL | sge.abi.STAGE_BLAS_REFIT)  # refit enqueued behind the skinning of the same step
+            pos, _, _ = gpu.skinned()
+            got = gpu.blas_bounds()
+            for c in range(n):
+                want = expected_bounds(topo, gpu.mesh["indices"], pos[c * V:(c + 1) * V])
+                assert np.array_equal(got[c], want), (step, c, np.argwhere(got[c] != want)[:4])
+        # a refit on its own, over a sub-range: only those characters' rows change
+        before = gpu.blas_bounds()
+        gpu.tick(stages=sge.abi.STAGE_ALL)
+        gpu.blas_refit(first=1, count=2)
+        pos, _, _ = gpu.skinned()
+        got = gpu.blas_bounds()
+        for c in range(n):
+            if c in (1, 2):
+                assert np.array_equal(got[c], expected_bounds(topo, gpu.mesh["indices"], pos[c * V:(c + 1) * V]))
+            else:
+                assert np.array_equal(got[c], before[c])
+        # idempotent
+        gpu.blas_refit()
+        a = gpu.blas_bounds()
+        gpu.blas_refit()
+        assert np.array_equal(a, gpu.blas_bounds())
+    finally:
+        gpu.close()
+
+
+def test_refit_over_caller_buffers(sge):
+    """sge_blas_refit_buffers: the same kernel over device buffers the caller owns (here: the context's own streams,
+    read through sge_crowd_buffers, written to a separately allocated box table)."""
+    import torch
+    gpu = sge.CharacterEngine(0)
+    try:
+        n = 4
+        _scene(sge, gpu, n, False)
+        info = gpu.blas_build(gpu.mesh["indices"])
+        gpu.tick(stages=sge.abi.STAGE_ALL)
+        gpu.synchronize()
+        op = C.c_void_p()
+        gpu._call("crowd_buffers", None, C.byref(op), None, None)
+        out = torch.zeros((n - 1, info.entryCount + 1, 6), dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        gpu._call("blas_refit_buffers", op, sge.abi.LAYOUT_PACKED, gpu.vertex_count, n - 1, C.c_void_p(out.data_ptr()))
+        gpu.synchronize()
+        gpu.blas_refit()
+        assert np.array_equal(out.cpu().numpy(), gpu.blas_bounds()[1:])
+    finally:
+        gpu.close()
+
+
+def _rotation(axis, angle):
+    a = np.asarray(axis, np.float64); a /= np.linalg.norm(a)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return (np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * K @ K).astype(np.float32)
+
+
+def _rays_at(rng, lo, hi, k):
+    """k rays from a shell around the box [lo, hi] towards random points inside it."""
+    centre, half = (lo + hi) / 2, (hi - lo) / 2
+    d = rng.normal(size=(k, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    origins = centre + d * (np.linalg.norm(half) * rng.uniform(1.2, 3.0, (k, 1)))
+    targets = centre + rng.uniform(-1, 1, (k, 3)) * half
+    dirs = targets - origins
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    return origins.astype(np.float32), dirs.astype(np.float32)
+
+
+@pytest.mark.parametrize("real", [False, True])
+def test_closest_hit_matches_the_triangle_scan(sge, real):
+    gpu, cpu = sge.CharacterEngine(0), ob.oracle_engine()
+    try:
+        n = 4
+        for e in (gpu, cpu):
+            _scene(sge, e, n, real, mixed=True, seed=5)
+            e.blas_build(e.mesh["indices"])
+        for _ in range(4):
+            gpu.tick(stages=sge.abi.STAGE_ALL | sge.abi.STAGE_BLAS_REFIT)
+        gp, gn, gt = gpu.skinned()
+        ob.skinned_upload(cpu, gp, gn, gt)  # both sides look at the same skinned vertices
+        # instance matrices (item.modelMatrix): identity, translation, rotation + translation, rotation + non-uniform scale
+        rng = np.random.default_rng(11)
+        mats = np.zeros((n, 4, 4), np.float32)
+        mats[0] = np.eye(4)
+        mats[1] = np.eye(4); mats[1][:3, 3] = (7, -2, 3)
+        mats[2] = np.eye(4); mats[2][:3, :3] = _rotation((0.3, 0.8, -0.5), 1.1)
+        mats[2][:3, 3] = (-4, 1, 9)
+        mats[3] = np.eye(4); mats[3][:3, :3] = np.diag([1.5, 0.75, 2.0]) @ np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]], np.float32)
+        mats[3][:3, 3] = (1, 2, 3)
+        cols = np.ascontiguousarray(mats.transpose(0, 2, 1)).reshape(n, 16)  # column-major
+        for e in (gpu, cpu):
+            e.blas_instances(cols)
+        V = gpu.vertex_count
+        O, D, I = [], [], []
+        for c in range(n):
+            world = gp[c * V:(c + 1) * V] @ mats[c][:3, :3].T + mats[c][:3, 3]
+            o, d = _rays_at(rng, world.min(0), world.max(0), 600)
+            O.append(o); D.append(d); I.append(np.full(len(o), c, np.int32))
+            # exactly through vertices and edge midpoints: several triangles report (nearly) the same distance
+            tri = gpu.mesh["indices"].reshape(-1, 3)[rng.integers(0, len(gpu.mesh["indices"]) // 3, 60)]
+            tgt = np.concatenate([world[tri[:30, 0]], (world[tri[30:, 0]] + world[tri[30:, 1]]) / 2]).astype(np.float32)
+            o2 = (world.mean(0) + (tgt - world.mean(0)) * 4).astype(np.float32)
+            d2 = tgt - o2
+            O.append(o2); D.append((d2 / np.linalg.norm(d2, axis=1, keepdims=True)).astype(np.float32)); I.append(np.full(len(o2), c, np.int32))
+        O, D, I = np.concatenate(O), np.concatenate(D), np.concatenate(I)
+        # axis-parallel rays (zero direction components) and rays that start inside the character
+        O = np.concatenate([O, gp[:8] @ mats[0][:3, :3].T + (0, 5, 0), gp[100:108] * 0.5]).astype(np.float32)
+        D = np.concatenate([D, np.tile(np.array([0, -1, 0], np.float32), (8, 1)), np.tile(np.array([1, 0, 0], np.float32), (8, 1))])
+        I = np.concatenate([I, np.zeros(16, np.int32)])
+        g = gpu.blas_intersect(O, D, I)
+        c_ = cpu.blas_intersect(O, D, I)
+        assert g["hit"].sum() > 0.2 * len(O), "the rays are aimed at the character"
+        assert (g["hit"] == 0).any()
+        assert np.array_equal(g["hit"], c_["hit"])
+        assert np.array_equal(g["primitive"], c_["primitive"]), np.argwhere(g["primitive"] != c_["primitive"])[:5]
+        for f in ("distance", "bary", "geomNormal", "normal", "tangent", "bitangent"):
+            assert np.abs(g[f] - c_[f]).max() <= 1e-6 * max(1.0, np.abs(c_[f]).max()), f
+        # distance limits
+        lim = np.where(g["hit"] == 1, g["distance"] * 0.5, 1.0).astype(np.float32)
+        assert gpu.blas_intersect(O, D, I, max_distance=lim)["distance"].max() <= lim.max()
+        g2, c2 = gpu.blas_intersect(O, D, I, min_distance=lim), cpu.blas_intersect(O, D, I, min_distance=lim)
+        assert np.array_equal(g2["primitive"], c2["primitive"]) and np.array_equal(g2["hit"], c2["hit"])
+        assert (g2["distance"][g2["hit"] == 1] >= lim[g2["hit"] == 1]).all()
+        # out-of-range instance = miss
+        assert gpu.blas_intersect(O[:2], D[:2], [n, -1])["hit"].tolist() == [0, 0]
+    finally:
+        gpu.close(); cpu.close()
+
+
+def test_state_errors(sge):
+    gpu = sge.CharacterEngine(0)
+    try:
+        _scene(sge, gpu, 2, False)
+        with pytest.raises(sge.SgeError, match="sge_blas_build"):
+            gpu.blas_refit(0, 2)
+        with pytest.raises(sge.SgeError, match="sge_blas_build"):
+            gpu.tick(stages=sge.abi.STAGE_ALL | sge.abi.STAGE_BLAS_REFIT)
+        with pytest.raises(sge.SgeError, match="out of range"):
+            gpu.blas_build(np.array([0, 1, 10 ** 6], np.uint32))
+        gpu.blas_build(gpu.mesh["indices"])
+        gpu.tick(stages=sge.abi.STAGE_ALL | sge.abi.STAGE_BLAS_REFIT)
+        with pytest.raises(sge.SgeError):
+            gpu.blas_refit(1, 5)
+        # a new mesh invalidates the structure built for the old one
+        _scene(sge, gpu, 2, False)
+        with pytest.raises(sge.SgeError, match="sge_blas_build"):
+            gpu.blas_refit(0, 2)
+        # resizing the crowd keeps it
+        gpu.blas_build(gpu.mesh["indices"])
+        gpu.resize(3)
+        gpu.tick(dt=0.0, stages=sge.abi.STAGE_POSE | sge.abi.STAGE_SKIN | sge.abi.STAGE_BLAS_REFIT)
+        assert gpu.blas_bounds().shape[0] == 3
+    finally:
+        gpu.close()
+
+
+def test_full_size_refit_properties(sge):
+    """BASELINE configs[2] size (10k characters): every character's root box is the min/max of its skinned vertices, and
+    every entry's box lies inside its parent's (checked on a sample of characters; the whole table for containment)."""
+    gpu = sge.CharacterEngine(0)
+    try:
+        n = 10000
+        ybot = sge.assets.YBotAssets()
+        sge.crowd.upload_character_assets(gpu, ybot)
+        terrain = sge.crowd.upload_terrain(gpu)
+        sge.crowd.spawn_crowd(gpu, ybot, n, terrain, seed=3, mode="ccd", mixed=True)
+        info = gpu.blas_build(gpu.mesh["indices"])
+        topo = _topology(sge, gpu)
+        for _ in range(3):
+            gpu.tick(stages=sge.abi.STAGE_ALL | sge.abi.STAGE_BLAS_REFIT)
+        V = gpu.vertex_count
+        b = gpu.blas_bounds()
+        assert np.isfinite(b).all() and (b[:, :, :3] <= b[:, :, 3:]).all()
+        used = np.unique(gpu.mesh["indices"])
+        for c in (0, 1, 4999, 9999):
+            p = gpu.skinned(first_vertex=c * V, vertex_count=V, normals=False, tangents=False)[0]
+            assert np.array_equal(b[c, -1, :3], p[used].min(0)) and np.array_equal(b[c, -1, 3:], p[used].max(0))
+            assert np.array_equal(b[c], expected_bounds(topo, gpu.mesh["indices"], p))
+        link, first, parent = topo["entryLink"], topo["wideFirst"], topo["wideParentEntry"]
+        for w in range(info.wideCount):
+            dst = info.entryCount if parent[w] < 0 else parent[w]
+            rows = slice(first[w], first[w + 1])
+            assert np.array_equal(b[:, rows, :3].min(1), b[:, dst, :3]) and np.array_equal(b[:, rows, 3:].max(1), b[:, dst, 3:])
+    finally:
+        gpu.close()
