@@ -93,7 +93,7 @@ struct sge_context {
     bool fuseBlas = false;
     int blasBoundsChars = 0;
     DevBuf dBlasEntryLink, dBlasWideFirst, dBlasWideParent, dBlasWideLevel, dBlasSlotIdx, dBlasSlotTri, dBlasVtxStart, dBlasVtxEntries,
-           dBlasIndices, dBlasBounds, dBlasInstances, dBlasRays, dBlasHits, dBlasTileStart, dBlasChunkCluster, dBlasChunkIds;
+           dBlasIndices, dBlasBounds, dBlasInstances, dBlasRays, dBlasHits, dBlasTileStart, dBlasRoundLen, dBlasRoundCluster, dBlasRoundIds;
     // stats / profiling
     DevBuf dStats;
     Events evMove, evPose, evSkin, evAgents, evBlas;
@@ -1107,16 +1107,17 @@ int sge_blas_build(sge_context* c, const uint32_t* indices, int32_t index_count)
     if ((rc = upload(c->dBlasVtxStart, hb.vertexEntryStart.data(), hb.vertexEntryStart.size() * 4, s)) != SGE_OK) return rc;
     if ((rc = upload(c->dBlasVtxEntries, hb.vertexEntries.data(), hb.vertexEntries.size() * 4, s)) != SGE_OK) return rc;
     if ((rc = upload(c->dBlasIndices, indices, (size_t)index_count * 4, s)) != SGE_OK) return rc;
-    if ((rc = upload(c->dBlasTileStart, hb.tileChunkStart.data(), hb.tileChunkStart.size() * 4, s)) != SGE_OK) return rc;
-    if ((rc = upload(c->dBlasChunkCluster, hb.chunkCluster.data(), hb.chunkCluster.size() * 4, s)) != SGE_OK) return rc;
-    if ((rc = upload(c->dBlasChunkIds, hb.chunkIds.data(), hb.chunkIds.size() * 2, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dBlasTileStart, hb.tileRoundStart.data(), hb.tileRoundStart.size() * 4, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dBlasRoundLen, hb.roundLen.data(), hb.roundLen.size() * 4, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dBlasRoundCluster, hb.roundCluster.data(), hb.roundCluster.size() * 4, s)) != SGE_OK) return rc;
+    if ((rc = upload(c->dBlasRoundIds, hb.roundIds.data(), hb.roundIds.size() * 4, s)) != SGE_OK) return rc;
     SGE_HIP(hipStreamSynchronize(s));
     c->hostBlas = std::move(hb);
     const HostBlas& h = c->hostBlas;
     c->blas = DevBlas{h.entryCount(), h.wideCount(), h.triCount, h.vertexCount, h.clusterCount, h.levels,
                       c->dBlasEntryLink.as<int2>(), c->dBlasWideFirst.as<int>(), c->dBlasWideParent.as<int>(), c->dBlasWideLevel.as<int>(),
                       c->dBlasSlotIdx.as<uint32_t>(), c->dBlasSlotTri.as<uint32_t>(), c->dBlasVtxStart.as<int>(), c->dBlasVtxEntries.as<int>(),
-                      h.tileVerts, h.tileCount, c->dBlasTileStart.as<int>(), c->dBlasChunkCluster.as<int>(), c->dBlasChunkIds.as<uint16_t>()};
+                      h.tileVerts, h.tileCount, c->dBlasTileStart.as<int>(), c->dBlasRoundLen.as<int>(), c->dBlasRoundCluster.as<int>(), c->dBlasRoundIds.as<uint32_t>()};
     c->blasBoundsChars = 0;
     return ensureBlasBuffers(c);
 }

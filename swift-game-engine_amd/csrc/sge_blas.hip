@@ -8,151 +8,186 @@
 // blas_refit_kernel — one workgroup per character. The skinned positions are read ONCE, coalesced, in vertex order, a
 // tile of ~4k vertices at a time into LDS; the routing "vertex -> the clusters it belongs to" (1.6 clusters per vertex
 // on the Y-Bot) is a schedule built once with the topology and shared by all clones: per tile, the vertices of every
-// cluster that reaches into it, in chunks of 16. A 16-lane group gathers a chunk's vertices from LDS, reduces with DPP
-// row shifts and folds the result into the cluster's row of an LDS table; no triangle ever gathers its three vertices from
-// HBM. The inner entries are then reduced level by level from LDS, one wavefront per wide node, and the whole table is
+// cluster that reaches into it, in chunks of 16. A lane walks one chunk from LDS with the running min / max in registers
+// and folds the result into the cluster's row of an LDS table; no triangle ever gathers its three vertices from HBM. The inner entries are then reduced level by level from LDS, one wavefront per wide node, and the whole table is
 // written out coalesced. HBM traffic per character: 12 B (16 B padded) per vertex in, 24 B per entry out; the index
-// buffer is not read at all. (A first version folded every vertex into its clusters with LDS atomics: 4.5 ms for 10k
-// Y-Bots, bound by the LDS atomic rate of about one lane per clock per CU.)
+// buffer is not read at all. (Versions measured on the way, 10k Y-Bots: every vertex folded into its clusters with LDS
+// atomics, 4.5 ms — the LDS atomic rate is about one lane per clock per CU; a 16-lane group per chunk with a DPP
+// row reduction, 1.6 ms — four times the instructions of the lane-sequential walk.)
 //
 // blas_intersect_kernel — one wavefront per ray: a lane tests one entry's box per step, then one triangle of a
 // cluster per lane; the closest hit is the wave minimum of (distance, primitive id), so the answer does not depend on
 // the visiting order and equals a brute-force scan of the index buffer.
+#include <algorithm>
 #include "sge_internal.hpp"
 
 namespace sge {
 
 constexpr int kWave = 64;
-
-// min / max over the 16 lanes of a DPP row: an inclusive scan with row_shr 1, 2, 4, 8 leaves the result in lane 15 of the
-// row. Lanes whose source falls outside the row are not written by the DPP form and keep their own value. The six chains
-// are interleaved, so a register is read again only five instructions after it was written (DPP needs two wait states).
-#define SGE_DPP6(CTRL)                                                                          \
-    asm volatile("v_min_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(mnx));   \
-    asm volatile("v_min_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(mny));   \
-    asm volatile("v_min_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(mnz));   \
-    asm volatile("v_max_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(mxx));   \
-    asm volatile("v_max_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(mxy));   \
-    asm volatile("v_max_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(mxz));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float waveMinF(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, kWave)); return v; }
 __device__ __forceinline__ float waveMaxF(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave)); return v; }
 
-// One workgroup per character. LDS: tab[c * rows + row] (c = 0..2 minima, 3..5 maxima), then one tile of positions as
-// X[], Y[], Z[]. Per tile: the workgroup's registers already hold the tile (its loads were issued a tile earlier and
-// completed behind the previous tile's work); they are written to LDS, the next tile's loads are issued, and every
-// 16-lane group then takes chunks — up to 16 vertices of this tile that belong to one cluster — reads them from LDS,
-// reduces across its lanes and folds the result into the cluster's row with LDS float atomics (one lane, six values).
-// Nothing in the chunk loop depends on a previous load: chunk c of the tile sits at a computable address.
+// v_min_f32 / v_max_f32 as written (fminf() on a value loaded from LDS would first canonicalise it: one more instruction each)
+#define SGE_FOLD(X_, Y_, Z_)                                                   \
+    asm("v_min_f32 %0, %0, %1" : "+v"(mnx) : "v"(X_)); asm("v_max_f32 %0, %0, %1" : "+v"(mxx) : "v"(X_)); \
+    asm("v_min_f32 %0, %0, %1" : "+v"(mny) : "v"(Y_)); asm("v_max_f32 %0, %0, %1" : "+v"(mxy) : "v"(Y_)); \
+    asm("v_min_f32 %0, %0, %1" : "+v"(mnz) : "v"(Z_)); asm("v_max_f32 %0, %0, %1" : "+v"(mxz) : "v"(Z_));
+
+// Persistent workgroups (two per CU), each taking characters blockIdx.x, blockIdx.x + gridDim.x, ... LDS: tab[c * rows + row]
+// (c = 0..2 minima, 3..5 maxima), one tile of positions as X[], Y[], Z[], and the tiles' round ranges. The work is one
+// flat sequence of (character, tile) steps. Per step: the workgroup's registers already hold the tile (its loads were
+// issued a step earlier and completed behind the previous step's work); they are written to LDS; every wavefront requests
+// its round of the schedule and then the NEXT step's positions — possibly the next character's first tile, so the
+// end-of-character work below also runs with loads in flight; then every LANE takes one chunk — up to 16 vertices of this
+// tile that belong to one cluster — walks it sequentially from LDS with the running min / max in registers (no cross-lane
+// step), and folds the result into the cluster's row with six LDS float atomics. 64 chunks of similar length form a round =
+// one wavefront's work. Memory loads retire in order: the round's words are requested before the positions, so the walk
+// waits only for them.
+// After a character's last tile: the inner entries are reduced from LDS level by level, one wavefront per wide node, the
+// table is written out coalesced and re-initialised.
+struct BlasRound { uint32_t w[8]; int cluster, len; };
+
 template <int STRIDE>
 __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, const float* __restrict__ positions, long long firstVertex,
-                                                                     float* __restrict__ bounds) {
+                                                                     int chars, float* __restrict__ bounds) {
     extern __shared__ float lds[];
     const int rows = B.entryCount + 1, tid = threadIdx.x;
     float* tab = lds;
-    float* X = lds + rows * 6;
-    float* Y = X + B.tileVerts;
-    float* Z = Y + B.tileVerts;
+    float* X = lds + rows * 6; // Y = X + kBlasTileVerts, Z = X + 2 * kBlasTileVerts
+    int* trs = reinterpret_cast<int*>(X + 3 * kBlasTileVerts);
     const float inf = __builtin_inff();
     for (int i = tid; i < rows * 6; i += kBlasRefitBlock) tab[i] = i < rows * 3 ? inf : -inf;
-    const float* P = positions + (size_t)(firstVertex + (long long)blockIdx.x * B.vertexCount) * STRIDE;
-    const int sub = tid & 15, group = tid >> 4;
-    constexpr int kGroups = kBlasRefitBlock / 16, kPerThread = kBlasTileVerts / kBlasRefitBlock, kBatch = 16;
+    for (int i = tid; i <= B.tileCount; i += kBlasRefitBlock) trs[i] = B.tileRoundStart[i];
+    __syncthreads();
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
+    constexpr int kWaves = kBlasRefitBlock / kWave, kPerThread = kBlasTileVerts / kBlasRefitBlock;
+    const int n = B.tileCount, lastRound = trs[n] - 1;
+    const float* P0 = positions + (size_t)firstVertex * STRIDE;
+    const size_t charStride = (size_t)B.vertexCount * STRIDE;
+
     float px[kPerThread], py[kPerThread], pz[kPerThread];
-    auto fetch = [&](int tile) {
+    auto fetchPos = [&](int c, int tile) {
+        const float* P = P0 + (size_t)c * charStride;
         const int base = tile * B.tileVerts, nv = min(B.tileVerts, B.vertexCount - base);
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
             const int v = min(tid + k * kBlasRefitBlock, nv - 1); // past the end: reload the last vertex (never stored), no branch
             const float* p = P + (size_t)(base + v) * STRIDE;
-            if (STRIDE == 4) { const float4 q = *reinterpret_cast<const float4*>(p); px[k] = q.x; py[k] = q.y; pz[k] = q.z; }
-            else { px[k] = p[0]; py[k] = p[1]; pz[k] = p[2]; }
+            // streamed once: non-temporal
+            if (STRIDE == 4) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p)); px[k] = q.x; py[k] = q.y; pz[k] = q.z; }
+            else { px[k] = __builtin_nontemporal_load(p); py[k] = __builtin_nontemporal_load(p + 1); pz[k] = __builtin_nontemporal_load(p + 2); }
         }
     };
-    fetch(0);
-    for (int tile = 0; tile < B.tileCount; ++tile) {
+    auto fetchRound = [&](int r, BlasRound& R) {
+        const int rr = __builtin_amdgcn_readfirstlane(min(r, lastRound)); // past the end: a valid round, loaded but not used
+#pragma unroll
+        for (int j = 0; j < 8; ++j) R.w[j] = B.roundIds[((size_t)rr * 8 + j) * 64 + lane];
+        R.cluster = B.roundCluster[(size_t)rr * 64 + lane];
+        R.len = B.roundLen[rr];
+    };
+    auto walk = [&](const BlasRound& R) {
+        float mnx = inf, mny = inf, mnz = inf, mxx = -inf, mxy = -inf, mxz = -inf;
+        const char* Xb = reinterpret_cast<const char*>(X);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i < R.len) { // wave-uniform
+                const uint32_t off = (i & 1) ? (R.w[i >> 1] >> 16) : (R.w[i >> 1] & 0xffffu);
+                const float* q = reinterpret_cast<const float*>(Xb + off);
+                const float x = q[0], y = q[kBlasTileVerts], z = q[2 * kBlasTileVerts];
+                SGE_FOLD(x, y, z)
+            }
+        }
+        float* t = tab + R.cluster;
+        __hip_atomic_fetch_min(t, mnx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_min(t + rows, mny, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_min(t + 2 * rows, mnz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(t + 3 * rows, mxx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(t + 4 * rows, mxy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(t + 5 * rows, mxz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
+    int c = blockIdx.x;
+    if (c >= chars) return;
+    // characters start at different tiles, so that the ones in flight at one time do not all read the same offset of their
+    // (equally spaced) vertex ranges
+    int tile = c % n, done = 0;
+    fetchPos(c, tile);
+    while (true) {
         const int nv = min(B.tileVerts, B.vertexCount - tile * B.tileVerts);
-        __syncthreads(); // the previous tile's chunks have read X/Y/Z (first tile: the table is initialised)
+        __syncthreads(); // the previous step's rounds have read X/Y/Z; a finished character's table has been re-initialised
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
             const int v = tid + k * kBlasRefitBlock;
-            if (v < nv) { X[v] = px[k]; Y[v] = py[k]; Z[v] = pz[k]; }
+            if (v < nv) { X[v] = px[k]; X[v + kBlasTileVerts] = py[k]; X[v + 2 * kBlasTileVerts] = pz[k]; }
         }
         __syncthreads();
-        // This group's chunks of the tile: c0, c0 + kGroups, ... Their ids and clusters are loaded kBatch at a time BEFORE the
-        // next tile's positions are requested: memory loads retire in order, so the chunk loop then waits only for its own
-        // (early) loads while the next tile's stay in flight behind it.
-        const int cEnd = B.tileChunkStart[tile + 1], cLast = B.tileChunkStart[B.tileCount] - 1;
-        int c0 = B.tileChunkStart[tile] + group;
-        bool first = true;
-        do {
-            int id[kBatch], cluster[kBatch];
-#pragma unroll
-            for (int k = 0; k < kBatch; ++k) {
-                const int c = min(c0 + k * kGroups, cLast); // past the end: a valid chunk, loaded but not used
-                id[k] = B.chunkIds[(size_t)c * 16 + sub];
-                cluster[k] = B.chunkCluster[c];
-            }
-            if (first && tile + 1 < B.tileCount) fetch(tile + 1);
-            first = false;
-#pragma unroll
-            for (int k = 0; k < kBatch; ++k) {
-                if (c0 + k * kGroups < cEnd) {
-                    float mnx = X[id[k]], mny = Y[id[k]], mnz = Z[id[k]];
-                    float mxx = mnx, mxy = mny, mxz = mnz;
-                    asm volatile("s_nop 1" : "+v"(mnx), "+v"(mny), "+v"(mnz), "+v"(mxx), "+v"(mxy), "+v"(mxz));
-                    SGE_DPP6("row_shr:1") SGE_DPP6("row_shr:2") SGE_DPP6("row_shr:4") SGE_DPP6("row_shr:8")
-                    if (sub == 15) {
-                        float* r = tab + cluster[k];
-                        __hip_atomic_fetch_min(r, mnx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_min(r + rows, mny, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_min(r + 2 * rows, mnz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_max(r + 3 * rows, mxx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_max(r + 4 * rows, mxy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_max(r + 5 * rows, mxz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int rEnd = trs[tile + 1];
+        int r = trs[tile] + wave;
+        BlasRound R;
+        fetchRound(r, R);
+        // the next step: this character's next tile, or the next character's first
+        const bool last = done + 1 == n;
+        const int cNext = last ? c + (int)gridDim.x : c;
+        const int tileNext = last ? cNext % n : (tile + 1 == n ? 0 : tile + 1);
+        fetchPos(min(cNext, chars - 1), tileNext); // unconditional (a branch here would make the waits below conservative); after the last step: unused
+        if (r < rEnd) walk(R); // wave-uniform
+        for (r += kWaves; r < rEnd; r += kWaves) { // only when a tile has more rounds than the workgroup has wavefronts
+            fetchRound(r, R);
+            walk(R);
+        }
+        if (last) {
+            // inner entries from their wide nodes, deepest level first, one wavefront per wide node; then the table goes out
+            for (int lvl = B.levels - 1; lvl >= 0; --lvl) {
+                __syncthreads();
+                for (int w = B.wideLevelStart[lvl] + wave; w < B.wideLevelStart[lvl + 1]; w += kWaves) {
+                    const int first = B.wideFirst[w], cnt = B.wideFirst[w + 1] - first;
+                    const int parent = B.wideParentEntry[w];
+                    const int dst = parent < 0 ? B.entryCount : parent;
+                    for (int q = 0; q < 6; ++q) {
+                        float k = lane < cnt ? tab[q * rows + first + lane] : (q < 3 ? inf : -inf);
+                        k = q < 3 ? waveMinF(k) : waveMaxF(k);
+                        if (lane == 0) tab[q * rows + dst] = k;
                     }
                 }
             }
-            c0 += kBatch * kGroups;
-        } while (c0 < cEnd);
-    }
-    // inner entries from their wide nodes, deepest level first, one wavefront per wide node; then the table goes out
-    const int lane = tid & (kWave - 1), wave = tid / kWave;
-    constexpr int kWaves = kBlasRefitBlock / kWave;
-    for (int lvl = B.levels - 1; lvl >= 0; --lvl) {
-        __syncthreads();
-        for (int w = B.wideLevelStart[lvl] + wave; w < B.wideLevelStart[lvl + 1]; w += kWaves) {
-            const int first = B.wideFirst[w], n = B.wideFirst[w + 1] - first;
-            const int parent = B.wideParentEntry[w];
-            const int dst = parent < 0 ? B.entryCount : parent;
-            for (int c = 0; c < 6; ++c) {
-                float k = lane < n ? tab[c * rows + first + lane] : (c < 3 ? inf : -inf);
-                k = c < 3 ? waveMinF(k) : waveMaxF(k);
-                if (lane == 0) tab[c * rows + dst] = k;
+            __syncthreads();
+            float* out = bounds + (size_t)c * rows * 6;
+            for (int i = tid; i < rows * 6; i += kBlasRefitBlock) {
+                const int row = i / 6, q = i - row * 6;
+                out[i] = tab[q * rows + row];
             }
+            __syncthreads();
+            for (int i = tid; i < rows * 6; i += kBlasRefitBlock) tab[i] = i < rows * 3 ? inf : -inf;
+            if (cNext >= chars) return;
+            c = cNext;
+            done = 0;
+        } else {
+            ++done;
         }
-    }
-    __syncthreads();
-    float* out = bounds + (size_t)blockIdx.x * rows * 6;
-    for (int i = tid; i < rows * 6; i += kBlasRefitBlock) {
-        const int row = i / 6, c = i - row * 6;
-        out[i] = tab[c * rows + row];
+        tile = tileNext;
     }
 }
 
 int launch_blas_refit(const DevBlas& B, const void* positions, int layout, long long firstVertex, int chars, float* bounds, hipStream_t s) {
     if (chars <= 0) return SGE_OK;
-    const size_t lds = blasRefitLdsBytes(B.entryCount, B.tileVerts);
-    static bool attrSet = false;
-    if (!attrSet) {
+    const size_t lds = blasRefitLdsBytes(B.entryCount, B.tileCount);
+    static int slots = 0;
+    if (!slots) {
         SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blas_refit_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlasMaxLdsBytes));
         SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blas_refit_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlasMaxLdsBytes));
-        attrSet = true;
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        slots = cus;
     }
-    if (layout == SGE_LAYOUT_PADDED16)
-        hipLaunchKernelGGL((blas_refit_kernel<4>), dim3(chars), dim3(kBlasRefitBlock), lds, s, B, reinterpret_cast<const float*>(positions), firstVertex, bounds);
-    else
-        hipLaunchKernelGGL((blas_refit_kernel<3>), dim3(chars), dim3(kBlasRefitBlock), lds, s, B, reinterpret_cast<const float*>(positions), firstVertex, bounds);
+    // as many workgroups as stay resident together: LDS allows floor(160 KB / lds) per CU
+    const int perCU = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / lds));
+    const int grid = std::min(chars, slots * perCU);
+    const float* p = reinterpret_cast<const float*>(positions);
+    if (layout == SGE_LAYOUT_PADDED16) hipLaunchKernelGGL((blas_refit_kernel<4>), dim3(grid), dim3(kBlasRefitBlock), lds, s, B, p, firstVertex, chars, bounds);
+    else hipLaunchKernelGGL((blas_refit_kernel<3>), dim3(grid), dim3(kBlasRefitBlock), lds, s, B, p, firstVertex, chars, bounds);
     return SGE_OK;
 }
 

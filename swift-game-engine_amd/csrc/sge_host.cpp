@@ -10,6 +10,7 @@
 // into a per-triangle visit rank the kernels use as a tie-breaker.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include "sge_internal.hpp"
 
@@ -412,7 +413,7 @@ bool HostBlas::build(const float* pos, int V, const uint32_t* idx, int indexCoun
     tileCount = (V + kBlasTileVerts - 1) / kBlasTileVerts;
     tileVerts = ((V + tileCount - 1) / tileCount + 63) / 64 * 64;
     tileCount = (V + tileVerts - 1) / tileVerts;
-    if (blasRefitLdsBytes(entryCount(), tileVerts) > kBlasMaxLdsBytes) { err = "blas: mesh too large (more than ~250k triangles per character)"; return false; }
+    if (blasRefitLdsBytes(entryCount(), V / 512 + 2) > kBlasMaxLdsBytes) { err = "blas: mesh too large (more than ~250k triangles per character)"; return false; }
 
     triCount = T;
     vertexCount = V;
@@ -438,10 +439,19 @@ bool HostBlas::build(const float* pos, int V, const uint32_t* idx, int indexCoun
     for (size_t i = 0; i < inc.size(); ++i) { vertexEntryStart[(size_t)inc[i].first + 1]++; vertexEntries[i] = inc[i].second; }
     for (int v = 0; v < V; ++v) vertexEntryStart[(size_t)v + 1] += vertexEntryStart[v];
 
-    // refit schedule (see HostBlas): per tile, the (cluster, vertices of the tile in it) pairs cut into chunks of 16
+    // refit schedule (see HostBlas): per tile, the (cluster, vertices of the tile in it) pairs cut into chunks of <= 16,
+    // longest first, 64 chunks per round
+    // The tile is shrunk until a tile has at most one round per wavefront of the refit workgroup (8), so that the kernel
+    // can request every wavefront's round one tile ahead.
     std::vector<std::vector<uint16_t>> bucket(entryCount());
     std::vector<int> touched;
-    tileChunkStart.assign(1, 0);
+    struct Chunk { int cluster; std::vector<uint16_t> ids; };
+    constexpr int kRoundsPerTile = kBlasRefitBlock / 64;
+    for (bool again = true; again;) {
+    again = false;
+    chunkCount = 0;
+    tileRoundStart.assign(1, 0);
+    roundLen.clear(); roundCluster.clear(); roundIds.clear();
     for (int tile = 0; tile < tileCount; ++tile) {
         const int base = tile * tileVerts, end = std::min(V, base + tileVerts);
         touched.clear();
@@ -452,15 +462,60 @@ bool HostBlas::build(const float* pos, int V, const uint32_t* idx, int indexCoun
                 bucket[e].push_back((uint16_t)(v - base));
             }
         std::sort(touched.begin(), touched.end());
+        std::vector<Chunk> chunks;
         for (int e : touched) {
             const std::vector<uint16_t>& ids = bucket[e];
-            for (size_t k = 0; k < ids.size(); k += 16) {
-                chunkCluster.push_back(e);
-                for (size_t j = 0; j < 16; ++j) chunkIds.push_back(k + j < ids.size() ? ids[k + j] : ids[k]);
-            }
+            for (size_t k = 0; k < ids.size(); k += 16)
+                chunks.push_back(Chunk{e, std::vector<uint16_t>(ids.begin() + k, ids.begin() + std::min(ids.size(), k + 16))});
             bucket[e].clear();
         }
-        tileChunkStart.push_back((int)chunkCluster.size());
+        std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk& a, const Chunk& b) { return a.ids.size() > b.ids.size(); });
+        chunkCount += (int)chunks.size();
+        for (size_t r = 0; r < chunks.size(); r += 64) {
+            const int len = (int)chunks[r].ids.size();
+            roundLen.push_back(len);
+            const size_t idBase = roundIds.size();
+            roundIds.resize(idBase + 8 * 64, 0u);
+            // The order of a chunk's vertices is free (min / max), so it is chosen against LDS bank conflicts: at step i the
+            // 32 lanes of a half-wave read X[id] (bank = id mod 32, same for Y and Z) together; every lane takes, among the
+            // vertices it has not read yet (all of them again once it ran out: padding), the one on the least loaded bank.
+            std::vector<uint16_t> order[64];
+            for (int lane = 0; lane < 64; ++lane) roundCluster.push_back(chunks[r + lane < chunks.size() ? r + lane : r].cluster);
+            for (int half = 0; half < 2; ++half) {
+                std::vector<uint16_t> left[32];
+                for (int l = 0; l < 32; ++l) left[l] = chunks[r + half * 32 + l < chunks.size() ? r + half * 32 + l : r].ids;
+                for (int i = 0; i < len; ++i) {
+                    int load[32] = {0};
+                    for (int l = 0; l < 32; ++l) {
+                        const Chunk& ch = chunks[r + half * 32 + l < chunks.size() ? r + half * 32 + l : r];
+                        std::vector<uint16_t>& pool = left[l];
+                        const bool pad = pool.empty();
+                        const std::vector<uint16_t>& from = pad ? ch.ids : pool;
+                        size_t best = 0;
+                        for (size_t k = 1; k < from.size() && !getenv("SGE_BLAS_X_NO_BANK_ORDER"); ++k)
+                            if (load[from[k] & 31] < load[from[best] & 31]) best = k;
+                        const uint16_t id = from[best];
+                        load[id & 31]++;
+                        order[half * 32 + l].push_back(id);
+                        if (!pad) pool.erase(pool.begin() + (long)best);
+                    }
+                }
+            }
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t off = 4u * order[lane][i < len ? i : 0];
+                    roundIds[idBase + (size_t)(i >> 1) * 64 + lane] |= off << (16 * (i & 1));
+                }
+        }
+        tileRoundStart.push_back((int)roundLen.size());
+        if ((int)roundLen.size() - tileRoundStart[tile] > kRoundsPerTile && tileVerts > 512 && !getenv("SGE_BLAS_X_ANY_ROUNDS")) { again = true; break; }
+    }
+    if (again) {
+        ++tileCount;
+        tileVerts = ((V + tileCount - 1) / tileCount + 63) / 64 * 64;
+        tileCount = (V + tileVerts - 1) / tileVerts;
+        for (auto& b : bucket) b.clear();
+    }
     }
     return true;
 }

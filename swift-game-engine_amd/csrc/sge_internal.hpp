@@ -160,11 +160,12 @@ struct HostBlas {
     std::vector<uint32_t> slotIndices;   // [T][3]: vertex indices of the triangle at every slot
     std::vector<int> vertexEntryStart, vertexEntries; // CSR vertex -> clusters
     // refit schedule: the vertex stream is cut into tiles of tileVerts vertices; a chunk = up to 16 vertices of ONE tile
-    // that belong to ONE cluster (ids local to the tile, padded by repeating the first), the work of one 16-lane group
-    int tileVerts = 0, tileCount = 0;
-    std::vector<int> tileChunkStart;     // [tileCount + 1]
-    std::vector<int> chunkCluster;       // [chunkCount] leaf entry
-    std::vector<uint16_t> chunkIds;      // [chunkCount][16]
+    // that belong to ONE cluster, the work of ONE lane; 64 chunks of similar length make a round, the work of one wavefront
+    int tileVerts = 0, tileCount = 0, chunkCount = 0;
+    std::vector<int> tileRoundStart;     // [tileCount + 1]
+    std::vector<int> roundLen;           // [roundCount] vertices per chunk in this round (1..16; shorter chunks repeat their first vertex)
+    std::vector<int> roundCluster;       // [roundCount][64] leaf entry of every lane's chunk (a short last round repeats its first chunk)
+    std::vector<uint32_t> roundIds;      // [roundCount][8][64]: word j of a lane = LDS byte offsets (4 * local vertex id) of its vertices 2j | 2j+1 << 16
     int entryCount() const { return (int)entryLink.size() / 2; }
     int wideCount() const { return (int)wideParentEntry.size(); }
     // false + message when the mesh cannot be handled
@@ -182,14 +183,15 @@ struct DevBlas {
     const int* vertexEntryStart;
     const int* vertexEntries;
     int tileVerts, tileCount;
-    const int* tileChunkStart;
-    const int* chunkCluster;
-    const uint16_t* chunkIds;
+    const int* tileRoundStart;
+    const int* roundLen;
+    const int* roundCluster;
+    const uint32_t* roundIds;
 };
 constexpr int kBlasRefitBlock = 512;
 constexpr int kBlasTileVerts = 4096; // vertices staged in LDS at a time (48 KB): kBlasRefitBlock threads x 8
-// LDS of the refit kernel: the box table, six floats per row, (entryCount + 1) rows, + one tile of positions (SoA)
-inline size_t blasRefitLdsBytes(int entryCount, int tileVerts) { return (size_t)(entryCount + 1) * 24 + (size_t)tileVerts * 12; }
+// LDS of the refit kernel: the box table, six floats per row, (entryCount + 1) rows, + one tile of positions (SoA) + tileRoundStart
+inline size_t blasRefitLdsBytes(int entryCount, int tileCount) { return (size_t)(entryCount + 1) * 24 + (size_t)kBlasTileVerts * 12 + (size_t)(tileCount + 1) * 4; }
 constexpr size_t kBlasMaxLdsBytes = 144 * 1024; // of the CU's 160 KB
 
 // ---- kernel launchers ----------------------------------------------------- //
