@@ -43,6 +43,9 @@ def main():
                     help="real: the FBX-derived Y-Bot (35,440 vertices) and 17-Cheese / merged static scene from tests/golden/")
     ap.add_argument("--layout", choices=["packed", "padded16"], default="packed")
     ap.add_argument("--overlap", action="store_true", help="skin(n) on a second stream, overlapping move(n+1)")
+    ap.add_argument("--refit", action="store_true",
+                    help="also refit every character's acceleration structure after skinning (SURVEY 8 f2, the reference's next step; "
+                         "not part of BASELINE.json's metric, so off by default); adds a `refit` object to the JSON line")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only to rehearse N>1 on one GPU")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -91,6 +94,9 @@ def main():
     state = _spawn_block(sge, eng, ybot, n_total, first, count, terrain, mode, agents=args.workload == "agents",
                          mixed=args.workload == "mixed")
     stages = abi.STAGE_ALL if mode == "ccd" else (abi.STAGE_LOCOMOTION | abi.STAGE_ACTION | abi.STAGE_POSE | abi.STAGE_WRITEBACK | abi.STAGE_SKIN)
+    if args.refit:
+        eng.blas_build(eng.mesh["indices"])
+        stages |= abi.STAGE_BLAS_REFIT
     exchange = None
     if args.workload == "agents":
         exchange = sge.parallel.AgentExchange(eng, n_total, rank, world, torch.device("cuda", local_rank), dist)
@@ -115,6 +121,8 @@ def main():
     eng.set_option(abi.OPT_PROFILE, 1)
     eng.profile_read(reset=True)
     eng.move_stats(reset=True)
+    if args.refit:
+        eng.blas_profile(reset=True)
 
     barrier()
     t0 = time.perf_counter()
@@ -175,8 +183,22 @@ def main():
                 "sweep_trips_per_query": stats.sweepTrips / max(stats.queries, 1),
                 "queries_per_s": stats.queries / max(prof.move_ms * 1e-3, 1e-9), "overflow": int(stats.overflow)},
     }
+    if args.refit:
+        # ALGORITHMIC bytes of one refit launch: the skinned positions read once + one box per entry written
+        ms, launches = eng.blas_profile(reset=True)
+        info = eng.blas_info
+        stride = 16.0 if args.layout == "padded16" else 12.0
+        refit_bytes = count * (stride * V + 24.0 * (info.entryCount + 1))
+        refit_ms = ms / max(launches, 1)
+        out["metric"] += " + acceleration-structure refit"
+        out["kernels_ms_per_step"]["blas_refit"] = ms / args.steps
+        out["refit"] = {"kernel": "blas_refit_kernel", "bound": "hbm", "bytes_per_launch": refit_bytes, "ms_per_launch": refit_ms,
+                        "achieved": refit_bytes / (refit_ms * 1e-3) / 1e9 if refit_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": (refit_bytes / (refit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if refit_ms > 0 else 0.0,
+                        "triangles_per_character": int(info.triangleCount), "clusters": int(info.clusterCount),
+                        "entries": int(info.entryCount), "wide_nodes": int(info.wideCount)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = _cpu_baseline(sge, eng, ybot, terrain, stages, args, mode)
+        out["cpu_baseline"] = _cpu_baseline(sge, eng, ybot, terrain, stages & ~abi.STAGE_BLAS_REFIT, args, mode)  # the oracle has no refit
     if rank == 0:
         print(json.dumps(out))
     eng.close()

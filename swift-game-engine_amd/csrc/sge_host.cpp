@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include "sge_internal.hpp"
 
 namespace sge {
@@ -441,17 +442,11 @@ bool HostBlas::build(const float* pos, int V, const uint32_t* idx, int indexCoun
 
     // refit schedule (see HostBlas): per tile, the (cluster, vertices of the tile in it) pairs cut into chunks of <= 16,
     // longest first, 64 chunks per round
-    // The tile is shrunk until a tile has at most one round per wavefront of the refit workgroup (8), so that the kernel
-    // can request every wavefront's round one tile ahead.
     std::vector<std::vector<uint16_t>> bucket(entryCount());
     std::vector<int> touched;
     struct Chunk { int cluster; std::vector<uint16_t> ids; };
-    constexpr int kRoundsPerTile = kBlasRefitBlock / 64;
-    for (bool again = true; again;) {
-    again = false;
     chunkCount = 0;
     tileRoundStart.assign(1, 0);
-    roundLen.clear(); roundCluster.clear(); roundIds.clear();
     for (int tile = 0; tile < tileCount; ++tile) {
         const int base = tile * tileVerts, end = std::min(V, base + tileVerts);
         touched.clear();
@@ -485,14 +480,46 @@ bool HostBlas::build(const float* pos, int V, const uint32_t* idx, int indexCoun
                 std::vector<uint16_t> left[32];
                 for (int l = 0; l < 32; ++l) left[l] = chunks[r + half * 32 + l < chunks.size() ? r + half * 32 + l : r].ids;
                 for (int i = 0; i < len; ++i) {
+                    // lanes that still have unread vertices are matched to distinct banks as far as possible (augmenting
+                    // paths over lane -> candidate banks); the rest, and the padding lanes, take their least loaded bank
+                    int owner[32], pick[32];
+                    for (int b = 0; b < 32; ++b) owner[b] = -1;
+                    for (int l = 0; l < 32; ++l) pick[l] = -1;
+                    bool seen[32];
+                    std::function<bool(int)> augment = [&](int l) -> bool {
+                        for (size_t k = 0; k < left[l].size(); ++k) {
+                            const int b = left[l][k] & 31;
+                            if (seen[b]) continue;
+                            seen[b] = true;
+                            if (owner[b] < 0 || augment(owner[b])) { owner[b] = l; pick[l] = (int)k; return true; }
+                        }
+                        return false;
+                    };
+                    for (int l = 0; l < 32; ++l)
+                        if (!left[l].empty()) { for (bool& f : seen) f = false; augment(l); }
+                    // an augmenting path re-picks by bank: resolve every matched lane's vertex from the bank it owns
+                    for (int b = 0; b < 32; ++b)
+                        if (owner[b] >= 0) {
+                            const int l = owner[b];
+                            for (size_t k = 0; k < left[l].size(); ++k)
+                                if ((left[l][k] & 31) == b) { pick[l] = (int)k; break; }
+                        }
                     int load[32] = {0};
+                    bool matched[32];
+                    for (int l = 0; l < 32; ++l) matched[l] = false;
+                    for (int b = 0; b < 32; ++b) if (owner[b] >= 0) { matched[owner[b]] = true; load[b] = 1; }
                     for (int l = 0; l < 32; ++l) {
                         const Chunk& ch = chunks[r + half * 32 + l < chunks.size() ? r + half * 32 + l : r];
                         std::vector<uint16_t>& pool = left[l];
+                        if (matched[l]) {
+                            order[half * 32 + l].push_back(pool[pick[l]]);
+                            pool.erase(pool.begin() + pick[l]);
+                            continue;
+                        }
                         const bool pad = pool.empty();
                         const std::vector<uint16_t>& from = pad ? ch.ids : pool;
                         size_t best = 0;
-                        for (size_t k = 1; k < from.size() && !getenv("SGE_BLAS_X_NO_BANK_ORDER"); ++k)
+                        for (size_t k = 1; k < from.size(); ++k)
                             if (load[from[k] & 31] < load[from[best] & 31]) best = k;
                         const uint16_t id = from[best];
                         load[id & 31]++;
@@ -508,14 +535,6 @@ bool HostBlas::build(const float* pos, int V, const uint32_t* idx, int indexCoun
                 }
         }
         tileRoundStart.push_back((int)roundLen.size());
-        if ((int)roundLen.size() - tileRoundStart[tile] > kRoundsPerTile && tileVerts > 512 && !getenv("SGE_BLAS_X_ANY_ROUNDS")) { again = true; break; }
-    }
-    if (again) {
-        ++tileCount;
-        tileVerts = ((V + tileCount - 1) / tileCount + 63) / 64 * 64;
-        tileCount = (V + tileVerts - 1) / tileVerts;
-        for (auto& b : bucket) b.clear();
-    }
     }
     return true;
 }
