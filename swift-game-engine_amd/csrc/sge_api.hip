@@ -1117,7 +1117,7 @@ int sge_blas_build(sge_context* c, const uint32_t* indices, int32_t index_count)
     c->blas = DevBlas{h.entryCount(), h.wideCount(), h.triCount, h.vertexCount, h.clusterCount, h.levels,
                       c->dBlasEntryLink.as<int2>(), c->dBlasWideFirst.as<int>(), c->dBlasWideParent.as<int>(), c->dBlasWideLevel.as<int>(),
                       c->dBlasSlotIdx.as<uint32_t>(), c->dBlasSlotTri.as<uint32_t>(), c->dBlasVtxStart.as<int>(), c->dBlasVtxEntries.as<int>(),
-                      h.tileVerts, h.tileCount, c->dBlasTileStart.as<int>(), c->dBlasRoundLen.as<int>(), c->dBlasRoundCluster.as<int>(), c->dBlasRoundIds.as<uint32_t>()};
+                      h.tileVerts, h.tileCount, h.tileCap, c->dBlasTileStart.as<int>(), c->dBlasRoundLen.as<int>(), c->dBlasRoundCluster.as<int>(), c->dBlasRoundIds.as<uint32_t>()};
     c->blasBoundsChars = 0;
     return ensureBlasBuffers(c);
 }

@@ -35,7 +35,7 @@ __device__ __forceinline__ float waveMaxF(float v) { for (int o = 32; o > 0; o >
     asm("v_min_f32 %0, %0, %1" : "+v"(mny) : "v"(Y_)); asm("v_max_f32 %0, %0, %1" : "+v"(mxy) : "v"(Y_)); \
     asm("v_min_f32 %0, %0, %1" : "+v"(mnz) : "v"(Z_)); asm("v_max_f32 %0, %0, %1" : "+v"(mxz) : "v"(Z_));
 
-// Persistent workgroups (two per CU), each taking characters blockIdx.x, blockIdx.x + gridDim.x, ... LDS: tab[c * rows + row]
+// Persistent workgroups (two or three per CU, as the LDS allows), each taking characters blockIdx.x, blockIdx.x + gridDim.x, ... LDS: tab[c * rows + row]
 // (c = 0..2 minima, 3..5 maxima), one tile of positions as X[], Y[], Z[], and the tiles' round ranges. The work is one
 // flat sequence of (character, tile) steps. Per step: the workgroup's registers already hold the tile (its loads were
 // issued a step earlier and completed behind the previous step's work); they are written to LDS; every wavefront requests
@@ -49,20 +49,20 @@ __device__ __forceinline__ float waveMaxF(float v) { for (int o = 32; o > 0; o >
 // table is written out coalesced and re-initialised.
 struct BlasRound { uint32_t w[8]; int cluster, len; };
 
-template <int STRIDE>
+template <int STRIDE, int TILE>
 __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, const float* __restrict__ positions, long long firstVertex,
                                                                      int chars, float* __restrict__ bounds) {
     extern __shared__ float lds[];
     const int rows = B.entryCount + 1, tid = threadIdx.x;
     float* tab = lds;
-    float* X = lds + rows * 6; // Y = X + kBlasTileVerts, Z = X + 2 * kBlasTileVerts
-    int* trs = reinterpret_cast<int*>(X + 3 * kBlasTileVerts);
+    float* X = lds + rows * 6; // Y = X + TILE, Z = X + 2 * TILE
+    int* trs = reinterpret_cast<int*>(X + 3 * TILE);
     const float inf = __builtin_inff();
     for (int i = tid; i < rows * 6; i += kBlasRefitBlock) tab[i] = i < rows * 3 ? inf : -inf;
     for (int i = tid; i <= B.tileCount; i += kBlasRefitBlock) trs[i] = B.tileRoundStart[i];
     __syncthreads();
     const int lane = tid & (kWave - 1), wave = tid / kWave;
-    constexpr int kWaves = kBlasRefitBlock / kWave, kPerThread = kBlasTileVerts / kBlasRefitBlock;
+    constexpr int kWaves = kBlasRefitBlock / kWave, kPerThread = TILE / kBlasRefitBlock;
     const int n = B.tileCount, lastRound = trs[n] - 1;
     const float* P0 = positions + (size_t)firstVertex * STRIDE;
     const size_t charStride = (size_t)B.vertexCount * STRIDE;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, 
             if (i < R.len) { // wave-uniform
                 const uint32_t off = (i & 1) ? (R.w[i >> 1] >> 16) : (R.w[i >> 1] & 0xffffu);
                 const float* q = reinterpret_cast<const float*>(Xb + off);
-                const float x = q[0], y = q[kBlasTileVerts], z = q[2 * kBlasTileVerts];
+                const float x = q[0], y = q[TILE], z = q[2 * TILE];
                 SGE_FOLD(x, y, z)
             }
         }
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, 
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
             const int v = tid + k * kBlasRefitBlock;
-            if (v < nv) { X[v] = px[k]; X[v + kBlasTileVerts] = py[k]; X[v + 2 * kBlasTileVerts] = pz[k]; }
+            if (v < nv) { X[v] = px[k]; X[v + TILE] = py[k]; X[v + 2 * TILE] = pz[k]; }
         }
         __syncthreads();
         const int rEnd = trs[tile + 1];
@@ -170,25 +170,38 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, 
     }
 }
 
+template <int TILE>
+static int launchRefitTile(const DevBlas& B, const float* p, int layout, long long firstVertex, int chars, float* bounds, int grid, size_t lds, hipStream_t s) {
+    static bool attrSet = false;
+    if (!attrSet) {
+        SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blas_refit_kernel<3, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlasMaxLdsBytes));
+        SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blas_refit_kernel<4, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlasMaxLdsBytes));
+        attrSet = true;
+    }
+    if (layout == SGE_LAYOUT_PADDED16) hipLaunchKernelGGL((blas_refit_kernel<4, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, B, p, firstVertex, chars, bounds);
+    else hipLaunchKernelGGL((blas_refit_kernel<3, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, B, p, firstVertex, chars, bounds);
+    return SGE_OK;
+}
+
 int launch_blas_refit(const DevBlas& B, const void* positions, int layout, long long firstVertex, int chars, float* bounds, hipStream_t s) {
     if (chars <= 0) return SGE_OK;
-    const size_t lds = blasRefitLdsBytes(B.entryCount, B.tileCount);
-    static int slots = 0;
-    if (!slots) {
-        SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blas_refit_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlasMaxLdsBytes));
-        SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blas_refit_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlasMaxLdsBytes));
-        int dev = 0, cus = 256;
+    const size_t lds = blasRefitLdsBytes(B.entryCount, B.tileCount, B.tileCap);
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        slots = cus;
     }
-    // as many workgroups as stay resident together: LDS allows floor(160 KB / lds) per CU
-    const int perCU = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / lds));
-    const int grid = std::min(chars, slots * perCU);
+    // persistent: as many workgroups as stay resident together (LDS allows floor(160 KB / lds) per CU)
+    const int perCU = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / (lds + 256)));
+    const int grid = std::min(chars, cus * perCU);
     const float* p = reinterpret_cast<const float*>(positions);
-    if (layout == SGE_LAYOUT_PADDED16) hipLaunchKernelGGL((blas_refit_kernel<4>), dim3(grid), dim3(kBlasRefitBlock), lds, s, B, p, firstVertex, chars, bounds);
-    else hipLaunchKernelGGL((blas_refit_kernel<3>), dim3(grid), dim3(kBlasRefitBlock), lds, s, B, p, firstVertex, chars, bounds);
-    return SGE_OK;
+    switch (B.tileCap) {
+    case 3072: return launchRefitTile<3072>(B, p, layout, firstVertex, chars, bounds, grid, lds, s);
+    case 2048: return launchRefitTile<2048>(B, p, layout, firstVertex, chars, bounds, grid, lds, s);
+    default: return launchRefitTile<4096>(B, p, layout, firstVertex, chars, bounds, grid, lds, s);
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -411,10 +411,13 @@ bool HostBlas::build(const float* pos, int V, const uint32_t* idx, int indexCoun
         ++levels;
         level.swap(next);
     }
-    tileCount = (V + kBlasTileVerts - 1) / kBlasTileVerts;
+    if (blasRefitLdsBytes(entryCount(), V / 512 + 2) > kBlasMaxLdsBytes) { err = "blas: mesh too large (more than ~250k triangles per character)"; return false; }
+    tileCap = kBlasTileVerts;
+    for (int cap : kBlasTileSteps)
+        if (cap >= 2048 && 3 * (blasRefitLdsBytes(entryCount(), V / cap + 2, cap) + 256) <= (size_t)160 * 1024) { tileCap = cap; break; }
+    tileCount = (V + tileCap - 1) / tileCap;
     tileVerts = ((V + tileCount - 1) / tileCount + 63) / 64 * 64;
     tileCount = (V + tileVerts - 1) / tileVerts;
-    if (blasRefitLdsBytes(entryCount(), V / 512 + 2) > kBlasMaxLdsBytes) { err = "blas: mesh too large (more than ~250k triangles per character)"; return false; }
 
     triCount = T;
     vertexCount = V;

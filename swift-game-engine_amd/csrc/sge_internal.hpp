@@ -161,7 +161,7 @@ struct HostBlas {
     std::vector<int> vertexEntryStart, vertexEntries; // CSR vertex -> clusters
     // refit schedule: the vertex stream is cut into tiles of tileVerts vertices; a chunk = up to 16 vertices of ONE tile
     // that belong to ONE cluster, the work of ONE lane; 64 chunks of similar length make a round, the work of one wavefront
-    int tileVerts = 0, tileCount = 0, chunkCount = 0;
+    int tileVerts = 0, tileCount = 0, chunkCount = 0, tileCap = 4096;
     std::vector<int> tileRoundStart;     // [tileCount + 1]
     std::vector<int> roundLen;           // [roundCount] vertices per chunk in this round (1..16; shorter chunks repeat their first vertex)
     std::vector<int> roundCluster;       // [roundCount][64] leaf entry of every lane's chunk (a short last round repeats its first chunk)
@@ -182,16 +182,19 @@ struct DevBlas {
     const uint32_t* slotTriangle;
     const int* vertexEntryStart;
     const int* vertexEntries;
-    int tileVerts, tileCount;
+    int tileVerts, tileCount, tileCap;
     const int* tileRoundStart;
     const int* roundLen;
     const int* roundCluster;
     const uint32_t* roundIds;
 };
 constexpr int kBlasRefitBlock = 512;
-constexpr int kBlasTileVerts = 4096; // vertices staged in LDS at a time (48 KB): kBlasRefitBlock threads x 8
+constexpr int kBlasTileVerts = 4096; // most vertices staged in LDS at a time (48 KB): kBlasRefitBlock threads x 8
+// LDS capacity of the tile: the largest of these that lets three workgroups share a CU's 160 KB beside their box tables,
+// else 4096 with two (HostBlas::build picks; the kernel is instantiated per capacity)
+constexpr int kBlasTileSteps[4] = {4096, 3072, 2048, 1024};
 // LDS of the refit kernel: the box table, six floats per row, (entryCount + 1) rows, + one tile of positions (SoA) + tileRoundStart
-inline size_t blasRefitLdsBytes(int entryCount, int tileCount) { return (size_t)(entryCount + 1) * 24 + (size_t)kBlasTileVerts * 12 + (size_t)(tileCount + 1) * 4; }
+inline size_t blasRefitLdsBytes(int entryCount, int tileCount, int tileCap = kBlasTileVerts) { return (size_t)(entryCount + 1) * 24 + (size_t)tileCap * 12 + (size_t)(tileCount + 1) * 4; }
 constexpr size_t kBlasMaxLdsBytes = 144 * 1024; // of the CU's 160 KB
 
 // ---- kernel launchers ----------------------------------------------------- //

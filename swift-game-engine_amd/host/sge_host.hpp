@@ -213,4 +213,39 @@ private:
     World* world_;
 };
 
+// ---- RTAccelerationBuilder, dynamic slices (RTAccelerationBuilder.swift:75-145) --------------------------
+// The skinned items' primitive acceleration structures: built once (usage .refit), refitted every frame from the
+// skinned vertex buffer. Static slices and the TLAS stay with the renderer.
+using RTRay = sge_blas_ray;
+using RTHit = sge_blas_hit;
+
+class RTAccelerationBuilder {
+public:
+    explicit RTAccelerationBuilder(World& w) : world_(&w) {}
+    // state.dynamicChanged branch (:75-112): encoder.build over the item's slice of the dynamic index buffer
+    void buildDynamic(const std::vector<uint32_t>& indices) {
+        check(sge_blas_build(world_->context(), indices.data(), (int32_t)indices.size()), "sge_blas_build");
+    }
+    // steady-state branch (:113-145): encoder.refit(... options: .vertexData) per dynamic slice; asynchronous
+    void refit(int first, int count) { check(sge_blas_refit(world_->context(), first, count), "sge_blas_refit"); }
+    // instance descriptors (:168-185): transformationMatrix = item.modelMatrix, column-major 4x4 per character
+    void setInstances(int first, int count, const float* modelMatrices) {
+        check(sge_blas_instances_upload(world_->context(), first, count, modelMatrices), "sge_blas_instances_upload");
+    }
+    // isect.intersect(ray, accel) against one instance + the kernel's reads at the hit (RayTracing.metalinc:242-300)
+    std::vector<RTHit> intersect(const std::vector<RTRay>& rays) {
+        std::vector<RTHit> hits(rays.size());
+        check(sge_blas_intersect_batch(world_->context(), rays.data(), (int32_t)rays.size(), hits.data()), "sge_blas_intersect_batch");
+        return hits;
+    }
+    sge_blas_info info() const {
+        sge_blas_info i{};
+        check(sge_blas_info_get(world_->context(), &i), "sge_blas_info_get");
+        return i;
+    }
+
+private:
+    World* world_;
+};
+
 } // namespace sge
