@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--refit", action="store_true",
                     help="also refit every character's acceleration structure after skinning (SURVEY 8 f2, the reference's next step; "
                          "not part of BASELINE.json's metric, so off by default); adds a `refit` object to the JSON line")
+    ap.add_argument("--fuse", action="store_true", help="with --refit: SGE_OPT_FUSE_BLAS_REFIT, the LBS kernel reduces the boxes itself")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only to rehearse N>1 on one GPU")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -96,6 +97,7 @@ def main():
     stages = abi.STAGE_ALL if mode == "ccd" else (abi.STAGE_LOCOMOTION | abi.STAGE_ACTION | abi.STAGE_POSE | abi.STAGE_WRITEBACK | abi.STAGE_SKIN)
     if args.refit:
         eng.blas_build(eng.mesh["indices"])
+        eng.set_option(abi.OPT_FUSE_BLAS_REFIT, 1 if args.fuse else 0)
         stages |= abi.STAGE_BLAS_REFIT
     exchange = None
     if args.workload == "agents":
@@ -192,7 +194,15 @@ def main():
         refit_ms = ms / max(launches, 1)
         out["metric"] += " + acceleration-structure refit"
         out["kernels_ms_per_step"]["blas_refit"] = ms / args.steps
-        out["refit"] = {"kernel": "blas_refit_kernel", "bound": "hbm", "bytes_per_launch": refit_bytes, "ms_per_launch": refit_ms,
+        if args.fuse:
+            # one launch does both: its bytes are the LBS kernel's plus the boxes (the positions are not read back)
+            fused_bytes = lbs_bytes + count * 24.0 * (info.entryCount + 1)
+            out["roofline"]["kernel"] = "skin_refit_kernel (4-weight LBS + box reduction from LDS)"
+            out["roofline"]["bytes_per_launch"] = fused_bytes
+            out["roofline"]["achieved"] = fused_bytes / (lbs_ms * 1e-3) / 1e9
+            out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
+            out["roofline"]["traffic"] = None
+        out["refit"] = {"fused_into_lbs": True, "entries": int(info.entryCount), "clusters": int(info.clusterCount)} if args.fuse else {"kernel": "blas_refit_kernel", "bound": "hbm", "bytes_per_launch": refit_bytes, "ms_per_launch": refit_ms,
                         "achieved": refit_bytes / (refit_ms * 1e-3) / 1e9 if refit_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": (refit_bytes / (refit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if refit_ms > 0 else 0.0,
                         "triangles_per_character": int(info.triangleCount), "clusters": int(info.clusterCount),

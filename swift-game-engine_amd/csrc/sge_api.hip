@@ -1067,16 +1067,24 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
             SGE_HIP(hipStreamWaitEvent(c->skinStream, c->evPoseDone, 0));
             ss = c->skinStream;
         }
-        {
+        const bool refit = (st & SGE_STAGE_BLAS_REFIT) != 0;
+        if (refit && c->blas.entryCount == 0) { set_error("SGE_STAGE_BLAS_REFIT needs sge_blas_build"); return SGE_ERR_STATE; }
+        float* boxes = refit ? c->dBlasBounds.as<float>() + (size_t)first * (c->blas.entryCount + 1) * 6 : nullptr;
+        if (refit && c->fuseBlas) {
+            // one launch: the LBS kernel keeps every position it computes in an LDS tile and reduces the boxes from there
             Bracket br(c, &c->evSkin, ss);
-            launch_skin(L, ss);
-        }
-        if (st & SGE_STAGE_BLAS_REFIT) { // RTAccelerationBuilder.build is enqueued right behind the skinning encoder (RayTracingScene.swift:35-43)
-            if (c->blas.entryCount == 0) { set_error("SGE_STAGE_BLAS_REFIT needs sge_blas_build"); return SGE_ERR_STATE; }
-            Bracket br(c, &c->evBlas, ss);
-            int rc = launch_blas_refit(c->blas, c->dOutPos.p, c->skinLayout, (long long)first * c->mesh.vertexCount, count,
-                                       c->dBlasBounds.as<float>() + (size_t)first * (c->blas.entryCount + 1) * 6, ss);
+            int rc = launch_skin_refit(L, c->blas, boxes, ss);
             if (rc != SGE_OK) return rc;
+        } else {
+            {
+                Bracket br(c, &c->evSkin, ss);
+                launch_skin(L, ss);
+            }
+            if (refit) { // RTAccelerationBuilder.build is enqueued right behind the skinning encoder (RayTracingScene.swift:35-43)
+                Bracket br(c, &c->evBlas, ss);
+                int rc = launch_blas_refit(c->blas, c->dOutPos.p, c->skinLayout, (long long)first * c->mesh.vertexCount, count, boxes, ss);
+                if (rc != SGE_OK) return rc;
+            }
         }
         if (overlap) { SGE_HIP(hipEventRecord(c->evSkinDone, c->skinStream)); c->skinPending = true; }
     } else if (st & SGE_STAGE_BLAS_REFIT) {

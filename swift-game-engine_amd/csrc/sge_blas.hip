@@ -19,21 +19,12 @@
 // cluster per lane; the closest hit is the wave minimum of (distance, primitive id), so the answer does not depend on
 // the visiting order and equals a brute-force scan of the index buffer.
 #include <algorithm>
-#include "sge_internal.hpp"
+#include "sge_blas_dev.hpp"
 
 namespace sge {
 
 constexpr int kWave = 64;
 typedef float v4f __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float waveMinF(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, kWave)); return v; }
-__device__ __forceinline__ float waveMaxF(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave)); return v; }
-
-// v_min_f32 / v_max_f32 as written (fminf() on a value loaded from LDS would first canonicalise it: one more instruction each)
-#define SGE_FOLD(X_, Y_, Z_)                                                   \
-    asm("v_min_f32 %0, %0, %1" : "+v"(mnx) : "v"(X_)); asm("v_max_f32 %0, %0, %1" : "+v"(mxx) : "v"(X_)); \
-    asm("v_min_f32 %0, %0, %1" : "+v"(mny) : "v"(Y_)); asm("v_max_f32 %0, %0, %1" : "+v"(mxy) : "v"(Y_)); \
-    asm("v_min_f32 %0, %0, %1" : "+v"(mnz) : "v"(Z_)); asm("v_max_f32 %0, %0, %1" : "+v"(mxz) : "v"(Z_));
 
 // Persistent workgroups (two or three per CU, as the LDS allows), each taking characters blockIdx.x, blockIdx.x + gridDim.x, ... LDS: tab[c * rows + row]
 // (c = 0..2 minima, 3..5 maxima), one tile of positions as X[], Y[], Z[], and the tiles' round ranges. The work is one
@@ -47,8 +38,6 @@ __device__ __forceinline__ float waveMaxF(float v) { for (int o = 32; o > 0; o >
 // waits only for them.
 // After a character's last tile: the inner entries are reduced from LDS level by level, one wavefront per wide node, the
 // table is written out coalesced and re-initialised.
-struct BlasRound { uint32_t w[8]; int cluster, len; };
-
 template <int STRIDE, int TILE>
 __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, const float* __restrict__ positions, long long firstVertex,
                                                                      int chars, float* __restrict__ bounds) {
@@ -57,8 +46,7 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, 
     float* tab = lds;
     float* X = lds + rows * 6; // Y = X + TILE, Z = X + 2 * TILE
     int* trs = reinterpret_cast<int*>(X + 3 * TILE);
-    const float inf = __builtin_inff();
-    for (int i = tid; i < rows * 6; i += kBlasRefitBlock) tab[i] = i < rows * 3 ? inf : -inf;
+    blasTableInit(tab, rows, tid, kBlasRefitBlock);
     for (int i = tid; i <= B.tileCount; i += kBlasRefitBlock) trs[i] = B.tileRoundStart[i];
     __syncthreads();
     const int lane = tid & (kWave - 1), wave = tid / kWave;
@@ -80,34 +68,6 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, 
             else { px[k] = __builtin_nontemporal_load(p); py[k] = __builtin_nontemporal_load(p + 1); pz[k] = __builtin_nontemporal_load(p + 2); }
         }
     };
-    auto fetchRound = [&](int r, BlasRound& R) {
-        const int rr = __builtin_amdgcn_readfirstlane(min(r, lastRound)); // past the end: a valid round, loaded but not used
-#pragma unroll
-        for (int j = 0; j < 8; ++j) R.w[j] = B.roundIds[((size_t)rr * 8 + j) * 64 + lane];
-        R.cluster = B.roundCluster[(size_t)rr * 64 + lane];
-        R.len = B.roundLen[rr];
-    };
-    auto walk = [&](const BlasRound& R) {
-        float mnx = inf, mny = inf, mnz = inf, mxx = -inf, mxy = -inf, mxz = -inf;
-        const char* Xb = reinterpret_cast<const char*>(X);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (i < R.len) { // wave-uniform
-                const uint32_t off = (i & 1) ? (R.w[i >> 1] >> 16) : (R.w[i >> 1] & 0xffffu);
-                const float* q = reinterpret_cast<const float*>(Xb + off);
-                const float x = q[0], y = q[TILE], z = q[2 * TILE];
-                SGE_FOLD(x, y, z)
-            }
-        }
-        float* t = tab + R.cluster;
-        __hip_atomic_fetch_min(t, mnx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_min(t + rows, mny, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_min(t + 2 * rows, mnz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_max(t + 3 * rows, mxx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_max(t + 4 * rows, mxy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_max(t + 5 * rows, mxz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-
     int c = blockIdx.x;
     if (c >= chars) return;
     // characters start at different tiles, so that the ones in flight at one time do not all read the same offset of their
@@ -126,40 +86,19 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, 
         const int rEnd = trs[tile + 1];
         int r = trs[tile] + wave;
         BlasRound R;
-        fetchRound(r, R);
+        blasFetchRound(B, r, lastRound, lane, R);
         // the next step: this character's next tile, or the next character's first
         const bool last = done + 1 == n;
         const int cNext = last ? c + (int)gridDim.x : c;
         const int tileNext = last ? cNext % n : (tile + 1 == n ? 0 : tile + 1);
         fetchPos(min(cNext, chars - 1), tileNext); // unconditional (a branch here would make the waits below conservative); after the last step: unused
-        if (r < rEnd) walk(R); // wave-uniform
+        if (r < rEnd) blasWalk<TILE>(tab, rows, X, R); // wave-uniform
         for (r += kWaves; r < rEnd; r += kWaves) { // only when a tile has more rounds than the workgroup has wavefronts
-            fetchRound(r, R);
-            walk(R);
+            blasFetchRound(B, r, lastRound, lane, R);
+            blasWalk<TILE>(tab, rows, X, R);
         }
         if (last) {
-            // inner entries from their wide nodes, deepest level first, one wavefront per wide node; then the table goes out
-            for (int lvl = B.levels - 1; lvl >= 0; --lvl) {
-                __syncthreads();
-                for (int w = B.wideLevelStart[lvl] + wave; w < B.wideLevelStart[lvl + 1]; w += kWaves) {
-                    const int first = B.wideFirst[w], cnt = B.wideFirst[w + 1] - first;
-                    const int parent = B.wideParentEntry[w];
-                    const int dst = parent < 0 ? B.entryCount : parent;
-                    for (int q = 0; q < 6; ++q) {
-                        float k = lane < cnt ? tab[q * rows + first + lane] : (q < 3 ? inf : -inf);
-                        k = q < 3 ? waveMinF(k) : waveMaxF(k);
-                        if (lane == 0) tab[q * rows + dst] = k;
-                    }
-                }
-            }
-            __syncthreads();
-            float* out = bounds + (size_t)c * rows * 6;
-            for (int i = tid; i < rows * 6; i += kBlasRefitBlock) {
-                const int row = i / 6, q = i - row * 6;
-                out[i] = tab[q * rows + row];
-            }
-            __syncthreads();
-            for (int i = tid; i < rows * 6; i += kBlasRefitBlock) tab[i] = i < rows * 3 ? inf : -inf;
+            blasFinishCharacter(B, tab, rows, tid, kBlasRefitBlock, bounds + (size_t)c * rows * 6);
             if (cNext >= chars) return;
             c = cNext;
             done = 0;

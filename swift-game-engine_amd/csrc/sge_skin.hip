@@ -14,7 +14,8 @@
 // This translation unit is compiled with the default -ffp-contract=fast: the Metal
 // original is built with MTL_FAST_MATH (project.pbxproj:328,386), there are no
 // thresholds downstream of this arithmetic, and the parity bound is 1e-5 relative.
-#include "sge_internal.hpp"
+#include <algorithm>
+#include "sge_blas_dev.hpp"
 
 namespace sge {
 
@@ -265,6 +266,145 @@ void launch_skin(const SkinLaunch& L, hipStream_t s) {
     else if (ss == 3 && ds == 4) hipLaunchKernelGGL((skin_kernel<3, 4>), grid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit);
     else if (ss == 4 && ds == 3) hipLaunchKernelGGL((skin_kernel<4, 3>), grid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit);
     else hipLaunchKernelGGL((skin_kernel<4, 4>), grid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit);
+}
+
+// ---------------------------------------------------------------------------
+// LBS + acceleration-structure refit in one kernel (SGE_OPT_FUSE_BLAS_REFIT): the positions never come back from HBM.
+// Persistent workgroups of kBlasRefitBlock threads, each taking characters blockIdx.x, blockIdx.x + gridDim.x, ...; per tile of
+// the refit schedule (sge_blas.hip, sge_blas_dev.hpp) the workgroup skins the tile's vertices — same arithmetic and the same
+// three non-temporal output streams as skin_kernel — and keeps a copy of every position in the LDS tile; after a barrier
+// every lane walks one chunk of the schedule exactly as blas_refit_kernel does. The boxes are therefore the min / max of
+// the very floats that were stored.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void blendAndTransform(const float4* pal, const VertexIn& v, float3& acc, float3& nn, float3& tn) {
+    const float w0 = fmaxf(v.w.x, 0.0f), w1 = fmaxf(v.w.y, 0.0f);
+    Row3 M;
+    {
+        const Row3 m = loadRows(pal, v.idx.x);
+        M.r0 = make_float4(m.r0.x * w0, m.r0.y * w0, m.r0.z * w0, m.r0.w * w0);
+        M.r1 = make_float4(m.r1.x * w0, m.r1.y * w0, m.r1.z * w0, m.r1.w * w0);
+        M.r2 = make_float4(m.r2.x * w0, m.r2.y * w0, m.r2.z * w0, m.r2.w * w0);
+    }
+#define SGE_BLEND(BONE, WGT)                                                  \
+    {                                                                         \
+        const Row3 m = loadRows(pal, (BONE));                                 \
+        M.r0.x += m.r0.x * (WGT); M.r0.y += m.r0.y * (WGT); M.r0.z += m.r0.z * (WGT); M.r0.w += m.r0.w * (WGT); \
+        M.r1.x += m.r1.x * (WGT); M.r1.y += m.r1.y * (WGT); M.r1.z += m.r1.z * (WGT); M.r1.w += m.r1.w * (WGT); \
+        M.r2.x += m.r2.x * (WGT); M.r2.y += m.r2.y * (WGT); M.r2.z += m.r2.z * (WGT); M.r2.w += m.r2.w * (WGT); \
+    }
+    SGE_BLEND(v.idx.y, w1)
+    if (v.w.z > 0.0f) SGE_BLEND(v.idx.z, v.w.z)
+    if (v.w.w > 0.0f) SGE_BLEND(v.idx.w, v.w.w)
+#undef SGE_BLEND
+    acc = xform(M, v.p, 1.0f);
+    nn = normalizeFast(xform(M, v.n, 0.0f));
+    tn = normalizeFast(xform(M, make_float3(v.t.x, v.t.y, v.t.z), 0.0f));
+}
+
+template <int SRC_STRIDE, int DST_STRIDE, int TILE>
+__global__ __launch_bounds__(kBlasRefitBlock) void skin_refit_kernel(SkinLaunch L, DevBlas B, float* __restrict__ bounds) {
+    extern __shared__ float lds[];
+    const int rows = B.entryCount + 1, tid = threadIdx.x;
+    float* tab = lds;
+    float* X = lds + rows * 6; // Y = X + TILE, Z = X + 2 * TILE
+    int* trs = reinterpret_cast<int*>(X + 3 * TILE);
+    float4* pal = reinterpret_cast<float4*>(lds + (((rows * 6 + 3 * TILE + B.tileCount + 1) + 3) & ~3));
+    blasTableInit(tab, rows, tid, kBlasRefitBlock);
+    for (int i = tid; i <= B.tileCount; i += kBlasRefitBlock) trs[i] = B.tileRoundStart[i];
+    __syncthreads();
+    const int lane = tid & (kBlasWave - 1), wave = tid / kBlasWave;
+    constexpr int kWaves = kBlasRefitBlock / kBlasWave, kPerThread = TILE / kBlasRefitBlock;
+    const int n = B.tileCount, lastRound = trs[n] - 1;
+    float* palf = reinterpret_cast<float*>(pal);
+
+    for (int c = blockIdx.x; c < L.chars; c += gridDim.x) {
+        // stage the palette: thread -> one float4 COLUMN (coalesced), scattered into rows (as skinRange does)
+        const float4* gp = reinterpret_cast<const float4*>(L.palettes + (size_t)c * L.paletteCount * 16);
+        for (int i = tid; i < L.paletteCount * 4; i += kBlasRefitBlock) {
+            const float4 col = gp[i];
+            const int bone = i >> 2, cc = i & 3;
+            palf[bone * 12 + 0 + cc] = col.x;
+            palf[bone * 12 + 4 + cc] = col.y;
+            palf[bone * 12 + 8 + cc] = col.z;
+        }
+        const size_t obase = (size_t)L.dstBaseVertex + (size_t)c * L.vertexCount;
+        for (int tile = 0; tile < n; ++tile) {
+            const int base = tile * B.tileVerts, nv = min(B.tileVerts, B.vertexCount - base);
+            // two vertices in flight per thread, as in skinRange (more would cost the occupancy that hides the store latency)
+            VertexIn cur = loadVertex<SRC_STRIDE>(L, base + min(tid, nv - 1));
+            // this wavefront's round of the tile, requested before the skinning arithmetic so that it has arrived by the walk
+            const int rEnd = trs[tile + 1];
+            int r = trs[tile] + wave;
+            BlasRound R;
+            blasFetchRound(B, r, lastRound, lane, R);
+            __syncthreads(); // palette staged (first tile); the previous tile's rounds have read X/Y/Z; the table is initialised
+#pragma unroll
+            for (int k = 0; k < kPerThread; ++k) {
+                const int v = tid + k * kBlasRefitBlock;
+                VertexIn nxt{};
+                if (k + 1 < kPerThread) nxt = loadVertex<SRC_STRIDE>(L, base + min(v + kBlasRefitBlock, nv - 1));
+                if (v < nv) {
+                    float3 acc, nn, tn;
+                    blendAndTransform(pal, cur, acc, nn, tn);
+                    const size_t o = obase + base + v;
+                    float* op = reinterpret_cast<float*>(L.outPos) + o * DST_STRIDE;
+                    float* on = reinterpret_cast<float*>(L.outNrm) + o * DST_STRIDE;
+                    if (DST_STRIDE == 4) {
+                        __builtin_nontemporal_store(v4f{acc.x, acc.y, acc.z, 0.f}, reinterpret_cast<v4f*>(op));
+                        __builtin_nontemporal_store(v4f{nn.x, nn.y, nn.z, 0.f}, reinterpret_cast<v4f*>(on));
+                    } else {
+                        __builtin_nontemporal_store(acc.x, op); __builtin_nontemporal_store(acc.y, op + 1); __builtin_nontemporal_store(acc.z, op + 2);
+                        __builtin_nontemporal_store(nn.x, on); __builtin_nontemporal_store(nn.y, on + 1); __builtin_nontemporal_store(nn.z, on + 2);
+                    }
+                    __builtin_nontemporal_store(v4f{tn.x, tn.y, tn.z, cur.t.w}, reinterpret_cast<v4f*>(L.outTan) + o);
+                    X[v] = acc.x; X[v + TILE] = acc.y; X[v + 2 * TILE] = acc.z;
+                }
+                cur = nxt;
+            }
+            __syncthreads();
+            if (r < rEnd) blasWalk<TILE>(tab, rows, X, R); // wave-uniform
+            for (r += kWaves; r < rEnd; r += kWaves) {
+                blasFetchRound(B, r, lastRound, lane, R);
+                blasWalk<TILE>(tab, rows, X, R);
+            }
+        }
+        blasFinishCharacter(B, tab, rows, tid, kBlasRefitBlock, bounds + (size_t)c * rows * 6);
+        // the next character's palette staging writes `pal` only after every wavefront has left the last walk (barriers inside
+        // blasFinishCharacter), and its first tile's barrier orders the table re-initialisation before any fold
+    }
+}
+
+template <int TILE>
+static int launchSkinRefitTile(const SkinLaunch& L, const DevBlas& B, float* bounds, int grid, size_t lds, hipStream_t s) {
+    static bool attrSet = false;
+    if (!attrSet) {
+        SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(skin_refit_kernel<3, 3, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(skin_refit_kernel<3, 4, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attrSet = true;
+    }
+    if (L.dstLayout == SGE_LAYOUT_PADDED16) hipLaunchKernelGGL((skin_refit_kernel<3, 4, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, L, B, bounds);
+    else hipLaunchKernelGGL((skin_refit_kernel<3, 3, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, L, B, bounds);
+    return SGE_OK;
+}
+
+// the crowd's skin stage and refit stage as one launch; the source mesh is the context's (packed)
+int launch_skin_refit(const SkinLaunch& L, const DevBlas& B, float* bounds, hipStream_t s) {
+    if (L.chars <= 0 || L.vertexCount <= 0) return SGE_OK;
+    const size_t lds = blasRefitLdsBytes(B.entryCount, B.tileCount, B.tileCap) + 16 + (size_t)L.paletteCount * 48;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    }
+    const int perCU = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / (lds + 256)));
+    const int grid = std::min(L.chars, cus * perCU);
+    switch (B.tileCap) {
+    case 3072: return launchSkinRefitTile<3072>(L, B, bounds, grid, lds, s);
+    case 2048: return launchSkinRefitTile<2048>(L, B, bounds, grid, lds, s);
+    default: return launchSkinRefitTile<4096>(L, B, bounds, grid, lds, s);
+    }
 }
 
 } // namespace sge

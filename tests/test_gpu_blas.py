@@ -66,6 +66,46 @@ def test_refit_boxes_are_exact(sge, real, layout):
         gpu.close()
 
 
+@pytest.mark.parametrize("real", [False, True])
+@pytest.mark.parametrize("layout", ["packed", "padded16"])
+def test_fused_skin_and_refit(sge, real, layout):
+    """SGE_OPT_FUSE_BLAS_REFIT: one kernel skins and reduces the boxes from the positions it has just computed. The boxes
+    must be the exact min / max of the positions it stored; the streams must match the two-kernel path."""
+    gpu = sge.CharacterEngine(0)
+    try:
+        n = 4 if real else 7
+        gpu.set_option(sge.abi.OPT_SKIN_LAYOUT, sge.abi.LAYOUT_PADDED16 if layout == "padded16" else sge.abi.LAYOUT_PACKED)
+        _scene(sge, gpu, n, real, mixed=True, seed=9)
+        gpu.blas_build(gpu.mesh["indices"])
+        topo = _topology(sge, gpu)
+        V = gpu.vertex_count
+        st = sge.abi.STAGE_ALL | sge.abi.STAGE_BLAS_REFIT
+        for _ in range(3):
+            gpu.tick(stages=st)
+        ref = [a.copy() for a in gpu.skinned()]
+        ref_boxes = gpu.blas_bounds()
+        gpu.set_option(sge.abi.OPT_FUSE_BLAS_REFIT, 1)
+        gpu.tick(dt=0.0, stages=sge.abi.STAGE_SKIN | sge.abi.STAGE_BLAS_REFIT)  # same palettes, fused kernel
+        got = gpu.skinned()
+        boxes = gpu.blas_bounds()
+        for g, r in zip(got, ref):
+            assert np.abs(g - r).max() <= 1e-6 * max(1.0, np.abs(r).max())
+        for c in range(n):
+            assert np.array_equal(boxes[c], expected_bounds(topo, gpu.mesh["indices"], got[0][c * V:(c + 1) * V])), c
+        assert np.abs(boxes - ref_boxes).max() <= 1e-6 * np.abs(ref_boxes).max()
+        # a sub-range through the fused path, then a few whole steps
+        gpu.tick(stages=st, first=1, count=2)
+        for _ in range(2):
+            gpu.tick(stages=st)
+        pos = gpu.skinned()[0]
+        boxes = gpu.blas_bounds()
+        for c in range(n):
+            assert np.array_equal(boxes[c], expected_bounds(topo, gpu.mesh["indices"], pos[c * V:(c + 1) * V])), c
+        gpu.set_option(sge.abi.OPT_FUSE_BLAS_REFIT, 0)
+    finally:
+        gpu.close()
+
+
 def test_refit_over_caller_buffers(sge):
     """sge_blas_refit_buffers: the same kernel over device buffers the caller owns (here: the context's own streams,
     read through sge_crowd_buffers, written to a separately allocated box table)."""
