@@ -207,6 +207,68 @@ def test_closest_hit_matches_the_triangle_scan(sge, real):
         gpu.close(); cpu.close()
 
 
+def _custom_mesh_engine(sge, positions, indices, n):
+    """An engine whose 'skinned mesh' is an arbitrary vertex / index set rigidly bound to the root bone; with the bind-pose
+    palette (identity) the skinned positions are the source positions, per clone."""
+    eng = sge.CharacterEngine(0)
+    ybot = sge.assets.YBotAssets()
+    eng.upload_skeleton(ybot)
+    eng.upload_profiles(ybot.profiles)
+    V = len(positions)
+    nrm = np.tile(np.array([0, 1, 0], np.float32), (V, 1))
+    mesh = {"positions": np.ascontiguousarray(positions, np.float32), "normals": nrm,
+            "tangents": np.tile(np.array([1, 0, 0, 1], np.float32), (V, 1)), "boneIndices": np.zeros((V, 4), np.uint16),
+            "boneWeights": np.tile(np.array([1, 0, 0, 0], np.float32), (V, 1)), "indices": np.ascontiguousarray(indices, np.uint32)}
+    eng.upload_skinned_mesh(mesh)
+    eng.resize(n)
+    L = sge.assets.default_locomotion(n, ybot)
+    L["flags"] = 0  # bind-pose branch: identity palette
+    eng.upload(bodies=sge.assets.default_bodies(n, np.zeros((n, 3))), params=sge.assets.default_controller_params(n),
+               controllers=sge.assets.default_controller_state(n), intents=sge.assets.default_intents(n), locomotion=L,
+               actions=sge.assets.default_actions(n))
+    return eng
+
+
+@pytest.mark.parametrize("case", ["one-triangle", "unreferenced+degenerate", "soup", "soup-fused"])
+def test_odd_meshes(sge, case):
+    """Edge cases of the topology / schedule: a single triangle; vertices no triangle uses and zero-area triangles; an
+    incoherent triangle soup whose vertex count is not a multiple of four and whose one tile has more rounds than the
+    workgroup has wavefronts (the on-demand path of the refit kernels)."""
+    rng = np.random.default_rng(3)
+    if case == "one-triangle":
+        pos, idx = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), np.array([0, 1, 2], np.uint32)
+    elif case == "unreferenced+degenerate":
+        pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [9, 9, 9], [2, 2, 2]], np.float32)
+        idx = np.array([0, 1, 2, 0, 0, 1, 2, 2, 2, 4, 1, 0], np.uint32)  # vertex 3 unused; two degenerate triangles
+    else:
+        pos = rng.uniform(-2, 2, (1237, 3)).astype(np.float32)
+        idx = rng.integers(0, 1237, 15000).astype(np.uint32)
+    n = 3
+    gpu = _custom_mesh_engine(sge, pos, idx, n)
+    try:
+        info = gpu.blas_build(idx)
+        topo = sge.CharacterEngine.blas_topology(pos, idx)
+        if case.startswith("soup"):
+            assert info.incidenceCount / 16 / 64 > 8, "this case is meant to have more than eight rounds in its tile"
+        if case == "soup-fused":
+            gpu.set_option(sge.abi.OPT_FUSE_BLAS_REFIT, 1)
+        gpu.tick(dt=0.0, stages=sge.abi.STAGE_POSE | sge.abi.STAGE_SKIN | sge.abi.STAGE_BLAS_REFIT)
+        p = gpu.skinned()[0]
+        V = len(pos)
+        assert np.abs(p[:V] - pos).max() < 1e-5
+        b = gpu.blas_bounds()
+        for c in range(n):
+            assert np.array_equal(b[c], expected_bounds(topo, idx, p[c * V:(c + 1) * V])), c
+        used = np.unique(idx)
+        assert np.array_equal(b[0, -1, :3], p[:V][used].min(0)) and np.array_equal(b[0, -1, 3:], p[:V][used].max(0))
+        if case == "unreferenced+degenerate":
+            assert b[0, -1, 3:].max() < 9, "the unreferenced vertex is in no box"
+            h = gpu.blas_intersect([[0.25, 0.25, -5]], [[0, 0, 1]], [1])  # triangle 0 at z = 0, triangle 3 just behind it
+            assert h["hit"][0] == 1 and h["primitive"][0] == 0 and abs(h["distance"][0] - 5) < 1e-6, "degenerate triangles are never hit"
+    finally:
+        gpu.close()
+
+
 def test_state_errors(sge):
     gpu = sge.CharacterEngine(0)
     try:
