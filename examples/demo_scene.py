@@ -11,7 +11,12 @@ and the fixed-step order of DemoScene.swift:56-75:
   KinematicMoveStopSystem -> LocomotionProfileSystem -> ActionAnimationSystem -> PoseStackSystem -> PhysicsWritebackSystem
   (+ the skinning encode of RayTracingScene.buildGeometryBuffers).
 
-Usage:  python examples/demo_scene.py [--steps 600] [--oracle]     (--oracle runs the CPU checker instead of the GPU)
+and what the renderer does next with the skinned vertices (RayTracingScene.buildGeometryBuffers ->
+RTAccelerationBuilder.build, RTAccelerationBuilder.swift:75-185; raytraceKernel primary rays, RayTracing.metalinc:225-300):
+the player's acceleration structure is refitted behind the skinning of every step, its instance matrix is the entity's
+TransformComponent, and `--render` shoots a small image of primary rays at it and prints the depth as ASCII.
+
+Usage:  python examples/demo_scene.py [--steps 600] [--oracle] [--render]   (--oracle runs the CPU checker instead of the GPU)
 The player walks to the ground mover, rides it, then heads for the elevator.
 """
 import argparse
@@ -91,7 +96,38 @@ def build(engine):
              "controllers": sge.assets.default_controller_state(1), "intents": sge.assets.default_intents(1),
              "locomotion": sge.assets.default_locomotion(1, ybot), "actions": sge.assets.default_actions(1, ybot, present=True)}
     engine.upload(**state)
+    engine.blas_build(engine.mesh["indices"])           # encoder.build of the skinned item (RTAccelerationBuilder.swift:75-112)
     return ybot, world, platforms, service
+
+
+def render_probe(engine, width=56, height=28, fov_y=0.6):
+    """Primary rays of the raytraceKernel (RayTracing.metalinc:225-235: origin = camera, direction through the pixel centre,
+    min_distance 0.001, max_distance 1e6) against the player's instance -> (hit mask, distances, hit records)."""
+    b = engine.download(what=("bodies",))["bodies"]
+    pos = b["position"][0].astype(np.float32)
+    m = F.model_matrix({"translation": pos, "rotation": b["transformRotation"][0], "scale": np.ones(3, np.float32)})
+    engine.blas_instances(np.asarray(m, np.float32).reshape(1, 16))   # instance descriptor = item.modelMatrix (:168-185)
+    eye = pos + np.array([0.0, 0.3, 9.0], np.float32)
+    target = pos + np.array([0.0, -0.2, 0.0], np.float32)
+    fwd = (target - eye) / np.linalg.norm(target - eye)
+    right = np.cross(fwd, (0, 1, 0)); right /= np.linalg.norm(right)
+    up = np.cross(right, fwd)
+    ys, xs = np.meshgrid((np.arange(height) + 0.5) / height, (np.arange(width) + 0.5) / width, indexing="ij")
+    th = np.tan(fov_y / 2)
+    d = fwd + ((xs * 2 - 1) * th * width / height * 0.5)[..., None] * right + ((1 - ys * 2) * th)[..., None] * up
+    d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).reshape(-1, 3).astype(np.float32)
+    h = engine.blas_intersect(np.tile(eye, (len(d), 1)), d, np.zeros(len(d), np.int32))
+    return h["hit"].reshape(height, width) == 1, h["distance"].reshape(height, width), h
+
+
+def ascii_depth(mask, dist):
+    ramp = "@%#*+=-:."
+    lo, hi = (dist[mask].min(), dist[mask].max()) if mask.any() else (0.0, 1.0)
+    rows = []
+    for r in range(mask.shape[0]):
+        rows.append("".join(ramp[min(len(ramp) - 1, int((dist[r, c] - lo) / max(hi - lo, 1e-6) * len(ramp)))] if mask[r, c] else " "
+                            for c in range(mask.shape[1])))
+    return "\n".join(rows)
 
 
 def run(engine, steps=600, dt=1.0 / 60.0, log=None):
@@ -109,7 +145,7 @@ def run(engine, steps=600, dt=1.0 / 60.0, log=None):
         dist = np.linalg.norm(d)
         v = d / dist * min(4.5, dist * 4) if dist > 0.05 else np.zeros(3)
         engine.upload(intents=sge.assets.default_intents(1, v.astype(np.float32)[None]))
-        engine.tick(dt=dt, stages=A.STAGE_ALL)
+        engine.tick(dt=dt, stages=A.STAGE_ALL | A.STAGE_BLAS_REFIT)   # ... skinning encode, then the acceleration-structure refit
         if s % 30 == 29 or s == steps - 1:
             b = engine.download(what=("bodies", "controllers", "locomotion"))
             trace.append((s + 1, b["bodies"]["position"][0].copy(), int(b["controllers"]["flags"][0]), int(b["controllers"]["groundTriangleIndex"][0]),
@@ -124,6 +160,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=600)
     ap.add_argument("--oracle", action="store_true", help="run the CPU checker (tests/oracle_binding.py) instead of the GPU library")
+    ap.add_argument("--render", action="store_true", help="shoot primary rays at the player after the last step and print the depth image")
     args = ap.parse_args()
     if args.oracle:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -133,3 +170,7 @@ if __name__ == "__main__":
         eng = sge.CharacterEngine(0)
     trace, skinned = run(eng, args.steps, log=print)
     print("skinned vertices: %d, bounds %s .. %s" % (len(skinned), skinned.min(0).round(3), skinned.max(0).round(3)))
+    if args.render:
+        mask, dist, hits = render_probe(eng)
+        print("primary rays: %d of %d hit the player, distances %.3f .. %.3f" % (mask.sum(), mask.size, dist[mask].min(), dist[mask].max()))
+        print(ascii_depth(mask, dist))

@@ -664,6 +664,17 @@ def test_demo_scene_example_parity(sge):
     assert np.abs(sg - sc).max() <= REL * np.abs(sc).max()
     pushed = [p[0] for _, p, _, _, _ in tg]
     assert min(pushed) < -12.0            # it reached the mover and was pushed along with it
+    # the renderer's next step: primary rays at the player's refitted acceleration structure (GPU: wide-BVH traversal over the
+    # boxes of the last step's refit; oracle: scan over every triangle). The two sides skin independently (1e-5), so silhouette
+    # pixels may differ; the image must agree almost everywhere and the depths where both hit.
+    mg, dg, hg = demo.render_probe(gpu)
+    mc, dc, hc = demo.render_probe(cpu)
+    assert mg.sum() > 100 and (mg != mc).sum() <= 0.02 * mg.sum()
+    both = mg & mc
+    assert np.abs(dg[both] - dc[both]).max() < 2e-3 and np.median(np.abs(dg[both] - dc[both])) < 1e-5
+    same = both.reshape(-1) & (hg["primitive"] == hc["primitive"])
+    assert same.sum() > 0.9 * both.sum()
+    assert np.abs(hg["normal"][same] - hc["normal"][same]).max() < 1e-3
     gpu.close()
     cpu.close()
 
