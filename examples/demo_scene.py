@@ -102,7 +102,7 @@ def build(engine):
 
 def render_probe(engine, width=56, height=28, fov_y=0.6):
     """Primary rays of the raytraceKernel (RayTracing.metalinc:225-235: origin = camera, direction through the pixel centre,
-    min_distance 0.001, max_distance 1e6) against the player's instance -> (hit mask, distances, hit records)."""
+    min_distance 0.001, max_distance 1e6) against the skinned items (here: the player) -> (hit mask, distances, hit records)."""
     b = engine.download(what=("bodies",))["bodies"]
     pos = b["position"][0].astype(np.float32)
     m = F.model_matrix({"translation": pos, "rotation": b["transformRotation"][0], "scale": np.ones(3, np.float32)})
@@ -116,7 +116,7 @@ def render_probe(engine, width=56, height=28, fov_y=0.6):
     th = np.tan(fov_y / 2)
     d = fwd + ((xs * 2 - 1) * th * width / height * 0.5)[..., None] * right + ((1 - ys * 2) * th)[..., None] * up
     d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).reshape(-1, 3).astype(np.float32)
-    h = engine.blas_intersect(np.tile(eye, (len(d), 1)), d, np.zeros(len(d), np.int32))
+    h = engine.blas_intersect(np.tile(eye, (len(d), 1)), d, np.full(len(d), -1, np.int32))   # instance < 0: against every skinned item
     return h["hit"].reshape(height, width) == 1, h["distance"].reshape(height, width), h
 
 

@@ -637,23 +637,25 @@ int sge_blas_buffers(sge_context* ctx, void** d_bounds, void** d_indices);
  * (RTAccelerationBuilder.swift:168-185): column-major 4x4 per character; identity until uploaded. */
 int sge_blas_instances_upload(sge_context* ctx, int32_t first, int32_t count, const float* model_matrices);
 
-/* `ray` of the raytraceKernel (RayTracing.metalinc:231-235) against ONE instance. 48 bytes. */
+/* `ray` of the raytraceKernel (RayTracing.metalinc:231-235). 48 bytes. */
 typedef struct sge_blas_ray {
     float origin[3];
     float minDistance;
     float direction[3];
     float maxDistance;
-    int32_t instance; /* character index */
+    int32_t instance; /* character index; < 0: every character (the TLAS level: closest hit over all instances, the smaller
+                       * instance index winning ties) */
     int32_t _pad[3];
 } sge_blas_ray;
 
 /* What the kernel derives from a triangle hit (RayTracing.metalinc:246-296) before materials and lights:
  * primitive_id, distance, triangle_barycentric_coord, the geometric normal of the world-space triangle flipped
  * against the ray, and the interpolated shading frame (nW, tW, bW) from the skinned normal / tangent streams.
- * 64 bytes. */
+ * 72 bytes. */
 typedef struct sge_blas_hit {
     int32_t hit;       /* intersection_type::triangle */
     int32_t primitive; /* hit.primitive_id: triangle of the index buffer */
+    int32_t instance;  /* hit.instance_id: character index (-1: no hit) */
     float distance;
     float bary[2];     /* weights of the triangle's second and third vertex */
     float geomNormal[3];
@@ -662,8 +664,10 @@ typedef struct sge_blas_hit {
     float bitangent[3];
 } sge_blas_hit;
 
-/* Closest hit of every ray against its instance's refitted structure. Host arrays; synchronous. Ties on distance
- * go to the smaller primitive id. */
+/* `isect.intersect(ray, accel)` (RayTracing.metalinc:242): closest hit of every ray against its instance's refitted
+ * structure, or against all of them. Host arrays; synchronous. Ties on distance go to the smaller instance, then the
+ * smaller primitive id. The instance level is a scan of the instances' world boxes (no TLAS is built: one wavefront tests
+ * 64 boxes per step). */
 int sge_blas_intersect_batch(sge_context* ctx, const sge_blas_ray* rays, int32_t count, sge_blas_hit* hits);
 
 /* HIP-event time of the refit launches since the last reset (SGE_OPT_PROFILE). */

@@ -34,11 +34,30 @@ static bool rayTriangleUV(V3 origin, V3 direction, V3 v0, V3 v1, V3 v2, float ep
     return true;
 }
 
+static void intersectInstance(const World& w, const sge_blas_ray& R, int instance, sge_blas_hit& H);
+
+// instance < 0: every character in ascending order, a later one winning only with a strictly smaller distance
 void blas_intersect(const World& w, const sge_blas_ray& R, sge_blas_hit& H) {
     std::memset(&H, 0, sizeof(H));
     H.primitive = -1;
-    const int N = (int)w.bodies.size(), V = w.mesh.vertexCount;
-    if (R.instance < 0 || R.instance >= N || w.blasIndices.empty()) return;
+    H.instance = -1;
+    const int N = (int)w.bodies.size();
+    if (R.instance >= N || w.blasIndices.empty()) return;
+    if (R.instance >= 0) { intersectInstance(w, R, R.instance, H); return; }
+    for (int i = 0; i < N; ++i) {
+        sge_blas_hit h;
+        intersectInstance(w, R, i, h);
+        if (h.hit && (!H.hit || h.distance < H.distance)) H = h;
+    }
+}
+
+static void intersectInstance(const World& w, const sge_blas_ray& R0, int instance, sge_blas_hit& H) {
+    std::memset(&H, 0, sizeof(H));
+    H.primitive = -1;
+    H.instance = -1;
+    sge_blas_ray R = R0;
+    R.instance = instance;
+    const int V = w.mesh.vertexCount;
     M4 M = m4_identity();
     if ((size_t)(R.instance + 1) * 16 <= w.blasInstances.size()) std::memcpy(&M, &w.blasInstances[(size_t)R.instance * 16], 64);
     const V3 a{M.c[0].x, M.c[0].y, M.c[0].z}, b{M.c[1].x, M.c[1].y, M.c[1].z}, c{M.c[2].x, M.c[2].y, M.c[2].z}, tr{M.c[3].x, M.c[3].y, M.c[3].z};
@@ -81,7 +100,7 @@ void blas_intersect(const World& w, const sge_blas_ray& R, sge_blas_hit& H) {
     const float tw = t4[3] * r4;
     const V3 nW = normalize(rot(nObj)), tW = normalize(rot(tObj)); // :298-299
     const V3 bW = normalize(cross(nW, tW) * tw);                   // :300
-    H.hit = 1; H.primitive = bestPrim; H.distance = bestT; H.bary[0] = bx; H.bary[1] = by;
+    H.hit = 1; H.primitive = bestPrim; H.instance = R.instance; H.distance = bestT; H.bary[0] = bx; H.bary[1] = by;
     H.geomNormal[0] = Ng.x; H.geomNormal[1] = Ng.y; H.geomNormal[2] = Ng.z;
     H.normal[0] = nW.x; H.normal[1] = nW.y; H.normal[2] = nW.z;
     H.tangent[0] = tW.x; H.tangent[1] = tW.y; H.tangent[2] = tW.z;

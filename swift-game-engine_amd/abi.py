@@ -158,7 +158,7 @@ class BlasRay(C.Structure):
 
 
 class BlasHit(C.Structure):
-    _fields_ = [("hit", i32), ("primitive", i32), ("distance", f32), ("bary", f32 * 2), ("geomNormal", f32 * 3),
+    _fields_ = [("hit", i32), ("primitive", i32), ("instance", i32), ("distance", f32), ("bary", f32 * 2), ("geomNormal", f32 * 3),
                 ("normal", f32 * 3), ("tangent", f32 * 3), ("bitangent", f32 * 3)]
 
 
@@ -229,7 +229,7 @@ platform_dtype = np.dtype([("aabbMin", "<f4", 3), ("aabbMax", "<f4", 3), ("delta
                            ("hasAABB", "<u4"), ("_pad", "<u4")])
 blas_ray_dtype = np.dtype([("origin", "<f4", 3), ("minDistance", "<f4"), ("direction", "<f4", 3), ("maxDistance", "<f4"),
                            ("instance", "<i4"), ("_pad", "<i4", 3)])
-blas_hit_dtype = np.dtype([("hit", "<i4"), ("primitive", "<i4"), ("distance", "<f4"), ("bary", "<f4", 2),
+blas_hit_dtype = np.dtype([("hit", "<i4"), ("primitive", "<i4"), ("instance", "<i4"), ("distance", "<f4"), ("bary", "<f4", 2),
                            ("geomNormal", "<f4", 3), ("normal", "<f4", 3), ("tangent", "<f4", 3), ("bitangent", "<f4", 3)])
 overlap_hit_dtype = np.dtype([("depth", "<f4"), ("position", "<f4", 3), ("normal", "<f4", 3),
                               ("triangleNormal", "<f4", 3), ("triangleIndex", "<i4"), ("material", material_dtype)])

@@ -93,7 +93,7 @@ struct sge_context {
     bool fuseBlas = false;
     int blasBoundsChars = 0;
     DevBuf dBlasEntryLink, dBlasWideFirst, dBlasWideParent, dBlasWideLevel, dBlasSlotIdx, dBlasSlotTri, dBlasVtxStart, dBlasVtxEntries,
-           dBlasIndices, dBlasBounds, dBlasInstances, dBlasRays, dBlasHits, dBlasTileStart, dBlasRoundLen, dBlasRoundCluster, dBlasRoundIds;
+           dBlasIndices, dBlasBounds, dBlasInstances, dBlasRays, dBlasHits, dBlasTileStart, dBlasRoundLen, dBlasRoundCluster, dBlasRoundIds, dBlasWorldBoxes;
     // stats / profiling
     DevBuf dStats;
     Events evMove, evPose, evSkin, evAgents, evBlas;
@@ -1204,9 +1204,12 @@ int sge_blas_intersect_batch(sge_context* c, const sge_blas_ray* rays, int32_t c
     int rc;
     if ((rc = upload(c->dBlasRays, rays, (size_t)count * sizeof(sge_blas_ray), c->stream)) != SGE_OK) return rc;
     if ((rc = c->dBlasHits.alloc((size_t)count * sizeof(sge_blas_hit))) != SGE_OK) return rc;
+    bool anyInstance = false;
+    for (int i = 0; i < count && !anyInstance; ++i) anyInstance = rays[i].instance < 0;
+    if (anyInstance && (rc = c->dBlasWorldBoxes.alloc((size_t)c->crowd.count * 24)) != SGE_OK) return rc;
     BlasTrace T{c->blas, c->dOutPos.p, c->dOutNrm.p, c->dOutTan.as<float>(), c->dBlasIndices.as<uint32_t>(), c->outLayoutAllocated,
-                c->dBlasBounds.as<float>(), c->dBlasInstances.as<float>(), c->crowd.count};
-    launch_blas_intersect(T, c->dBlasRays.as<sge_blas_ray>(), count, c->dBlasHits.as<sge_blas_hit>(), c->stream);
+                c->dBlasBounds.as<float>(), c->dBlasInstances.as<float>(), c->crowd.count, c->dBlasWorldBoxes.as<float>()};
+    launch_blas_intersect(T, c->dBlasRays.as<sge_blas_ray>(), count, c->dBlasHits.as<sge_blas_hit>(), anyInstance, c->stream);
     SGE_HIP(hipGetLastError());
     SGE_HIP(hipMemcpyAsync(hits, c->dBlasHits.p, (size_t)count * sizeof(sge_blas_hit), hipMemcpyDeviceToHost, c->stream));
     SGE_HIP(hipStreamSynchronize(c->stream));

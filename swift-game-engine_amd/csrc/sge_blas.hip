@@ -182,6 +182,48 @@ __device__ __forceinline__ F3 loadP(const float* base, uint32_t i) { const float
 
 constexpr int kBlasStack = 256;
 
+__device__ __forceinline__ Aff loadInstance(const float* instances, int inst) {
+    const float* Mf = instances + (size_t)inst * 16;
+    return Aff{F3{Mf[0], Mf[1], Mf[2]}, F3{Mf[4], Mf[5], Mf[6]}, F3{Mf[8], Mf[9], Mf[10]}, F3{Mf[12], Mf[13], Mf[14]}};
+}
+
+// widened slab test (CollisionQuery.swift:1603-1630 form): a box is only skipped when it is clearly off the ray or clearly
+// behind the best hit
+__device__ __forceinline__ bool slabPass(const float* bx, F3 o, F3 inv, float tMin, float bestT) {
+    float t0 = (bx[0] - o.x) * inv.x, t1 = (bx[3] - o.x) * inv.x;
+    float lo = fminf(t0, t1), hi = fmaxf(t0, t1);
+    t0 = (bx[1] - o.y) * inv.y; t1 = (bx[4] - o.y) * inv.y;
+    lo = fmaxf(lo, fminf(t0, t1)); hi = fminf(hi, fmaxf(t0, t1));
+    t0 = (bx[2] - o.z) * inv.z; t1 = (bx[5] - o.z) * inv.z;
+    lo = fmaxf(lo, fminf(t0, t1)); hi = fminf(hi, fmaxf(t0, t1));
+    const float slack = 1e-3f * fmaxf(fabsf(lo), fabsf(hi)) + 1e-4f;
+    return (lo - slack <= hi + slack) && (hi + slack >= tMin) && (lo - slack <= bestT);
+}
+__device__ __forceinline__ F3 invDir(F3 d) {
+    return F3{d.x != 0 ? 1.0f / d.x : kFloatMax, d.y != 0 ? 1.0f / d.y : kFloatMax, d.z != 0 ? 1.0f / d.z : kFloatMax};
+}
+
+// The instances' world-space boxes (what a TLAS build would start from): the box of the eight transformed corners of every
+// character's root row. One thread per instance.
+__global__ void blas_world_boxes_kernel(BlasTrace T, float* worldBoxes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T.chars) return;
+    const Aff M = loadInstance(T.instances, i);
+    const float* bx = T.bounds + ((size_t)i * (T.blas.entryCount + 1) + T.blas.entryCount) * 6;
+    F3 mn{kFloatMax, kFloatMax, kFloatMax}, mx{-kFloatMax, -kFloatMax, -kFloatMax};
+    for (int k = 0; k < 8; ++k) {
+        const F3 c = affMulPoint(M, F3{bx[(k & 1) ? 3 : 0], bx[(k & 2) ? 4 : 1], bx[(k & 4) ? 5 : 2]});
+        mn = vmin(mn, c);
+        mx = vmax(mx, c);
+    }
+    float* o = worldBoxes + (size_t)i * 6;
+    o[0] = mn.x; o[1] = mn.y; o[2] = mn.z; o[3] = mx.x; o[4] = mx.y; o[5] = mx.z;
+}
+
+// One wavefront per ray. `instance >= 0`: that character only. `instance < 0`: every character — the instance level is a
+// scan of the world boxes, 64 per step (the reference rebuilds its TLAS every frame; with a wavefront per ray 10,000 box
+// tests are 157 steps, so nothing is built), characters in ascending order, a later one winning only with a strictly
+// smaller distance.
 template <int STRIDE>
 __global__ __launch_bounds__(kWave) void blas_intersect_kernel(BlasTrace T, const sge_blas_ray* rays, int n, sge_blas_hit* hits) {
     __shared__ int stack[kBlasStack];
@@ -190,88 +232,107 @@ __global__ __launch_bounds__(kWave) void blas_intersect_kernel(BlasTrace T, cons
     const DevBlas& B = T.blas;
     sge_blas_hit H{};
     H.primitive = -1;
-    if (R.instance < 0 || R.instance >= T.chars) { if (lane == 0) hits[blockIdx.x] = H; return; }
-    const float* Mf = T.instances + (size_t)R.instance * 16;
-    const Aff M{F3{Mf[0], Mf[1], Mf[2]}, F3{Mf[4], Mf[5], Mf[6]}, F3{Mf[8], Mf[9], Mf[10]}, F3{Mf[12], Mf[13], Mf[14]}};
-    const Inv3 Mi = inverse3(M);
+    H.instance = -1;
+    if (R.instance >= T.chars) { if (lane == 0) hits[blockIdx.x] = H; return; }
     const F3 wo{R.origin[0], R.origin[1], R.origin[2]}, wd{R.direction[0], R.direction[1], R.direction[2]};
-    const F3 o = mul3(Mi, wo - M.c3), d = mul3(Mi, wd);
-    const F3 inv{d.x != 0 ? 1.0f / d.x : kFloatMax, d.y != 0 ? 1.0f / d.y : kFloatMax, d.z != 0 ? 1.0f / d.z : kFloatMax};
     const float tMin = smax(R.minDistance, 0.0f);
-    const size_t vbase = (size_t)R.instance * B.vertexCount;
-    const float* P = reinterpret_cast<const float*>(T.positions) + vbase * STRIDE;
-    const float* boxes = T.bounds + (size_t)R.instance * (B.entryCount + 1) * 6;
 
-    // best = (distance bits, primitive id); distances are >= 0, so their bit patterns order like the values
-    unsigned long long best = ((unsigned long long)__float_as_uint(R.maxDistance) << 32) | 0xffffffffull;
-    float bestU = 0, bestV = 0;
-    bool found = false;
-    int sp = 0;
-    if (lane == 0) stack[0] = 0;
-    sp = 1;
-    __syncthreads();
-    while (sp > 0) {
-        const int w = stack[sp - 1];
-        --sp;
+    float bestT = R.maxDistance, bestU = 0, bestV = 0;
+    uint32_t bestPrim = 0;
+    int bestInst = -1;
+
+    // closest hit inside one character; accepted when closer than bestT (equal: only the first character found keeps it)
+    auto traverse = [&](int inst) {
+        const Aff M = loadInstance(T.instances, inst);
+        const Inv3 Mi = inverse3(M);
+        const F3 o = mul3(Mi, wo - M.c3), d = mul3(Mi, wd);
+        const F3 inv = invDir(d);
+        const float* P = reinterpret_cast<const float*>(T.positions) + (size_t)inst * B.vertexCount * STRIDE;
+        const float* boxes = T.bounds + (size_t)inst * (B.entryCount + 1) * 6;
+        // (distance bits, primitive id); distances are >= 0, so their bit patterns order like the values. A character found
+        // earlier keeps a tie: the starting key carries primitive 0, which nothing is smaller than at equal distance.
+        unsigned long long best = ((unsigned long long)__float_as_uint(bestT) << 32) | (bestInst < 0 ? 0xffffffffull : 0ull);
+        float u0 = 0, v0 = 0;
+        bool found = false;
+        int sp = 1;
+        if (lane == 0) stack[0] = 0;
         __syncthreads();
-        const int first = B.wideFirst[w], cnt = B.wideFirst[w + 1] - first;
-        bool pass = false;
-        int2 link = make_int2(0, 0);
-        if (lane < cnt) {
-            const float* bx = boxes + (size_t)(first + lane) * 6;
-            link = B.entryLink[first + lane];
-            // slab test (CollisionQuery.swift:1603-1630 form), widened: a box is only skipped when it is clearly behind the best hit
-            float t0 = (bx[0] - o.x) * inv.x, t1 = (bx[3] - o.x) * inv.x;
-            float lo = fminf(t0, t1), hi = fmaxf(t0, t1);
-            t0 = (bx[1] - o.y) * inv.y; t1 = (bx[4] - o.y) * inv.y;
-            lo = fmaxf(lo, fminf(t0, t1)); hi = fminf(hi, fmaxf(t0, t1));
-            t0 = (bx[2] - o.z) * inv.z; t1 = (bx[5] - o.z) * inv.z;
-            lo = fmaxf(lo, fminf(t0, t1)); hi = fminf(hi, fmaxf(t0, t1));
-            const float bestT = __uint_as_float((unsigned)(best >> 32));
-            const float slack = 1e-3f * fmaxf(fabsf(lo), fabsf(hi)) + 1e-4f;
-            pass = (lo - slack <= hi + slack) && (hi + slack >= tMin) && (lo - slack <= bestT);
-        }
-        const unsigned long long inner = __ballot(pass && link.x >= 0), leaves = __ballot(pass && link.x < 0);
-        if (pass && link.x >= 0) {
-            const int at = sp + __popcll(inner & ((1ull << lane) - 1));
-            if (at < kBlasStack) stack[at] = link.x;
-        }
-        sp = min(sp + __popcll(inner), kBlasStack);
-        unsigned long long m = leaves;
-        while (m) {
-            const int src = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int firstSlot = ~__shfl(link.x, src, kWave), count = __shfl(link.y, src, kWave);
-            unsigned long long key = ~0ull;
-            float u = 0, v = 0;
-            if (lane < count) {
-                const uint32_t* ix = B.slotIndices + (size_t)(firstSlot + lane) * 3;
-                const F3 v0 = loadP<STRIDE>(P, ix[0]), v1 = loadP<STRIDE>(P, ix[1]), v2 = loadP<STRIDE>(P, ix[2]);
-                float t;
-                if (rayTriangleUV(o, d, v0, v1, v2, 1e-6f, t, u, v) && t >= tMin && t <= R.maxDistance)
-                    key = ((unsigned long long)__float_as_uint(t) << 32) | B.slotTriangle[firstSlot + lane];
+        while (sp > 0) {
+            const int w = stack[sp - 1];
+            --sp;
+            __syncthreads();
+            const int first = B.wideFirst[w], cnt = B.wideFirst[w + 1] - first;
+            bool pass = false;
+            int2 link = make_int2(0, 0);
+            if (lane < cnt) {
+                link = B.entryLink[first + lane];
+                pass = slabPass(boxes + (size_t)(first + lane) * 6, o, inv, tMin, __uint_as_float((unsigned)(best >> 32)));
             }
-            unsigned long long k = key;
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned lo32 = __shfl_xor((unsigned)k, off, kWave), hi32 = __shfl_xor((unsigned)(k >> 32), off, kWave);
-                const unsigned long long other = ((unsigned long long)hi32 << 32) | lo32;
-                k = other < k ? other : k;
+            const unsigned long long inner = __ballot(pass && link.x >= 0), leaves = __ballot(pass && link.x < 0);
+            if (pass && link.x >= 0) {
+                const int at = sp + __popcll(inner & ((1ull << lane) - 1));
+                if (at < kBlasStack) stack[at] = link.x;
             }
-            if (k != ~0ull && k < best) {
-                best = k;
-                found = true;
-                const int winner = __ffsll((long long)__ballot(key == k)) - 1;
-                bestU = __shfl(u, winner, kWave);
-                bestV = __shfl(v, winner, kWave);
+            sp = min(sp + __popcll(inner), kBlasStack);
+            unsigned long long m = leaves;
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int firstSlot = ~__shfl(link.x, src, kWave), count = __shfl(link.y, src, kWave);
+                unsigned long long key = ~0ull;
+                float u = 0, v = 0;
+                if (lane < count) {
+                    const uint32_t* ix = B.slotIndices + (size_t)(firstSlot + lane) * 3;
+                    const F3 p0 = loadP<STRIDE>(P, ix[0]), p1 = loadP<STRIDE>(P, ix[1]), p2 = loadP<STRIDE>(P, ix[2]);
+                    float t;
+                    if (rayTriangleUV(o, d, p0, p1, p2, 1e-6f, t, u, v) && t >= tMin && t <= R.maxDistance)
+                        key = ((unsigned long long)__float_as_uint(t) << 32) | B.slotTriangle[firstSlot + lane];
+                }
+                unsigned long long k = key;
+                for (int off = 32; off > 0; off >>= 1) {
+                    const unsigned lo32 = __shfl_xor((unsigned)k, off, kWave), hi32 = __shfl_xor((unsigned)(k >> 32), off, kWave);
+                    const unsigned long long other = ((unsigned long long)hi32 << 32) | lo32;
+                    k = other < k ? other : k;
+                }
+                if (k != ~0ull && k < best) {
+                    best = k;
+                    found = true;
+                    const int winner = __ffsll((long long)__ballot(key == k)) - 1;
+                    u0 = __shfl(u, winner, kWave);
+                    v0 = __shfl(v, winner, kWave);
+                }
+            }
+            __syncthreads();
+        }
+        if (found) {
+            bestT = __uint_as_float((unsigned)(best >> 32));
+            bestPrim = (uint32_t)best;
+            bestU = u0; bestV = v0;
+            bestInst = inst;
+        }
+    };
+
+    if (R.instance >= 0) {
+        traverse(R.instance);
+    } else {
+        const F3 inv = invDir(wd);
+        for (int base = 0; base < T.chars; base += kWave) {
+            const int i = base + lane;
+            const bool pass = i < T.chars && slabPass(T.worldBoxes + (size_t)i * 6, wo, inv, tMin, bestT);
+            unsigned long long m = __ballot(pass);
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                traverse(base + src);
             }
         }
-        __syncthreads();
     }
     if (lane != 0) return;
-    if (found) {
-        const uint32_t prim = (uint32_t)best;
-        const float t = __uint_as_float((unsigned)(best >> 32));
-        const uint32_t* ix = T.indices + (size_t)prim * 3;
+    if (bestInst >= 0) {
+        const Aff M = loadInstance(T.instances, bestInst);
+        const size_t vbase = (size_t)bestInst * B.vertexCount;
+        const float* P = reinterpret_cast<const float*>(T.positions) + vbase * STRIDE;
+        const uint32_t* ix = T.indices + (size_t)bestPrim * 3;
         const uint32_t i0 = ix[0], i1 = ix[1], i2 = ix[2];
         // RayTracing.metalinc:258-268
         const F3 w0 = affMulPoint(M, loadP<STRIDE>(P, i0)), w1 = affMulPoint(M, loadP<STRIDE>(P, i1)), w2 = affMulPoint(M, loadP<STRIDE>(P, i2));
@@ -292,7 +353,7 @@ __global__ __launch_bounds__(kWave) void blas_intersect_kernel(BlasTrace T, cons
         const F3 nW = normalize((M.c0 * nObj.x + M.c1 * nObj.y) + M.c2 * nObj.z);
         const F3 tW = normalize((M.c0 * tObj.x + M.c1 * tObj.y) + M.c2 * tObj.z);
         const F3 bW = normalize(cross(nW, tW) * tw);
-        H.hit = 1; H.primitive = (int32_t)prim; H.distance = t; H.bary[0] = bx; H.bary[1] = by;
+        H.hit = 1; H.primitive = (int32_t)bestPrim; H.instance = bestInst; H.distance = bestT; H.bary[0] = bx; H.bary[1] = by;
         H.geomNormal[0] = N.x; H.geomNormal[1] = N.y; H.geomNormal[2] = N.z;
         H.normal[0] = nW.x; H.normal[1] = nW.y; H.normal[2] = nW.z;
         H.tangent[0] = tW.x; H.tangent[1] = tW.y; H.tangent[2] = tW.z;
@@ -301,8 +362,9 @@ __global__ __launch_bounds__(kWave) void blas_intersect_kernel(BlasTrace T, cons
     hits[blockIdx.x] = H;
 }
 
-void launch_blas_intersect(const BlasTrace& T, const sge_blas_ray* d_rays, int n, sge_blas_hit* d_hits, hipStream_t s) {
+void launch_blas_intersect(const BlasTrace& T, const sge_blas_ray* d_rays, int n, sge_blas_hit* d_hits, bool anyInstance, hipStream_t s) {
     if (n <= 0) return;
+    if (anyInstance && T.chars > 0) hipLaunchKernelGGL(blas_world_boxes_kernel, dim3((T.chars + 255) / 256), dim3(256), 0, s, T, const_cast<float*>(T.worldBoxes));
     if (T.layout == SGE_LAYOUT_PADDED16) hipLaunchKernelGGL((blas_intersect_kernel<4>), dim3(n), dim3(kWave), 0, s, T, d_rays, n, d_hits);
     else hipLaunchKernelGGL((blas_intersect_kernel<3>), dim3(n), dim3(kWave), 0, s, T, d_rays, n, d_hits);
 }

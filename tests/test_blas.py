@@ -93,4 +93,8 @@ def test_oracle_ray_scan_known_answers(sge):
     assert np.allclose(h["geomNormal"][0], (0, 1, 0)) and np.allclose(h["geomNormal"][5], (0, -1, 0)), "flipped against the ray"
     assert np.allclose(h["normal"][0], (0, 1, 0)) and np.allclose(h["tangent"][0], (1, 0, 0))
     assert np.allclose(h["bitangent"][0], np.cross((0, 1, 0), (1, 0, 0)))
+    assert h["instance"].tolist() == [0, 0, 1, -1, -1, 0, -1]
+    # instance < 0: every character; ray 3 (above character 0, asked for character 1 before) now finds character 0
+    a = cpu.blas_intersect(o, d, np.full(len(o), -1, np.int32), max_distance=[1e6] * 6 + [2.0])
+    assert a["hit"].tolist() == [1, 1, 1, 1, 0, 1, 0] and a["instance"].tolist() == [0, 0, 1, 0, -1, 0, -1]
     cpu.close()

@@ -201,8 +201,26 @@ def test_closest_hit_matches_the_triangle_scan(sge, real):
         g2, c2 = gpu.blas_intersect(O, D, I, min_distance=lim), cpu.blas_intersect(O, D, I, min_distance=lim)
         assert np.array_equal(g2["primitive"], c2["primitive"]) and np.array_equal(g2["hit"], c2["hit"])
         assert (g2["distance"][g2["hit"] == 1] >= lim[g2["hit"] == 1]).all()
+        assert np.array_equal(g["instance"], np.where(g["hit"] == 1, I, -1))
         # out-of-range instance = miss
-        assert gpu.blas_intersect(O[:2], D[:2], [n, -1])["hit"].tolist() == [0, 0]
+        assert gpu.blas_intersect(O[:2], D[:2], [n, n + 7])["hit"].tolist() == [0, 0]
+        # instance < 0: the instance level — closest hit over ALL characters (the reference's TLAS), against the oracle's loop
+        # over every character and every triangle. Characters 0 and 1 are then put at the same place: the smaller index wins.
+        A = np.full(len(O), -1, np.int32)
+        ga, ca = gpu.blas_intersect(O, D, A), cpu.blas_intersect(O, D, A)
+        for f in ("hit", "primitive", "instance"):
+            assert np.array_equal(ga[f], ca[f]), (f, np.argwhere(ga[f] != ca[f])[:5])
+        assert np.abs(ga["distance"] - ca["distance"]).max() <= 1e-6 * max(1.0, np.abs(ca["distance"]).max())
+        assert (ga["hit"] >= g["hit"]).all() and (ga["distance"][g["hit"] == 1] <= g["distance"][g["hit"] == 1]).all()
+        assert len(np.unique(ga["instance"][ga["hit"] == 1])) == n, "rays aimed at every character find it"
+        cols[1] = cols[0]
+        for e in (gpu, cpu):
+            e.blas_instances(cols)
+        sel = I <= 1
+        gb, cb = gpu.blas_intersect(O[sel], D[sel], A[sel]), cpu.blas_intersect(O[sel], D[sel], A[sel])
+        for f in ("hit", "primitive", "instance"):
+            assert np.array_equal(gb[f], cb[f]), f
+        assert gb["hit"].sum() > 100
     finally:
         gpu.close(); cpu.close()
 
