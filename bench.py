@@ -42,9 +42,7 @@ def main():
     ap.add_argument("--assets", choices=["synthetic", "real"], default="synthetic",
                     help="real: the FBX-derived Y-Bot (35,440 vertices) and 17-Cheese / merged static scene from tests/golden/")
     ap.add_argument("--layout", choices=["packed", "padded16"], default="packed")
-    ap.add_argument("--overlap", type=int, nargs="?", const=1, default=0,
-                    help="skin(n) on a second stream, overlapping move(n+1). 1 (or no value): both streams share the chip; "
-                         "K > 1: the skin stream owns K of the 256 CUs, collision and pose the rest")
+    ap.add_argument("--overlap", action="store_true", help="skin(n) on a second stream, overlapping move(n+1)")
     ap.add_argument("--refit", action="store_true",
                     help="also refit every character's acceleration structure after skinning (SURVEY 8 f2, the reference's next step; "
                          "not part of BASELINE.json's metric, so off by default); adds a `refit` object to the JSON line")
@@ -85,7 +83,7 @@ def main():
     # ---- world: replicated per GPU ------------------------------------------------
     eng = sge.CharacterEngine(local_rank)
     eng.set_option(abi.OPT_SKIN_LAYOUT, abi.LAYOUT_PADDED16 if args.layout == "padded16" else abi.LAYOUT_PACKED)
-    eng.set_option(abi.OPT_OVERLAP_SKIN, args.overlap)
+    eng.set_option(abi.OPT_OVERLAP_SKIN, 1 if args.overlap else 0)
     ybot = sge.assets.YBotAssets()
     terrain = _build_world(sge, eng, ybot, args)
     n_total = args.chars * world
@@ -172,7 +170,7 @@ def main():
             "assets": args.assets,
             "characters_per_gpu": args.chars, "characters_total": n_total, "bones": B, "vertices_per_character": V,
             "static_triangles": int(eng.collision_counts()[1]), "dt": 1.0 / 60.0, "sharding": f"by-character x{world}",
-            "skin_layout": args.layout, "overlap_skin_with_next_move": bool(args.overlap), "skin_stream_cus": args.overlap if args.overlap > 1 else None, "settle_steps": SETTLE_STEPS if mode == "ccd" else 0, "seed": 1234,
+            "skin_layout": args.layout, "overlap_skin_with_next_move": bool(args.overlap), "settle_steps": SETTLE_STEPS if mode == "ccd" else 0, "seed": 1234,
         },
         "roofline": {"bound": "hbm", "kernel": "skin_kernel (4-weight LBS)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -57,7 +57,6 @@ struct sge_context {
     float placementMs = 0; int placementTried = 0;
     int heavyThreshold = 4000; // distance evaluations in a character's last step above which it takes the multi-wave kernel; < 0: off
     bool skinPending = false, overlapSkin = false, customStream = false;
-    int skinCUs = 0; // > 0: the skin stream owns this many CUs, every other stream of the context the rest (overlap option)
     // options
     bool storePoseDebug = false, profile = false;
     int skinLayout = SGE_LAYOUT_PACKED;
@@ -132,37 +131,6 @@ struct Bracket {
         if (c->profile) { (void)hipEventRecord(b, s); ev->pending.emplace_back(a, b); }
     }
 };
-
-// (Re)creates the context's own streams. skinCUs == 0: all of them on the whole chip (main / heavy at the highest priority,
-// skin at the lowest). skinCUs > 0: the skin stream is confined to the CUs of mask bits [0, skinCUs) and the main and heavy
-// streams to the rest (hipExtStreamCreateWithCUMask; mask bits are dealt round-robin over the XCDs, so both sets are spread
-// over all eight). A caller-provided main stream is left alone.
-int createStreams(sge_context* c, int skinCUs) {
-    if (c->skinStream) { (void)hipStreamDestroy(c->skinStream); c->skinStream = nullptr; }
-    if (c->heavyStream) { (void)hipStreamDestroy(c->heavyStream); c->heavyStream = nullptr; }
-    const bool ownIsCurrent = c->stream == c->ownStream;
-    if (c->ownStream) { (void)hipStreamDestroy(c->ownStream); c->ownStream = nullptr; }
-    if (skinCUs <= 0) {
-        int prLeast = 0, prGreatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest);
-        SGE_HIP(hipStreamCreateWithPriority(&c->ownStream, hipStreamNonBlocking, prGreatest));
-        SGE_HIP(hipStreamCreateWithPriority(&c->skinStream, hipStreamNonBlocking, prLeast));
-        SGE_HIP(hipStreamCreateWithPriority(&c->heavyStream, hipStreamNonBlocking, prGreatest));
-    } else {
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
-        skinCUs = std::min(skinCUs, cus - 8);
-        const int words = (cus + 31) / 32;
-        std::vector<uint32_t> a(words, 0u), b(words, 0u);
-        for (int i = 0; i < cus; ++i) (i < skinCUs ? a : b)[i / 32] |= 1u << (i % 32);
-        SGE_HIP(hipExtStreamCreateWithCUMask(&c->ownStream, (uint32_t)words, b.data()));
-        SGE_HIP(hipExtStreamCreateWithCUMask(&c->heavyStream, (uint32_t)words, b.data()));
-        SGE_HIP(hipExtStreamCreateWithCUMask(&c->skinStream, (uint32_t)words, a.data()));
-    }
-    if (ownIsCurrent) c->stream = c->ownStream;
-    c->skinCUs = skinCUs;
-    return SGE_OK;
-}
 
 // Everything enqueued so far on either stream has completed.
 int syncAll(sge_context* c) {
@@ -391,10 +359,14 @@ sge_context* sge_context_create(int device_index) {
     sge_context* c = new sge_context();
     c->device = device_index;
     // the latency-bound collision / pose launches go first when they compete with a streaming skin launch (overlap option)
-    if (createStreams(c, 0) != SGE_OK) { delete c; return nullptr; }
+    int prLeast = 0, prGreatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest);
+    if (hipStreamCreateWithPriority(&c->ownStream, hipStreamNonBlocking, prGreatest) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
     c->stream = c->ownStream;
-    if (hipEventCreateWithFlags(&c->evPoseDone, hipEventDisableTiming) != hipSuccess ||
+    if (hipStreamCreateWithPriority(&c->skinStream, hipStreamNonBlocking, prLeast) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evPoseDone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evSkinDone, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->heavyStream, hipStreamNonBlocking, prGreatest) != hipSuccess ||
         hipEventCreateWithFlags(&c->evClassified, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evHeavyDone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evTablesCopied, hipEventDisableTiming) != hipSuccess) { set_error("stream/event creation failed"); delete c; return nullptr; }
@@ -448,19 +420,7 @@ int sge_context_set_option(sge_context* c, int option, int value) {
         c->skinLayout = value;
         break;
     case SGE_OPT_PROFILE: c->profile = value != 0; break;
-    case SGE_OPT_OVERLAP_SKIN: {
-        int rcs = syncAll(c);
-        if (rcs != SGE_OK) return rcs;
-        c->overlapSkin = value != 0;
-        const int want = value > 1 && !c->customStream ? value : 0; // 1: shared CUs; > 1: that many CUs for the skin stream
-        if (want != c->skinCUs) {
-            (void)hipSetDevice(c->device);
-            if ((rcs = drainEvents(c->evMove)) != SGE_OK || (rcs = drainEvents(c->evPose)) != SGE_OK || (rcs = drainEvents(c->evSkin)) != SGE_OK ||
-                (rcs = drainEvents(c->evAgents)) != SGE_OK || (rcs = drainEvents(c->evBlas)) != SGE_OK) return rcs;
-            if ((rcs = createStreams(c, want)) != SGE_OK) return rcs;
-        }
-        break;
-    }
+    case SGE_OPT_OVERLAP_SKIN: { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; c->overlapSkin = value != 0; break; }
     case SGE_OPT_HEAVY_THRESHOLD: c->heavyThreshold = value; break;
     case SGE_OPT_PLACEMENT_PROBES: c->placementProbes = value; break;
     default: set_error("unknown option"); return SGE_ERR_INVALID;
