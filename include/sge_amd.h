@@ -4,7 +4,9 @@
  * This is the drop-in boundary for ONE hot path of kelian343/swift-game-engine:
  * MotionProfile pose evaluation + bone palette, 4-weight linear-blend skinning,
  * and capsule-CCD move-and-slide against the static and dynamic triangle sets of
- * CollisionQuery (kinematic-platform carry included).  The reference
+ * CollisionQuery (kinematic-platform carry included), followed by what the
+ * renderer does next with the skinned vertices: the per-frame refit of the skinned
+ * items' acceleration structures and the ray-hit reads (last section).  The reference
  * has no FFI layer; each entry point below names the Swift surface it replaces
  * (paths relative to the reference checkout).  A Swift host binds these through
  * a module map; tests and bench.py bind them with ctypes.
