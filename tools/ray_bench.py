@@ -1,0 +1,33 @@
+"""Diagnostic: closest-hit rays/s of sge_blas_intersect_batch (host arrays in, host arrays out, so PCIe included) for rays that
+name their character and for rays asked against all of them. usage: ray_bench.py [--real] [--chars N] [--rays M]"""
+import importlib, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sge = importlib.import_module("swift-game-engine_amd")
+abi = sge.abi
+arg = lambda k, d: int(sys.argv[sys.argv.index(k) + 1]) if k in sys.argv else d
+n, m = arg("--chars", 10000), arg("--rays", 200000)
+eng = sge.CharacterEngine(0)
+ybot = sge.assets.YBotAssets()
+(sge.crowd.upload_ybot_mesh if "--real" in sys.argv else sge.crowd.upload_character_assets)(eng, ybot)
+terrain = sge.crowd.upload_terrain(eng)
+sge.crowd.spawn_crowd(eng, ybot, n, terrain, mode="ccd")
+eng.blas_build(eng.mesh["indices"])
+for _ in range(130):
+    eng.tick(stages=abi.STAGE_ALL | abi.STAGE_BLAS_REFIT)
+b = eng.download(what=("bodies",))["bodies"]
+mats = np.tile(np.eye(4, dtype=np.float32), (n, 1, 1))
+mats[:, 3, :3] = b["position"].astype(np.float32)            # column-major: translation in the last column
+eng.blas_instances(mats.reshape(n, 16))
+rng = np.random.default_rng(1)
+inst = rng.integers(0, n, m).astype(np.int32)
+target = b["position"][inst].astype(np.float32) + rng.uniform(-0.6, 0.6, (m, 3)).astype(np.float32) * (1, 2, 1)
+origin = target + (rng.normal(size=(m, 3)) * (8, 2, 8) + (0, 6, 0)).astype(np.float32)
+d = target - origin
+d /= np.linalg.norm(d, axis=1, keepdims=True)
+for name, ids in (("named instance", inst), ("all instances ", np.full(m, -1, np.int32))):
+    eng.blas_intersect(origin[:1000], d[:1000], ids[:1000])
+    t = time.perf_counter()
+    h = eng.blas_intersect(origin, d, ids)
+    dt = time.perf_counter() - t
+    print("%s: %d rays vs %d characters in %.1f ms = %.2f M rays/s, %.0f %% hit" % (name, m, n, dt * 1e3, m / dt / 1e6, 100 * h["hit"].mean()))
