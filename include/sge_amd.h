@@ -621,6 +621,9 @@ int sge_blas_topology(const float* positions, int32_t vertex_count, const uint32
  * from the uploaded source positions; needs sge_skinned_mesh_upload first. */
 int sge_blas_build(sge_context* ctx, const uint32_t* indices, int32_t index_count);
 int sge_blas_info_get(sge_context* ctx, sge_blas_info* info);
+/* The item's slice of dynamicUVBuffer (RTGeometryCache.swift:277-283: the skinned item's uvs, copied once): float[V][2].
+ * Optional; without it hits report uv = (0, 0). Call after sge_blas_build. */
+int sge_blas_set_uvs(sge_context* ctx, const float* uvs, int32_t vertex_count);
 
 /* encoder.refit(..., options: .vertexData) (RTAccelerationBuilder.swift:113-145) for characters [first, first+count)
  * over the context's skinned positions. Asynchronous; also runs as SGE_STAGE_BLAS_REFIT of sge_tick, after the skin
@@ -652,8 +655,8 @@ typedef struct sge_blas_ray {
 
 /* What the kernel derives from a triangle hit (RayTracing.metalinc:246-296) before materials and lights:
  * primitive_id, distance, triangle_barycentric_coord, the geometric normal of the world-space triangle flipped
- * against the ray, and the interpolated shading frame (nW, tW, bW) from the skinned normal / tangent streams.
- * 72 bytes. */
+ * against the ray, the interpolated shading frame (nW, tW, bW) from the skinned normal / tangent streams, and interp_uv
+ * (RayTracing.metalinc:106-119). 80 bytes. */
 typedef struct sge_blas_hit {
     int32_t hit;       /* intersection_type::triangle */
     int32_t primitive; /* hit.primitive_id: triangle of the index buffer */
@@ -664,6 +667,7 @@ typedef struct sge_blas_hit {
     float normal[3];
     float tangent[3];
     float bitangent[3];
+    float uv[2];
 } sge_blas_hit;
 
 /* `isect.intersect(ray, accel)` (RayTracing.metalinc:242): closest hit of every ray against its instance's refitted

@@ -107,6 +107,7 @@ struct World {
     // the skinned item's slice of dynamicIndexBuffer + per-character instance matrices (RTAccelerationBuilder.swift:75-185)
     std::vector<uint32_t> blasIndices;
     std::vector<float> blasInstances; // [N][16], missing rows = identity
+    std::vector<float> blasUVs;       // [V][2] or empty
     // agents (start-of-step snapshot over ALL ranks' characters)
     std::vector<sge_agent_state> importedAgents;
     int agentSelfOffset = 0;

@@ -105,6 +105,10 @@ static void intersectInstance(const World& w, const sge_blas_ray& R0, int instan
     H.normal[0] = nW.x; H.normal[1] = nW.y; H.normal[2] = nW.z;
     H.tangent[0] = tW.x; H.tangent[1] = tW.y; H.tangent[2] = tW.z;
     H.bitangent[0] = bW.x; H.bitangent[1] = bW.y; H.bitangent[2] = bW.z;
+    if (w.blasUVs.size() == (size_t)V * 2) { // interp_uv, RayTracing.metalinc:106-119
+        const float* uv = w.blasUVs.data();
+        for (int k = 0; k < 2; ++k) H.uv[k] = (uv[(size_t)ix[0] * 2 + k] * bw + uv[(size_t)ix[1] * 2 + k] * bx) + uv[(size_t)ix[2] * 2 + k] * by;
+    }
 }
 
 } // namespace sgeo

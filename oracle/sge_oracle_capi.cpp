@@ -421,6 +421,15 @@ int sgeo_blas_build(sgeo_world* h, const uint32_t* indices, int32_t index_count)
     for (int i = 0; i < index_count; ++i)
         if (indices[i] >= (uint32_t)h->w.mesh.vertexCount) return SGE_ERR_INVALID;
     h->w.blasIndices.assign(indices, indices + index_count);
+    h->w.blasUVs.clear();
+    return SGE_OK;
+}
+
+int sgeo_blas_set_uvs(sgeo_world* h, const float* uvs, int32_t vertex_count) {
+    if (!h || !uvs) return SGE_ERR_INVALID;
+    if (h->w.blasIndices.empty()) return SGE_ERR_STATE;
+    if (vertex_count != h->w.mesh.vertexCount) return SGE_ERR_INVALID;
+    h->w.blasUVs.assign(uvs, uvs + (size_t)vertex_count * 2);
     return SGE_OK;
 }
 

@@ -159,7 +159,7 @@ class BlasRay(C.Structure):
 
 class BlasHit(C.Structure):
     _fields_ = [("hit", i32), ("primitive", i32), ("instance", i32), ("distance", f32), ("bary", f32 * 2), ("geomNormal", f32 * 3),
-                ("normal", f32 * 3), ("tangent", f32 * 3), ("bitangent", f32 * 3)]
+                ("normal", f32 * 3), ("tangent", f32 * 3), ("bitangent", f32 * 3), ("uv", f32 * 2)]
 
 
 class PlatformState(C.Structure):
@@ -230,7 +230,7 @@ platform_dtype = np.dtype([("aabbMin", "<f4", 3), ("aabbMax", "<f4", 3), ("delta
 blas_ray_dtype = np.dtype([("origin", "<f4", 3), ("minDistance", "<f4"), ("direction", "<f4", 3), ("maxDistance", "<f4"),
                            ("instance", "<i4"), ("_pad", "<i4", 3)])
 blas_hit_dtype = np.dtype([("hit", "<i4"), ("primitive", "<i4"), ("instance", "<i4"), ("distance", "<f4"), ("bary", "<f4", 2),
-                           ("geomNormal", "<f4", 3), ("normal", "<f4", 3), ("tangent", "<f4", 3), ("bitangent", "<f4", 3)])
+                           ("geomNormal", "<f4", 3), ("normal", "<f4", 3), ("tangent", "<f4", 3), ("bitangent", "<f4", 3), ("uv", "<f4", 2)])
 overlap_hit_dtype = np.dtype([("depth", "<f4"), ("position", "<f4", 3), ("normal", "<f4", 3),
                               ("triangleNormal", "<f4", 3), ("triangleIndex", "<i4"), ("material", material_dtype)])
 bvh_node_dtype = np.dtype([("boundsMin", "<f4", 3), ("boundsMax", "<f4", 3), ("left", "<i4"), ("right", "<i4"),
@@ -287,6 +287,7 @@ PROTOTYPES = {
     "sge_blas_topology": (C.c_int, [VP, i32, VP, i32, P(BlasInfo), VP, VP, VP, VP, VP, VP]),
     "sge_blas_build": (C.c_int, [VP, VP, i32]),
     "sge_blas_info_get": (C.c_int, [VP, P(BlasInfo)]),
+    "sge_blas_set_uvs": (C.c_int, [VP, VP, i32]),
     "sge_blas_refit": (C.c_int, [VP, i32, i32]),
     "sge_blas_refit_buffers": (C.c_int, [VP, VP, i32, i64, i32, VP]),
     "sge_blas_bounds_download": (C.c_int, [VP, i32, i32, VP]),

@@ -93,7 +93,8 @@ struct sge_context {
     bool fuseBlas = false;
     int blasBoundsChars = 0;
     DevBuf dBlasEntryLink, dBlasWideFirst, dBlasWideParent, dBlasWideLevel, dBlasSlotIdx, dBlasSlotTri, dBlasVtxStart, dBlasVtxEntries,
-           dBlasIndices, dBlasBounds, dBlasInstances, dBlasRays, dBlasHits, dBlasTileStart, dBlasRoundLen, dBlasRoundCluster, dBlasRoundIds, dBlasWorldBoxes;
+           dBlasIndices, dBlasBounds, dBlasInstances, dBlasRays, dBlasHits, dBlasTileStart, dBlasRoundLen, dBlasRoundCluster, dBlasRoundIds, dBlasWorldBoxes, dBlasUVs;
+    bool blasHasUVs = false;
     // stats / profiling
     DevBuf dStats;
     Events evMove, evPose, evSkin, evAgents, evBlas;
@@ -578,6 +579,7 @@ int sge_skinned_mesh_upload(sge_context* c, const sge_skinned_mesh_desc* d) {
     c->hostMeshPos.assign(d->positions, d->positions + V * 3);
     c->hostBlas = HostBlas{}; // a new mesh invalidates the acceleration structure built for the old one
     c->blas = DevBlas{};
+    c->blasHasUVs = false;
     if (c->crowd.count > 0) return allocCrowdOutputs(c);
     return SGE_OK;
 }
@@ -1127,7 +1129,20 @@ int sge_blas_build(sge_context* c, const uint32_t* indices, int32_t index_count)
                       c->dBlasSlotIdx.as<uint32_t>(), c->dBlasSlotTri.as<uint32_t>(), c->dBlasVtxStart.as<int>(), c->dBlasVtxEntries.as<int>(),
                       h.tileVerts, h.tileCount, h.tileCap, c->dBlasTileStart.as<int>(), c->dBlasRoundLen.as<int>(), c->dBlasRoundCluster.as<int>(), c->dBlasRoundIds.as<uint32_t>()};
     c->blasBoundsChars = 0;
+    c->blasHasUVs = false;
     return ensureBlasBuffers(c);
+}
+
+int sge_blas_set_uvs(sge_context* c, const float* uvs, int32_t vertex_count) {
+    if (!c || !uvs) { set_error("sge_blas_set_uvs: bad argument"); return SGE_ERR_INVALID; }
+    if (c->blas.entryCount == 0) { set_error("sge_blas_set_uvs needs sge_blas_build"); return SGE_ERR_STATE; }
+    if (vertex_count != c->mesh.vertexCount) { set_error("sge_blas_set_uvs: vertex count differs from the skinned mesh"); return SGE_ERR_INVALID; }
+    (void)hipSetDevice(c->device);
+    int rc = upload(c->dBlasUVs, uvs, (size_t)vertex_count * 8, c->stream);
+    if (rc != SGE_OK) return rc;
+    SGE_HIP(hipStreamSynchronize(c->stream));
+    c->blasHasUVs = true;
+    return SGE_OK;
 }
 
 int sge_blas_info_get(sge_context* c, sge_blas_info* info) {
@@ -1208,7 +1223,8 @@ int sge_blas_intersect_batch(sge_context* c, const sge_blas_ray* rays, int32_t c
     for (int i = 0; i < count && !anyInstance; ++i) anyInstance = rays[i].instance < 0;
     if (anyInstance && (rc = c->dBlasWorldBoxes.alloc((size_t)c->crowd.count * 24)) != SGE_OK) return rc;
     BlasTrace T{c->blas, c->dOutPos.p, c->dOutNrm.p, c->dOutTan.as<float>(), c->dBlasIndices.as<uint32_t>(), c->outLayoutAllocated,
-                c->dBlasBounds.as<float>(), c->dBlasInstances.as<float>(), c->crowd.count, c->dBlasWorldBoxes.as<float>()};
+                c->dBlasBounds.as<float>(), c->dBlasInstances.as<float>(), c->crowd.count, c->dBlasWorldBoxes.as<float>(),
+                c->blasHasUVs ? c->dBlasUVs.as<float>() : nullptr};
     launch_blas_intersect(T, c->dBlasRays.as<sge_blas_ray>(), count, c->dBlasHits.as<sge_blas_hit>(), anyInstance, c->stream);
     SGE_HIP(hipGetLastError());
     SGE_HIP(hipMemcpyAsync(hits, c->dBlasHits.p, (size_t)count * sizeof(sge_blas_hit), hipMemcpyDeviceToHost, c->stream));

@@ -358,6 +358,11 @@ __global__ __launch_bounds__(kWave) void blas_intersect_kernel(BlasTrace T, cons
         H.normal[0] = nW.x; H.normal[1] = nW.y; H.normal[2] = nW.z;
         H.tangent[0] = tW.x; H.tangent[1] = tW.y; H.tangent[2] = tW.z;
         H.bitangent[0] = bW.x; H.bitangent[1] = bW.y; H.bitangent[2] = bW.z;
+        if (T.uvs) { // interp_uv, RayTracing.metalinc:106-119
+            const float* a0 = T.uvs + (size_t)i0 * 2; const float* a1 = T.uvs + (size_t)i1 * 2; const float* a2 = T.uvs + (size_t)i2 * 2;
+            H.uv[0] = (a0[0] * bw + a1[0] * bx) + a2[0] * by;
+            H.uv[1] = (a0[1] * bw + a1[1] * bx) + a2[1] * by;
+        }
     }
     hits[blockIdx.x] = H;
 }

@@ -364,6 +364,11 @@ class CharacterEngine:
             return info
         return None
 
+    def blas_set_uvs(self, uvs):
+        """The item's slice of the dynamic UV buffer: hits then carry interp_uv."""
+        u = np.ascontiguousarray(uvs, np.float32).reshape(-1, 2)
+        self._call("blas_set_uvs", ptr(u), u.shape[0])
+
     def blas_refit(self, first=0, count=None):
         """encoder.refit(options: .vertexData) over the context's skinned positions. Asynchronous."""
         self._call("blas_refit", first, self.count - first if count is None else count)

@@ -226,6 +226,8 @@ public:
     void buildDynamic(const std::vector<uint32_t>& indices) {
         check(sge_blas_build(world_->context(), indices.data(), (int32_t)indices.size()), "sge_blas_build");
     }
+    // the item's uvs in the dynamic UV buffer (RTGeometryCache.swift:277-283); hits then carry interp_uv
+    void setUVs(const std::vector<float>& uvs) { check(sge_blas_set_uvs(world_->context(), uvs.data(), (int32_t)(uvs.size() / 2)), "sge_blas_set_uvs"); }
     // steady-state branch (:113-145): encoder.refit(... options: .vertexData) per dynamic slice; asynchronous
     void refit(int first, int count) { check(sge_blas_refit(world_->context(), first, count), "sge_blas_refit"); }
     // instance descriptors (:168-185): transformationMatrix = item.modelMatrix, column-major 4x4 per character

@@ -94,6 +94,10 @@ def test_oracle_ray_scan_known_answers(sge):
     assert np.allclose(h["normal"][0], (0, 1, 0)) and np.allclose(h["tangent"][0], (1, 0, 0))
     assert np.allclose(h["bitangent"][0], np.cross((0, 1, 0), (1, 0, 0)))
     assert h["instance"].tolist() == [0, 0, 1, -1, -1, 0, -1]
+    assert not h["uv"].any(), "no uvs uploaded: (0, 0)"
+    cpu.blas_set_uvs(pos[:, [0, 2]] * 10)   # uv = 10 * (x, z): interp_uv of the hit point
+    hu = cpu.blas_intersect(o, d, inst, max_distance=[1e6] * 6 + [2.0])
+    assert np.allclose(hu["uv"][0], (2.5, 2.5)) and np.allclose(hu["uv"][1], (7.5, 7.5)) and np.allclose(hu["uv"][2], (2.5, 2.5))
     # instance < 0: every character; ray 3 (above character 0, asked for character 1 before) now finds character 0
     a = cpu.blas_intersect(o, d, np.full(len(o), -1, np.int32), max_distance=[1e6] * 6 + [2.0])
     assert a["hit"].tolist() == [1, 1, 1, 1, 0, 1, 0] and a["instance"].tolist() == [0, 0, 1, 0, -1, 0, -1]

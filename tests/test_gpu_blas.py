@@ -154,6 +154,9 @@ def test_closest_hit_matches_the_triangle_scan(sge, real):
         for e in (gpu, cpu):
             _scene(sge, e, n, real, mixed=True, seed=5)
             e.blas_build(e.mesh["indices"])
+        uvs = gpu.mesh["uvs"] if "uvs" in gpu.mesh else np.random.default_rng(2).uniform(0, 1, (gpu.vertex_count, 2)).astype(np.float32)
+        for e in (gpu, cpu):
+            e.blas_set_uvs(uvs)
         for _ in range(4):
             gpu.tick(stages=sge.abi.STAGE_ALL | sge.abi.STAGE_BLAS_REFIT)
         gp, gn, gt = gpu.skinned()
@@ -193,7 +196,8 @@ def test_closest_hit_matches_the_triangle_scan(sge, real):
         assert (g["hit"] == 0).any()
         assert np.array_equal(g["hit"], c_["hit"])
         assert np.array_equal(g["primitive"], c_["primitive"]), np.argwhere(g["primitive"] != c_["primitive"])[:5]
-        for f in ("distance", "bary", "geomNormal", "normal", "tangent", "bitangent"):
+        assert np.abs(g["uv"][g["hit"] == 1]).max() > 0.1
+        for f in ("distance", "bary", "geomNormal", "normal", "tangent", "bitangent", "uv"):
             assert np.abs(g[f] - c_[f]).max() <= 1e-6 * max(1.0, np.abs(c_[f]).max()), f
         # distance limits
         lim = np.where(g["hit"] == 1, g["distance"] * 0.5, 1.0).astype(np.float32)
