@@ -379,12 +379,15 @@ void sge_context_destroy(sge_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)syncAll(c);
-    drainEvents(c->evMove); drainEvents(c->evPose); drainEvents(c->evSkin); drainEvents(c->evAgents);
+    drainEvents(c->evMove); drainEvents(c->evPose); drainEvents(c->evSkin); drainEvents(c->evAgents); drainEvents(c->evBlas);
     DevBuf* bufs[] = {&c->dParent, &c->dDepth, &c->dLeanChain, &c->dPath, &c->dBindLocal, &c->dInvBind, &c->dRestT, &c->dRawRestT, &c->dPreRot,
                       &c->dCoeffs, &c->dCoeffCount, &c->dBonePresent, &c->dMeshPos, &c->dMeshNrm, &c->dMeshTan, &c->dMeshIdx, &c->dMeshWgt,
                       &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dSlotOfRank, &c->dCost, &c->dHint, &c->dHeavyFlags, &c->dJobTable, &c->dBlockJob, &c->dLists, &c->dListCounts, &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
                       &c->dPalettes, &c->dPoseModel, &c->dPoseLocal, &c->dMoveScratch, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
-                      &c->dCellCursor, &c->dAgentMinMax, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats};
+                      &c->dCellCursor, &c->dAgentMinMax, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats,
+                      &c->dBlasEntryLink, &c->dBlasWideFirst, &c->dBlasWideParent, &c->dBlasWideLevel, &c->dBlasSlotIdx, &c->dBlasSlotTri, &c->dBlasVtxStart,
+                      &c->dBlasVtxEntries, &c->dBlasIndices, &c->dBlasBounds, &c->dBlasInstances, &c->dBlasRays, &c->dBlasHits, &c->dBlasTileStart,
+                      &c->dBlasRoundLen, &c->dBlasRoundCluster, &c->dBlasRoundIds, &c->dBlasWorldBoxes, &c->dBlasUVs};
     for (DevBuf* b : bufs) b->release();
     if (c->evPoseDone) (void)hipEventDestroy(c->evPoseDone);
     if (c->evSkinDone) (void)hipEventDestroy(c->evSkinDone);
