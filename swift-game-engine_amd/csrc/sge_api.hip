@@ -92,7 +92,7 @@ struct sge_context {
     DevBlas blas{};
     bool fuseBlas = false;
     int blasBoundsChars = 0;
-    DevBuf dBlasEntryLink, dBlasWideFirst, dBlasWideParent, dBlasWideLevel, dBlasSlotIdx, dBlasSlotTri, dBlasVtxStart, dBlasVtxEntries,
+    DevBuf dBlasEntryLink, dBlasWideFirst, dBlasWideParent, dBlasWideLevel, dBlasSlotIdx, dBlasSlotTri,
            dBlasIndices, dBlasBounds, dBlasInstances, dBlasRays, dBlasHits, dBlasTileStart, dBlasRoundLen, dBlasRoundCluster, dBlasRoundIds, dBlasWorldBoxes, dBlasUVs;
     bool blasHasUVs = false;
     // stats / profiling
@@ -385,8 +385,8 @@ void sge_context_destroy(sge_context* c) {
                       &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dSlotOfRank, &c->dCost, &c->dHint, &c->dHeavyFlags, &c->dJobTable, &c->dBlockJob, &c->dLists, &c->dListCounts, &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
                       &c->dPalettes, &c->dPoseModel, &c->dPoseLocal, &c->dMoveScratch, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
                       &c->dCellCursor, &c->dAgentMinMax, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats,
-                      &c->dBlasEntryLink, &c->dBlasWideFirst, &c->dBlasWideParent, &c->dBlasWideLevel, &c->dBlasSlotIdx, &c->dBlasSlotTri, &c->dBlasVtxStart,
-                      &c->dBlasVtxEntries, &c->dBlasIndices, &c->dBlasBounds, &c->dBlasInstances, &c->dBlasRays, &c->dBlasHits, &c->dBlasTileStart,
+                      &c->dBlasEntryLink, &c->dBlasWideFirst, &c->dBlasWideParent, &c->dBlasWideLevel, &c->dBlasSlotIdx, &c->dBlasSlotTri,
+                      &c->dBlasIndices, &c->dBlasBounds, &c->dBlasInstances, &c->dBlasRays, &c->dBlasHits, &c->dBlasTileStart,
                       &c->dBlasRoundLen, &c->dBlasRoundCluster, &c->dBlasRoundIds, &c->dBlasWorldBoxes, &c->dBlasUVs};
     for (DevBuf* b : bufs) b->release();
     if (c->evPoseDone) (void)hipEventDestroy(c->evPoseDone);
@@ -1117,8 +1117,6 @@ int sge_blas_build(sge_context* c, const uint32_t* indices, int32_t index_count)
     if ((rc = upload(c->dBlasWideLevel, hb.wideLevelStart.data(), hb.wideLevelStart.size() * 4, s)) != SGE_OK) return rc;
     if ((rc = upload(c->dBlasSlotIdx, hb.slotIndices.data(), hb.slotIndices.size() * 4, s)) != SGE_OK) return rc;
     if ((rc = upload(c->dBlasSlotTri, hb.slotTriangle.data(), hb.slotTriangle.size() * 4, s)) != SGE_OK) return rc;
-    if ((rc = upload(c->dBlasVtxStart, hb.vertexEntryStart.data(), hb.vertexEntryStart.size() * 4, s)) != SGE_OK) return rc;
-    if ((rc = upload(c->dBlasVtxEntries, hb.vertexEntries.data(), hb.vertexEntries.size() * 4, s)) != SGE_OK) return rc;
     if ((rc = upload(c->dBlasIndices, indices, (size_t)index_count * 4, s)) != SGE_OK) return rc;
     if ((rc = upload(c->dBlasTileStart, hb.tileRoundStart.data(), hb.tileRoundStart.size() * 4, s)) != SGE_OK) return rc;
     if ((rc = upload(c->dBlasRoundLen, hb.roundLen.data(), hb.roundLen.size() * 4, s)) != SGE_OK) return rc;
@@ -1129,7 +1127,7 @@ int sge_blas_build(sge_context* c, const uint32_t* indices, int32_t index_count)
     const HostBlas& h = c->hostBlas;
     c->blas = DevBlas{h.entryCount(), h.wideCount(), h.triCount, h.vertexCount, h.clusterCount, h.levels,
                       c->dBlasEntryLink.as<int2>(), c->dBlasWideFirst.as<int>(), c->dBlasWideParent.as<int>(), c->dBlasWideLevel.as<int>(),
-                      c->dBlasSlotIdx.as<uint32_t>(), c->dBlasSlotTri.as<uint32_t>(), c->dBlasVtxStart.as<int>(), c->dBlasVtxEntries.as<int>(),
+                      c->dBlasSlotIdx.as<uint32_t>(), c->dBlasSlotTri.as<uint32_t>(),
                       h.tileVerts, h.tileCount, h.tileCap, c->dBlasTileStart.as<int>(), c->dBlasRoundLen.as<int>(), c->dBlasRoundCluster.as<int>(), c->dBlasRoundIds.as<uint32_t>()};
     c->blasBoundsChars = 0;
     c->blasHasUVs = false;

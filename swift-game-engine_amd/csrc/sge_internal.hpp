@@ -180,8 +180,6 @@ struct DevBlas {
     const int* wideLevelStart;
     const uint32_t* slotIndices;
     const uint32_t* slotTriangle;
-    const int* vertexEntryStart;
-    const int* vertexEntries;
     int tileVerts, tileCount, tileCap;
     const int* tileRoundStart;
     const int* roundLen;
