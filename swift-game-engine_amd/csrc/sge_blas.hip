@@ -5,19 +5,22 @@
 // Layout (include/sge_amd.h, HostBlas::build): a 64-wide BVH whose topology is shared by all clones of the mesh; what
 // changes per character and per frame is one box per entry, float[entryCount + 1][6].
 //
-// blas_refit_kernel — one workgroup per character. The skinned positions are read ONCE, coalesced, in vertex order, a
-// tile of ~4k vertices at a time into LDS; the routing "vertex -> the clusters it belongs to" (1.6 clusters per vertex
-// on the Y-Bot) is a schedule built once with the topology and shared by all clones: per tile, the vertices of every
-// cluster that reaches into it, in chunks of 16. A lane walks one chunk from LDS with the running min / max in registers
-// and folds the result into the cluster's row of an LDS table; no triangle ever gathers its three vertices from HBM. The inner entries are then reduced level by level from LDS, one wavefront per wide node, and the whole table is
-// written out coalesced. HBM traffic per character: 12 B (16 B padded) per vertex in, 24 B per entry out; the index
-// buffer is not read at all. (Versions measured on the way, 10k Y-Bots: every vertex folded into its clusters with LDS
-// atomics, 4.5 ms — the LDS atomic rate is about one lane per clock per CU; a 16-lane group per chunk with a DPP
-// row reduction, 1.6 ms — four times the instructions of the lane-sequential walk.)
+// blas_refit_kernel — persistent workgroups, one character at a time. The skinned positions are read ONCE, coalesced, in
+// vertex order, a tile of 2-4k vertices at a time into LDS; the routing "vertex -> the clusters it belongs to" (1.6
+// clusters per vertex on the Y-Bot) is a schedule built once with the topology and shared by all clones: per tile, the
+// vertices of every cluster that reaches into it, in chunks of 16. A lane walks one chunk from LDS with the running
+// min / max in registers and folds the result into the cluster's row of an LDS table; no triangle ever gathers its three
+// vertices from HBM. The inner entries are then reduced level by level from LDS, one wavefront per wide node, and the
+// whole table is written out coalesced. HBM traffic per character: 12 B (16 B padded) per vertex in, 24 B per entry out;
+// the index buffer is not read at all. (Versions measured on the way, 10k Y-Bots: every vertex folded into its clusters
+// with LDS atomics, 4.5 ms — the LDS atomic rate is about one lane per clock per CU; a 16-lane group per chunk with a DPP
+// row reduction, 1.6 ms — four times the instructions of the lane-sequential walk; DESIGN.md section 9 has the table.)
+// The same per-tile work runs inside the LBS kernel when the two stages are fused (sge_skin.hip: skin_refit_kernel).
 //
 // blas_intersect_kernel — one wavefront per ray: a lane tests one entry's box per step, then one triangle of a
 // cluster per lane; the closest hit is the wave minimum of (distance, primitive id), so the answer does not depend on
-// the visiting order and equals a brute-force scan of the index buffer.
+// the visiting order and equals a brute-force scan of the index buffer. Rays that name no character scan the characters'
+// world boxes (blas_world_boxes_kernel) 64 per step and descend into the ones they may hit.
 #include <algorithm>
 #include "sge_blas_dev.hpp"
 
