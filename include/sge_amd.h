@@ -672,9 +672,12 @@ typedef struct sge_blas_hit {
 
 /* `isect.intersect(ray, accel)` (RayTracing.metalinc:242): closest hit of every ray against its instance's refitted
  * structure, or against all of them. Host arrays; synchronous. Ties on distance go to the smaller instance, then the
- * smaller primitive id. The instance level is a scan of the instances' world boxes (no TLAS is built: one wavefront tests
- * 64 boxes per step). */
+ * smaller primitive id. The instance level is two scans of world boxes, 64 per step: groups of 64 consecutive characters,
+ * then the characters of the groups the ray may hit (nothing else is built per frame). */
 int sge_blas_intersect_batch(sge_context* ctx, const sge_blas_ray* rays, int32_t count, sge_blas_hit* hits);
+/* The same with rays and hits in device memory (a renderer's ray buffers), enqueued on the context's stream: asynchronous.
+ * `any_instance` != 0 when some ray may carry instance < 0 (the world boxes are then refreshed first). */
+int sge_blas_intersect_device(sge_context* ctx, const void* d_rays, int32_t count, void* d_hits, int32_t any_instance);
 
 /* HIP-event time of the refit launches since the last reset (SGE_OPT_PROFILE). */
 int sge_blas_profile_read(sge_context* ctx, double* refit_ms, int64_t* refit_launches, int reset);

@@ -294,6 +294,7 @@ PROTOTYPES = {
     "sge_blas_buffers": (C.c_int, [VP, P(VP), P(VP)]),
     "sge_blas_instances_upload": (C.c_int, [VP, i32, i32, VP]),
     "sge_blas_intersect_batch": (C.c_int, [VP, VP, i32, VP]),
+    "sge_blas_intersect_device": (C.c_int, [VP, VP, i32, VP, i32]),
     "sge_blas_profile_read": (C.c_int, [VP, P(C.c_double), P(i64), C.c_int]),
 }
 

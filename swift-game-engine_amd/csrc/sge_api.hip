@@ -1222,7 +1222,7 @@ int sge_blas_intersect_batch(sge_context* c, const sge_blas_ray* rays, int32_t c
     if ((rc = c->dBlasHits.alloc((size_t)count * sizeof(sge_blas_hit))) != SGE_OK) return rc;
     bool anyInstance = false;
     for (int i = 0; i < count && !anyInstance; ++i) anyInstance = rays[i].instance < 0;
-    if (anyInstance && (rc = c->dBlasWorldBoxes.alloc((size_t)c->crowd.count * 24)) != SGE_OK) return rc;
+    if (anyInstance && (rc = c->dBlasWorldBoxes.alloc(((size_t)c->crowd.count + (c->crowd.count + 63) / 64) * 24)) != SGE_OK) return rc;
     BlasTrace T{c->blas, c->dOutPos.p, c->dOutNrm.p, c->dOutTan.as<float>(), c->dBlasIndices.as<uint32_t>(), c->outLayoutAllocated,
                 c->dBlasBounds.as<float>(), c->dBlasInstances.as<float>(), c->crowd.count, c->dBlasWorldBoxes.as<float>(),
                 c->blasHasUVs ? c->dBlasUVs.as<float>() : nullptr};
@@ -1230,6 +1230,22 @@ int sge_blas_intersect_batch(sge_context* c, const sge_blas_ray* rays, int32_t c
     SGE_HIP(hipGetLastError());
     SGE_HIP(hipMemcpyAsync(hits, c->dBlasHits.p, (size_t)count * sizeof(sge_blas_hit), hipMemcpyDeviceToHost, c->stream));
     SGE_HIP(hipStreamSynchronize(c->stream));
+    return SGE_OK;
+}
+
+int sge_blas_intersect_device(sge_context* c, const void* d_rays, int32_t count, void* d_hits, int32_t any_instance) {
+    if (!c || count < 0 || (count > 0 && (!d_rays || !d_hits))) { set_error("sge_blas_intersect_device: bad argument"); return SGE_ERR_INVALID; }
+    if (c->blas.entryCount == 0 || c->crowd.count == 0) { set_error("sge_blas_intersect_device needs sge_blas_build and characters"); return SGE_ERR_STATE; }
+    if (count == 0) return SGE_OK;
+    (void)hipSetDevice(c->device);
+    { int rcj = joinSkin(c); if (rcj != SGE_OK) return rcj; }
+    int rc;
+    if (any_instance && (rc = c->dBlasWorldBoxes.alloc(((size_t)c->crowd.count + (c->crowd.count + 63) / 64) * 24)) != SGE_OK) return rc;
+    BlasTrace T{c->blas, c->dOutPos.p, c->dOutNrm.p, c->dOutTan.as<float>(), c->dBlasIndices.as<uint32_t>(), c->outLayoutAllocated,
+                c->dBlasBounds.as<float>(), c->dBlasInstances.as<float>(), c->crowd.count, c->dBlasWorldBoxes.as<float>(),
+                c->blasHasUVs ? c->dBlasUVs.as<float>() : nullptr};
+    launch_blas_intersect(T, reinterpret_cast<const sge_blas_ray*>(d_rays), count, reinterpret_cast<sge_blas_hit*>(d_hits), any_instance != 0, c->stream);
+    SGE_HIP(hipGetLastError());
     return SGE_OK;
 }
 

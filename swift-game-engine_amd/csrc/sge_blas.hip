@@ -207,26 +207,36 @@ __device__ __forceinline__ F3 invDir(F3 d) {
 }
 
 // The instances' world-space boxes (what a TLAS build would start from): the box of the eight transformed corners of every
-// character's root row. One thread per instance.
-__global__ void blas_world_boxes_kernel(BlasTrace T, float* worldBoxes) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T.chars) return;
-    const Aff M = loadInstance(T.instances, i);
-    const float* bx = T.bounds + ((size_t)i * (T.blas.entryCount + 1) + T.blas.entryCount) * 6;
+// character's root row, and above them one box per 64 consecutive characters (worldBoxes[chars ..]). One wavefront per
+// 64 instances.
+__global__ __launch_bounds__(kWave) void blas_world_boxes_kernel(BlasTrace T, float* worldBoxes) {
+    const int i = blockIdx.x * kWave + threadIdx.x;
     F3 mn{kFloatMax, kFloatMax, kFloatMax}, mx{-kFloatMax, -kFloatMax, -kFloatMax};
-    for (int k = 0; k < 8; ++k) {
-        const F3 c = affMulPoint(M, F3{bx[(k & 1) ? 3 : 0], bx[(k & 2) ? 4 : 1], bx[(k & 4) ? 5 : 2]});
-        mn = vmin(mn, c);
-        mx = vmax(mx, c);
+    if (i < T.chars) {
+        const Aff M = loadInstance(T.instances, i);
+        const float* bx = T.bounds + ((size_t)i * (T.blas.entryCount + 1) + T.blas.entryCount) * 6;
+        for (int k = 0; k < 8; ++k) {
+            const F3 c = affMulPoint(M, F3{bx[(k & 1) ? 3 : 0], bx[(k & 2) ? 4 : 1], bx[(k & 4) ? 5 : 2]});
+            mn = vmin(mn, c);
+            mx = vmax(mx, c);
+        }
+        float* o = worldBoxes + (size_t)i * 6;
+        o[0] = mn.x; o[1] = mn.y; o[2] = mn.z; o[3] = mx.x; o[4] = mx.y; o[5] = mx.z;
     }
-    float* o = worldBoxes + (size_t)i * 6;
-    o[0] = mn.x; o[1] = mn.y; o[2] = mn.z; o[3] = mx.x; o[4] = mx.y; o[5] = mx.z;
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = vmin(mn, F3{__shfl_xor(mn.x, off, kWave), __shfl_xor(mn.y, off, kWave), __shfl_xor(mn.z, off, kWave)});
+        mx = vmax(mx, F3{__shfl_xor(mx.x, off, kWave), __shfl_xor(mx.y, off, kWave), __shfl_xor(mx.z, off, kWave)});
+    }
+    if (threadIdx.x == 0) {
+        float* o = worldBoxes + ((size_t)T.chars + blockIdx.x) * 6;
+        o[0] = mn.x; o[1] = mn.y; o[2] = mn.z; o[3] = mx.x; o[4] = mx.y; o[5] = mx.z;
+    }
 }
 
-// One wavefront per ray. `instance >= 0`: that character only. `instance < 0`: every character — the instance level is a
-// scan of the world boxes, 64 per step (the reference rebuilds its TLAS every frame; with a wavefront per ray 10,000 box
-// tests are 157 steps, so nothing is built), characters in ascending order, a later one winning only with a strictly
-// smaller distance.
+// One wavefront per ray. `instance >= 0`: that character only. `instance < 0`: every character — the instance level is two
+// scans, 64 boxes per step: the boxes of 64 consecutive characters, then the world boxes of the groups the ray may hit (the
+// reference rebuilds its TLAS every frame; here the per-frame work is one box reduction, and a crowd's index order is
+// largely its spatial order), characters in ascending order, a later one winning only with a strictly smaller distance.
 template <int STRIDE>
 __global__ __launch_bounds__(kWave) void blas_intersect_kernel(BlasTrace T, const sge_blas_ray* rays, int n, sge_blas_hit* hits) {
     __shared__ int stack[kBlasStack];
@@ -319,14 +329,22 @@ __global__ __launch_bounds__(kWave) void blas_intersect_kernel(BlasTrace T, cons
         traverse(R.instance);
     } else {
         const F3 inv = invDir(wd);
-        for (int base = 0; base < T.chars; base += kWave) {
-            const int i = base + lane;
-            const bool pass = i < T.chars && slabPass(T.worldBoxes + (size_t)i * 6, wo, inv, tMin, bestT);
-            unsigned long long m = __ballot(pass);
-            while (m) {
-                const int src = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                traverse(base + src);
+        const int groups = (T.chars + kWave - 1) / kWave;
+        const float* groupBoxes = T.worldBoxes + (size_t)T.chars * 6;
+        for (int gbase = 0; gbase < groups; gbase += kWave) {
+            const int g = gbase + lane;
+            unsigned long long gm = __ballot(g < groups && slabPass(groupBoxes + (size_t)g * 6, wo, inv, tMin, bestT));
+            while (gm) {
+                const int gsrc = __ffsll((long long)gm) - 1;
+                gm &= gm - 1;
+                const int base = (gbase + gsrc) * kWave, i = base + lane;
+                const bool pass = i < T.chars && slabPass(T.worldBoxes + (size_t)i * 6, wo, inv, tMin, bestT);
+                unsigned long long m = __ballot(pass);
+                while (m) {
+                    const int src = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    traverse(base + src);
+                }
             }
         }
     }
@@ -372,7 +390,7 @@ __global__ __launch_bounds__(kWave) void blas_intersect_kernel(BlasTrace T, cons
 
 void launch_blas_intersect(const BlasTrace& T, const sge_blas_ray* d_rays, int n, sge_blas_hit* d_hits, bool anyInstance, hipStream_t s) {
     if (n <= 0) return;
-    if (anyInstance && T.chars > 0) hipLaunchKernelGGL(blas_world_boxes_kernel, dim3((T.chars + 255) / 256), dim3(256), 0, s, T, const_cast<float*>(T.worldBoxes));
+    if (anyInstance && T.chars > 0) hipLaunchKernelGGL(blas_world_boxes_kernel, dim3((T.chars + kWave - 1) / kWave), dim3(kWave), 0, s, T, const_cast<float*>(T.worldBoxes));
     if (T.layout == SGE_LAYOUT_PADDED16) hipLaunchKernelGGL((blas_intersect_kernel<4>), dim3(n), dim3(kWave), 0, s, T, d_rays, n, d_hits);
     else hipLaunchKernelGGL((blas_intersect_kernel<3>), dim3(n), dim3(kWave), 0, s, T, d_rays, n, d_hits);
 }

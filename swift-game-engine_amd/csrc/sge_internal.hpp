@@ -266,7 +266,8 @@ struct BlasTrace {
     const float* bounds;     // [chars][entryCount + 1][6]
     const float* instances;  // [chars][16] model matrices
     int chars;
-    const float* worldBoxes; // [chars][6], filled by launch_blas_intersect when a ray asks for every instance
+    const float* worldBoxes; // [chars + ceil(chars / 64)][6]: per instance, then per 64 consecutive instances; filled by
+                             // launch_blas_intersect when a ray asks for every instance
     const float* uvs;        // [V][2] of the shared mesh, or null
 };
 void launch_blas_intersect(const BlasTrace& T, const sge_blas_ray* d_rays, int n, sge_blas_hit* d_hits, bool anyInstance, hipStream_t s);

@@ -396,6 +396,10 @@ class CharacterEngine:
         self._call("blas_intersect_batch", ptr(r), r.shape[0], ptr(out))
         return out
 
+    def blas_intersect_device(self, d_rays, count, d_hits, any_instance=True):
+        """Rays / hits already in device memory (blas_ray_dtype / blas_hit_dtype records); asynchronous on the context's stream."""
+        self._call("blas_intersect_device", C.c_void_p(d_rays), int(count), C.c_void_p(d_hits), int(bool(any_instance)))
+
     def blas_profile(self, reset=True):
         ms, n = C.c_double(0), C.c_int64(0)
         self._call("blas_profile_read", C.byref(ms), C.byref(n), int(reset))

@@ -21,7 +21,7 @@ _SKIP = {"sge_context_create", "sge_context_destroy", "sge_last_error", "sge_abi
          "sge_skinned_mesh_buffers", "sge_profile_read",
          # the acceleration structure is the product's own layout; the oracle only scans the index buffer
          "sge_blas_topology", "sge_blas_info_get", "sge_blas_refit", "sge_blas_refit_buffers", "sge_blas_bounds_download",
-         "sge_blas_buffers", "sge_blas_profile_read"}
+         "sge_blas_buffers", "sge_blas_profile_read", "sge_blas_intersect_device"}
 
 
 def build_oracle():

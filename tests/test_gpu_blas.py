@@ -217,6 +217,18 @@ def test_closest_hit_matches_the_triangle_scan(sge, real):
         assert np.abs(ga["distance"] - ca["distance"]).max() <= 1e-6 * max(1.0, np.abs(ca["distance"]).max())
         assert (ga["hit"] >= g["hit"]).all() and (ga["distance"][g["hit"] == 1] <= g["distance"][g["hit"] == 1]).all()
         assert len(np.unique(ga["instance"][ga["hit"] == 1])) == n, "rays aimed at every character find it"
+        # the device-memory entry point gives the same records
+        import torch
+        r = np.zeros(len(O), sge.abi.blas_ray_dtype)
+        r["origin"], r["direction"], r["minDistance"], r["maxDistance"], r["instance"] = O, D, 0.001, 1e6, A
+        d_r = torch.from_numpy(r.view(np.uint8).copy()).to("cuda:0")
+        d_h = torch.zeros(len(O) * sge.abi.blas_hit_dtype.itemsize, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        gpu.blas_intersect_device(d_r.data_ptr(), len(O), d_h.data_ptr())
+        gpu.synchronize()
+        hd = d_h.cpu().numpy().view(sge.abi.blas_hit_dtype)
+        for f in hd.dtype.names:
+            assert np.array_equal(hd[f], ga[f]), f
         cols[1] = cols[0]
         for e in (gpu, cpu):
             e.blas_instances(cols)

@@ -31,3 +31,20 @@ for name, ids in (("named instance", inst), ("all instances ", np.full(m, -1, np
     h = eng.blas_intersect(origin, d, ids)
     dt = time.perf_counter() - t
     print("%s: %d rays vs %d characters in %.1f ms = %.2f M rays/s, %.0f %% hit" % (name, m, n, dt * 1e3, m / dt / 1e6, 100 * h["hit"].mean()))
+
+import torch
+r = np.zeros(m, abi.blas_ray_dtype)
+r["origin"], r["direction"], r["minDistance"], r["maxDistance"] = origin, d, 0.001, 1e6
+for name, ids in (("named instance", inst), ("all instances ", np.full(m, -1, np.int32))):
+    r["instance"] = ids
+    d_r = torch.from_numpy(r.view(np.uint8).copy()).to("cuda:0")
+    d_h = torch.zeros(m * abi.blas_hit_dtype.itemsize, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    eng.blas_intersect_device(d_r.data_ptr(), m, d_h.data_ptr())
+    eng.synchronize()
+    t = time.perf_counter()
+    for _ in range(5):
+        eng.blas_intersect_device(d_r.data_ptr(), m, d_h.data_ptr())
+    eng.synchronize()
+    dt = (time.perf_counter() - t) / 5
+    print("%s, rays and hits resident on the device: %.2f ms = %.1f M rays/s" % (name, dt * 1e3, m / dt / 1e6))
