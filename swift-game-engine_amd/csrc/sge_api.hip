@@ -83,7 +83,7 @@ struct sge_context {
     int outLayoutAllocated = -1;
     // agents
     DevAgents agents{};
-    DevBuf dCellStart, dCellItems, dCellCursor, dAgentMinMax;
+    DevBuf dCellStart, dCellItems, dCellCursor, dAgentMinMax, dAgentGrid;
     // scratch for batched queries
     DevBuf dQueries, dCastOut, dOverlapOut, dCounts;
     // skinned-geometry acceleration structure (RTAccelerationBuilder.swift:75-145)
@@ -266,22 +266,45 @@ __global__ void agentBoundsKernel(const sge_agent_state* a, int n, float* mm /*m
     }
 }
 
-__device__ __forceinline__ int agentCell(const sge_agent_state& a, float ox, float oz, float inv, int nx, int nz) {
-    int cx = (int)floorf((a.position[0] - ox) * inv), cz = (int)floorf((a.position[2] - oz) * inv);
-    cx = cx < 0 ? 0 : (cx >= nx ? nx - 1 : cx);
-    cz = cz < 0 ? 0 : (cz >= nz ? nz - 1 : cz);
-    return cz * nx + cx;
+// grid parameters from the encoded bounds: one thread
+__global__ void agentGridKernel(const unsigned* enc, AgentGrid* grid) {
+    auto dec = [](unsigned u) { unsigned v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; return __uint_as_float(v); };
+    AgentGrid G{};
+    if (enc[0] != 0xffffffffu) { // at least one solid agent
+        const float minx = dec(enc[0]), minz = dec(enc[1]), maxx = dec(enc[2]), maxz = dec(enc[3]);
+        G.maxRadius = dec(enc[4]);
+        G.maxSpeed = dec(enc[5]);
+        float cell = 4.0f * (G.maxRadius > 0.25f ? G.maxRadius : 0.25f);
+        int nx = (int)((maxx - minx) / cell) + 1, nz = (int)((maxz - minz) / cell) + 1;
+        while ((long long)nx * nz > kAgentMaxCells) { cell *= 2; nx = (int)((maxx - minx) / cell) + 1; nz = (int)((maxz - minz) / cell) + 1; }
+        G.originX = minx; G.originZ = minz; G.invCell = 1.0f / cell; G.nx = nx; G.nz = nz; G.cells = nx * nz;
+    }
+    *grid = G;
 }
-__global__ void agentCountKernel(const sge_agent_state* a, int n, float ox, float oz, float inv, int nx, int nz, int* counts) {
+__device__ __forceinline__ int agentCell(const sge_agent_state& a, const AgentGrid& G) {
+    int cx = (int)floorf((a.position[0] - G.originX) * G.invCell), cz = (int)floorf((a.position[2] - G.originZ) * G.invCell);
+    cx = cx < 0 ? 0 : (cx >= G.nx ? G.nx - 1 : cx);
+    cz = cz < 0 ? 0 : (cz >= G.nz ? G.nz - 1 : cz);
+    return cz * G.nx + cx;
+}
+__global__ void agentClearKernel(const AgentGrid* grid, int* counts) {
+    const int cells = grid->cells;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += gridDim.x * blockDim.x) counts[i] = 0;
+}
+__global__ void agentCountKernel(const sge_agent_state* a, int n, const AgentGrid* grid, int* counts) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && a[i].radius >= 0) atomicAdd(&counts[agentCell(a[i], ox, oz, inv, nx, nz)], 1);
+    const AgentGrid G = *grid;
+    if (G.nx == 0) return;
+    if (i < n && a[i].radius >= 0) atomicAdd(&counts[agentCell(a[i], G)], 1);
 }
-__global__ void agentScanKernel(const int* counts, int cells, int* start, int* cursor) {
+__global__ void agentScanKernel(const int* counts, const AgentGrid* grid, int* start, int* cursor) {
     // single 1024-thread block exclusive scan (cells <= 1<<20)
     __shared__ int part[1024];
+    const int cells = grid->cells;
     int tid = threadIdx.x;
     int per = (cells + 1023) / 1024;
     int b = tid * per, e = b + per < cells ? b + per : cells;
+    if (b > cells) b = cells;
     int s = 0;
     for (int i = b; i < e; ++i) s += counts[i];
     part[tid] = s;
@@ -296,44 +319,38 @@ __global__ void agentScanKernel(const int* counts, int cells, int* start, int* c
     for (int i = b; i < e; ++i) { start[i] = run; cursor[i] = run; run += counts[i]; }
     if (tid == 1023) start[cells] = part[1023];
 }
-__global__ void agentScatterKernel(const sge_agent_state* a, int n, float ox, float oz, float inv, int nx, int nz,
-                                   int* cursor, int* items) {
+__global__ void agentScatterKernel(const sge_agent_state* a, int n, const AgentGrid* grid, int* cursor, int* items) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && a[i].radius >= 0) items[atomicAdd(&cursor[agentCell(a[i], ox, oz, inv, nx, nz)], 1)] = i;
+    const AgentGrid G = *grid;
+    if (G.nx == 0) return;
+    if (i < n && a[i].radius >= 0) items[atomicAdd(&cursor[agentCell(a[i], G)], 1)] = i;
 }
 
+// Bins the gathered agents into the XZ grid, entirely on the device and on the context's stream (sge_tick stays asynchronous):
+// bounds -> grid parameters -> count / scan / scatter. The cell arrays are sized once for the largest grid.
 int buildAgentGrid(sge_context* c) {
     DevAgents& ag = c->agents;
     if (!ag.all || ag.total <= 0) return SGE_OK;
     int rc;
     if ((rc = c->dAgentMinMax.alloc(32)) != SGE_OK) return rc;
-    const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u};
-    SGE_HIP(hipMemcpyAsync(c->dAgentMinMax.p, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-    int blocks = (ag.total + 255) / 256;
-    hipLaunchKernelGGL(agentBoundsKernel, dim3(blocks), dim3(256), 0, c->stream, ag.all, ag.total, c->dAgentMinMax.as<float>());
-    unsigned enc[6];
-    SGE_HIP(hipMemcpyAsync(enc, c->dAgentMinMax.p, sizeof(enc), hipMemcpyDeviceToHost, c->stream));
-    SGE_HIP(hipStreamSynchronize(c->stream));
-    auto dec = [](unsigned u) { unsigned v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; std::memcpy(&f, &v, 4); return f; };
-    if (enc[0] == 0xffffffffu) { ag.nx = ag.nz = 0; ag.cellStart = nullptr; return SGE_OK; } // no solid agents
-    float minx = dec(enc[0]), minz = dec(enc[1]), maxx = dec(enc[2]), maxz = dec(enc[3]);
-    ag.maxRadius = dec(enc[4]);
-    ag.maxSpeed = dec(enc[5]);
-    float cell = 4.0f * (ag.maxRadius > 0.25f ? ag.maxRadius : 0.25f);
-    int nx = (int)((maxx - minx) / cell) + 1, nz = (int)((maxz - minz) / cell) + 1;
-    while ((long long)nx * nz > (1 << 20)) { cell *= 2; nx = (int)((maxx - minx) / cell) + 1; nz = (int)((maxz - minz) / cell) + 1; }
-    ag.originX = minx; ag.originZ = minz; ag.invCell = 1.0f / cell; ag.nx = nx; ag.nz = nz;
-    int cells = nx * nz;
+    if ((rc = c->dAgentGrid.alloc(sizeof(AgentGrid))) != SGE_OK) return rc;
     // counts live in dCellCursor's tail: [cursor cells][counts cells]
-    if ((rc = c->dCellCursor.alloc((size_t)cells * 8)) != SGE_OK) return rc;
-    if ((rc = c->dCellStart.alloc((size_t)(cells + 1) * 4)) != SGE_OK) return rc;
+    if ((rc = c->dCellCursor.alloc((size_t)kAgentMaxCells * 8)) != SGE_OK) return rc;
+    if ((rc = c->dCellStart.alloc((size_t)(kAgentMaxCells + 1) * 4)) != SGE_OK) return rc;
     if ((rc = c->dCellItems.alloc((size_t)ag.total * 4)) != SGE_OK) return rc;
+    static const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u};
+    SGE_HIP(hipMemcpyAsync(c->dAgentMinMax.p, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    const int blocks = (ag.total + 255) / 256;
+    AgentGrid* grid = c->dAgentGrid.as<AgentGrid>();
     int* cursor = c->dCellCursor.as<int>();
-    int* cnt = cursor + cells;
-    SGE_HIP(hipMemsetAsync(cnt, 0, (size_t)cells * 4, c->stream));
-    hipLaunchKernelGGL(agentCountKernel, dim3(blocks), dim3(256), 0, c->stream, ag.all, ag.total, ag.originX, ag.originZ, ag.invCell, nx, nz, cnt);
-    hipLaunchKernelGGL(agentScanKernel, dim3(1), dim3(1024), 0, c->stream, cnt, cells, c->dCellStart.as<int>(), cursor);
-    hipLaunchKernelGGL(agentScatterKernel, dim3(blocks), dim3(256), 0, c->stream, ag.all, ag.total, ag.originX, ag.originZ, ag.invCell, nx, nz, cursor, c->dCellItems.as<int>());
+    int* cnt = cursor + kAgentMaxCells;
+    hipLaunchKernelGGL(agentBoundsKernel, dim3(blocks), dim3(256), 0, c->stream, ag.all, ag.total, c->dAgentMinMax.as<float>());
+    hipLaunchKernelGGL(agentGridKernel, dim3(1), dim3(1), 0, c->stream, c->dAgentMinMax.as<unsigned>(), grid);
+    hipLaunchKernelGGL(agentClearKernel, dim3(256), dim3(256), 0, c->stream, grid, cnt);
+    hipLaunchKernelGGL(agentCountKernel, dim3(blocks), dim3(256), 0, c->stream, ag.all, ag.total, grid, cnt);
+    hipLaunchKernelGGL(agentScanKernel, dim3(1), dim3(1024), 0, c->stream, cnt, grid, c->dCellStart.as<int>(), cursor);
+    hipLaunchKernelGGL(agentScatterKernel, dim3(blocks), dim3(256), 0, c->stream, ag.all, ag.total, grid, cursor, c->dCellItems.as<int>());
+    ag.grid = grid;
     ag.cellStart = c->dCellStart.as<int>();
     ag.cellItems = c->dCellItems.as<int>();
     return SGE_OK;
@@ -384,7 +401,7 @@ void sge_context_destroy(sge_context* c) {
                       &c->dCoeffs, &c->dCoeffCount, &c->dBonePresent, &c->dMeshPos, &c->dMeshNrm, &c->dMeshTan, &c->dMeshIdx, &c->dMeshWgt,
                       &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dSlotOfRank, &c->dCost, &c->dHint, &c->dHeavyFlags, &c->dJobTable, &c->dBlockJob, &c->dLists, &c->dListCounts, &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
                       &c->dPalettes, &c->dPoseModel, &c->dPoseLocal, &c->dMoveScratch, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
-                      &c->dCellCursor, &c->dAgentMinMax, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats,
+                      &c->dCellCursor, &c->dAgentMinMax, &c->dAgentGrid, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats,
                       &c->dBlasEntryLink, &c->dBlasWideFirst, &c->dBlasWideParent, &c->dBlasWideLevel, &c->dBlasSlotIdx, &c->dBlasSlotTri,
                       &c->dBlasIndices, &c->dBlasBounds, &c->dBlasInstances, &c->dBlasRays, &c->dBlasHits, &c->dBlasTileStart,
                       &c->dBlasRoundLen, &c->dBlasRoundCluster, &c->dBlasRoundIds, &c->dBlasWorldBoxes, &c->dBlasUVs};
@@ -1041,7 +1058,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
                      c->dStats.as<unsigned long long>(), c->dMoveScratch.p, c->dPlatforms.as<sge_platform_state>(), c->platformCount,
                      c->dCost.as<int>(), c->dHint.as<uint8_t>(), c->heavyThreshold >= 0 ? c->dLists.as<int>() : nullptr, c->dListCounts.as<int>(), c->dHeavyFlags.as<uint8_t>(),
                      c->heavyThreshold, 2048, c->heavyStream, c->evClassified, c->evHeavyDone, nullptr, nullptr};
-        if (!(st & SGE_STAGE_AGENTS) || c->agents.nx == 0) L.agents.all = nullptr;
+        if (!(st & SGE_STAGE_AGENTS) || !c->agents.grid) L.agents.all = nullptr;
         Bracket br(c, &c->evMove);
         launch_move(L, c->stream);
     }

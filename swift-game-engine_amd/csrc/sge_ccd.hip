@@ -798,22 +798,24 @@ __device__ __forceinline__ bool capsuleCapsuleSweep(F3 from, F3 delta, float rad
 // `<` over its (index-ordered) snapshot.
 __device__ __forceinline__ bool waveAgentBestHit(const DevAgents& ag, F3 position, F3 remaining, float remainingLen,
                                               float baseMoveLen, float dt, int selfIndex, float selfRadius,
-                                              float halfHeight, float maxAgentRadius, float maxAgentSpeed,
-                                              float& toiOut, F3& normalOut) {
+                                              float halfHeight, float& toiOut, F3& normalOut) {
     const int lane = laneId();
+    const AgentGrid G = *ag.grid; // wave-uniform
+    if (G.nx == 0) return false;  // no solid agent in the snapshot
+    const float maxAgentRadius = G.maxRadius, maxAgentSpeed = G.maxSpeed;
     float timeScale = baseMoveLen > 1e-6f ? smin(remainingLen / baseMoveLen, 1.0f) : 1.0f;
     float segmentDt = dt * timeScale;
     // conservative XZ reach: own move + the fastest other agent's move + both radii
     float reach = remainingLen + maxAgentSpeed * segmentDt + selfRadius + maxAgentRadius + 1e-3f;
-    int cx0 = (int)floorf((position.x - reach - ag.originX) * ag.invCell), cx1 = (int)floorf((position.x + reach - ag.originX) * ag.invCell);
-    int cz0 = (int)floorf((position.z - reach - ag.originZ) * ag.invCell), cz1 = (int)floorf((position.z + reach - ag.originZ) * ag.invCell);
+    int cx0 = (int)floorf((position.x - reach - G.originX) * G.invCell), cx1 = (int)floorf((position.x + reach - G.originX) * G.invCell);
+    int cz0 = (int)floorf((position.z - reach - G.originZ) * G.invCell), cz1 = (int)floorf((position.z + reach - G.originZ) * G.invCell);
     cx0 = cx0 < 0 ? 0 : cx0; cz0 = cz0 < 0 ? 0 : cz0;
-    cx1 = cx1 >= ag.nx ? ag.nx - 1 : cx1; cz1 = cz1 >= ag.nz ? ag.nz - 1 : cz1;
+    cx1 = cx1 >= G.nx ? G.nx - 1 : cx1; cz1 = cz1 >= G.nz ? G.nz - 1 : cz1;
     unsigned long long bestKey = ~0ull;
     F3 bestN{0, 0, 0};
     for (int cz = cz0; cz <= cz1; ++cz) {
         // cells of one row are contiguous in cellStart: scan [start(cx0), start(cx1+1))
-        int s = ag.cellStart[cz * ag.nx + cx0], e = ag.cellStart[cz * ag.nx + cx1 + 1];
+        int s = ag.cellStart[cz * G.nx + cx0], e = ag.cellStart[cz * G.nx + cx1 + 1];
         for (int base = s; base < e; base += kWave) {
             int j = base + lane;
             unsigned long long key = ~0ull;
@@ -1514,7 +1516,7 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? 4 
                 const float selfRadius = (hasAgent && (P.agentFlags & SGE_AGENT_RADIUS_OVERRIDE)) ? P.agentRadiusOverride : P.radius;
                 float aToi = 0; F3 aNormal{0, 0, 0};
                 bool have = waveAgentBestHit(K.agents, ms.position, remaining, length(remaining), ms.baseMoveLen, dt, K.agents.selfOffset + e,
-                                             selfRadius, P.halfHeight, K.agents.maxRadius, K.agents.maxSpeed, aToi, aNormal);
+                                             selfRadius, P.halfHeight, aToi, aNormal);
                 ms.aHave = have ? 1 : 0; ms.aToi = aToi; ms.aNormal = aNormal;
             }
             consumeSlide();

@@ -111,15 +111,22 @@ struct DevMesh {
     const float* boneWeights;     // [V][4]
 };
 
+// parameters of the agent grid, computed ON THE DEVICE every step (no host round trip inside sge_tick)
+struct AgentGrid {
+    float originX, originZ, invCell;
+    int nx, nz;                 // nx == 0: no solid agent in the snapshot
+    float maxRadius, maxSpeed;  // over the solid agents of the snapshot (bounds the XZ reach of a sweep)
+    int cells;
+};
+constexpr int kAgentMaxCells = 1 << 20;
+
 struct DevAgents {
     const sge_agent_state* all; // gathered snapshot
     int total, selfOffset;
     // uniform XZ grid over the snapshot
+    const AgentGrid* grid;      // device
     const int32_t* cellStart;   // [cells+1]
     const int32_t* cellItems;   // [total] agent indices sorted by cell
-    float originX, originZ, invCell;
-    int nx, nz;
-    float maxRadius, maxSpeed;  // over the solid agents of the snapshot (bounds the XZ reach of a sweep)
 };
 
 // ---- host-side collision build (sge_host.cpp) ---------------------------- //
