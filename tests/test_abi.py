@@ -54,7 +54,9 @@ def test_struct_layouts_match_the_header(sge, tmp_path):
              "sge_capsule_query": sge.abi.CapsuleQuery, "sge_capsule_cast_hit": sge.abi.CapsuleCastHit,
              "sge_capsule_overlap_hit": sge.abi.CapsuleOverlapHit, "sge_tick_desc": sge.abi.TickDesc,
              "sge_agent_state": sge.abi.AgentState, "sge_stage_times": sge.abi.StageTimes,
-             "sge_move_stats": sge.abi.MoveStats, "sge_surface_material": sge.abi.SurfaceMaterial}
+             "sge_move_stats": sge.abi.MoveStats, "sge_surface_material": sge.abi.SurfaceMaterial,
+             "sge_blas_info": sge.abi.BlasInfo, "sge_blas_ray": sge.abi.BlasRay, "sge_blas_hit": sge.abi.BlasHit,
+             "sge_ray_query": sge.abi.RayQuery, "sge_raycast_hit": sge.abi.RaycastHit, "sge_platform_state": sge.abi.PlatformState}
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "sge_amd.h"\nint main(void){' +
                    "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}\n")
