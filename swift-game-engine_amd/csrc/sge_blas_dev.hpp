@@ -79,12 +79,11 @@ __device__ __forceinline__ void blasFinishCharacter(const DevBlas& B, float* tab
         }
     }
     __syncthreads();
-    for (int i = tid; i < rows * 6; i += threads) {
+    for (int i = tid; i < rows * 6; i += threads) { // every table element is read by exactly one thread, which re-initialises it
         const int row = i / 6, q = i - row * 6;
         out[i] = tab[q * rows + row];
+        tab[q * rows + row] = q < 3 ? inf : -inf;
     }
-    __syncthreads();
-    blasTableInit(tab, rows, tid, threads);
 }
 
 } // namespace sge
