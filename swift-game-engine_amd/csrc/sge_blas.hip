@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, 
         const int rEnd = trs[tile + 1];
         int r = trs[tile] + wave;
         BlasRound R;
-        blasFetchRound(B, r, lastRound, lane, R);
+        if (r < rEnd) blasFetchRound(B, r, lastRound, lane, R); // wave-uniform; a wavefront without a round in this tile loads nothing
         // the next step: this character's next tile, or the next character's first
         const bool last = done + 1 == n;
         const int cNext = last ? c + (int)gridDim.x : c;

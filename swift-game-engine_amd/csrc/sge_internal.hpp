@@ -193,7 +193,10 @@ struct DevBlas {
     const int* roundCluster;
     const uint32_t* roundIds;
 };
-constexpr int kBlasRefitBlock = 512;
+#ifndef SGE_BLAS_BLOCK
+#define SGE_BLAS_BLOCK 512
+#endif
+constexpr int kBlasRefitBlock = SGE_BLAS_BLOCK;
 constexpr int kBlasTileVerts = 4096; // most vertices staged in LDS at a time (48 KB): kBlasRefitBlock threads x 8
 // LDS capacity of the tile: the largest of these that lets three workgroups share a CU's 160 KB beside their box tables,
 // else 4096 with two (HostBlas::build picks; the kernel is instantiated per capacity)
