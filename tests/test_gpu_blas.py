@@ -146,11 +146,12 @@ def _rays_at(rng, lo, hi, k):
     return origins.astype(np.float32), dirs.astype(np.float32)
 
 
-@pytest.mark.parametrize("real", [False, True])
-def test_closest_hit_matches_the_triangle_scan(sge, real):
+@pytest.mark.parametrize("real,layout", [(False, "packed"), (True, "packed"), (False, "padded16")])
+def test_closest_hit_matches_the_triangle_scan(sge, real, layout):
     gpu, cpu = sge.CharacterEngine(0), ob.oracle_engine()
     try:
         n = 4
+        gpu.set_option(sge.abi.OPT_SKIN_LAYOUT, sge.abi.LAYOUT_PADDED16 if layout == "padded16" else sge.abi.LAYOUT_PACKED)
         for e in (gpu, cpu):
             _scene(sge, e, n, real, mixed=True, seed=5)
             e.blas_build(e.mesh["indices"])
