@@ -8,10 +8,14 @@ A "step" is one fixed step (dt = 1/60) of the whole hot path over one batch of s
 characters already resident in HBM: intent -> gravity -> capsule-CCD move-and-slide ->
 locomotion -> action -> pose + palette -> 4-weight LBS of every vertex.
 Workload (BASELINE.json configs[2]): 10,000 Y-Bot clones per GPU
-(65 bones, 14,080 skinned vertices each) against a 71,680-triangle static mesh; characters
-shard by index across GPUs with no data-path collective ("weak" scaling: per-GPU work fixed).
-`--workload lbs` is configs[1] (pose + LBS only), `--workload agents` is configs[4]'s
+(65 bones, 14,080 skinned vertices each) against the 17-Cheese triangle mesh (71,680 triangles,
+FBX-derived, tests/golden/cheese_static.npz, used directly as the collision mesh:
+`collisionMesh ?? mesh`, CollisionQuery.swift:344); characters shard by index across GPUs with
+no data-path collective ("weak" scaling: per-GPU work fixed).
+`--workload lbs` is configs[1] (pose + LBS only), `--workload mixed` configs[3]'s mixed-motion
+crowd (default scene: the merged cheese + mirror + semla), `--workload agents` is configs[4]'s
 character-vs-character exchange (one RCCL all-gather of capsule state per step).
+`--scene` and `--mesh` choose the static scene and the skinned mesh independently.
 
 Rank 0 prints ONE JSON line. `roofline` prices the LBS kernel (the HBM-bound kernel of the
 path) from HIP events recorded on the stream it runs on; `cpu_baseline` times the CPU oracle
@@ -39,8 +43,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--chars", type=int, default=10000, help="characters per GPU")
     ap.add_argument("--workload", choices=["ccd", "lbs", "agents", "mixed"], default="ccd")
-    ap.add_argument("--assets", choices=["synthetic", "real"], default="synthetic",
-                    help="real: the FBX-derived Y-Bot (35,440 vertices) and 17-Cheese / merged static scene from tests/golden/")
+    ap.add_argument("--scene", choices=["cheese", "merged", "synthetic"], default=None,
+                    help="static collision scene: cheese = 17-Cheese (71,680 tris + ground quad, the mesh configs[2] names; default), "
+                         "merged = cheese + ornate mirror + semla (135,928 tris + ground quad; default of --workload mixed), "
+                         "synthetic = a 71,680-triangle height field")
+    ap.add_argument("--mesh", choices=["synthetic", "ybot"], default=None,
+                    help="skinned mesh: synthetic = 14,080 vertices around the real Y-Bot skeleton (BASELINE's '~14k verts'; default), "
+                         "ybot = the FBX-derived Y-Bot (35,440 welded vertices)")
+    ap.add_argument("--assets", choices=["synthetic", "real"], default=None,
+                    help="shorthand of round 1: real = --mesh ybot with the cheese / merged scene, synthetic = --mesh synthetic --scene synthetic")
     ap.add_argument("--layout", choices=["packed", "padded16"], default="packed")
     ap.add_argument("--overlap", action="store_true", help="skin(n) on a second stream, overlapping move(n+1)")
     ap.add_argument("--refit", action="store_true",
@@ -53,6 +64,12 @@ def main():
     ap.add_argument("--cpu-sample-chars", type=int, default=2048)
     ap.add_argument("--cpu-sample-steps", type=int, default=16)
     args = ap.parse_args()
+    if args.assets == "real":
+        args.mesh = args.mesh or "ybot"
+    elif args.assets == "synthetic":
+        args.mesh, args.scene = args.mesh or "synthetic", args.scene or "synthetic"
+    args.mesh = args.mesh or "synthetic"
+    args.scene = args.scene or ("merged" if args.workload == "mixed" else "cheese")
 
     import numpy as np
     import torch
@@ -142,6 +159,10 @@ def main():
     eng.set_option(abi.OPT_PROFILE, 0)
 
     V, B = eng.vertex_count, eng.bone_count
+    tris = int(eng.collision_counts()[1])
+    scene_label = {"cheese": f"the 17-Cheese triangle mesh ({tris:,} triangles incl. the 2-triangle ground quad)",
+                   "merged": f"the merged static scene: cheese + ornate mirror + semla ({tris:,} triangles incl. the ground quad)",
+                   "synthetic": f"a synthetic height-field mesh ({tris:,} triangles)"}[args.scene]
     # ALGORITHMIC bytes of one LBS launch: per character 40*V written, 4160 B palette read,
     # source streams 64*V read once per launch (shared by all clones of the mesh)
     lbs_bytes = count * (40.0 * V + B * 64.0) + 64.0 * V
@@ -161,15 +182,19 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic" if args.assets == "synthetic" else "synthetic crowd state over FBX-derived assets (tests/golden/)",
+        "data": "synthetic crowd state; " + {"synthetic": "synthetic 14,080-vertex skinned mesh on the real Y-Bot skeleton and motion profiles",
+                                              "ybot": "FBX-derived Y-Bot skinned mesh"}[args.mesh]
+                + ("" if mode == "lbs" else "; " + {"cheese": "FBX-derived 17-Cheese static mesh", "merged": "FBX-derived cheese + ornate mirror + semla static meshes",
+                                                    "synthetic": "synthetic height-field static mesh"}[args.scene]) + " (tests/golden/)",
         "config": {
-            "workload": {"ccd": "configs[2]: 10k Y-Bot clones/GPU, pose + LBS + capsule-CCD vs 71,680-tri static mesh",
-                         "lbs": "configs[1]: 10k Y-Bot clones/GPU, Running profile, pose + LBS only",
-                         "agents": "configs[4]-style: configs[2] + character-vs-character sweeps, RCCL all-gather of capsule state",
-                         "mixed": "configs[3]-style: mixed-motion Y-Bots (idle/walk/run/falling, 10% mid-blend) vs the merged static scene"}[args.workload],
-            "assets": args.assets,
+            "workload": {"ccd": "configs[2]: 10k Y-Bot clones/GPU, pose + LBS + capsule-CCD vs " + scene_label,
+                         "lbs": "configs[1]: 10k Y-Bot clones/GPU, Running profile, pose + LBS only (no collision)",
+                         "agents": "configs[4]-style: character-vs-character sweeps (RCCL all-gather of capsule state) + pose + LBS + capsule-CCD vs " + scene_label,
+                         "mixed": "configs[3]-style: mixed-motion Y-Bots (idle/walk/run/falling, 10% mid-blend) vs " + scene_label}[args.workload],
+            "scene": args.scene if mode != "lbs" else None, "mesh": args.mesh,
+            "scene_scale": terrain.get("scales") if mode != "lbs" else None,
             "characters_per_gpu": args.chars, "characters_total": n_total, "bones": B, "vertices_per_character": V,
-            "static_triangles": int(eng.collision_counts()[1]), "dt": 1.0 / 60.0, "sharding": f"by-character x{world}",
+            "static_triangles": tris, "dt": 1.0 / 60.0, "sharding": f"by-character x{world}",
             "skin_layout": args.layout, "overlap_skin_with_next_move": bool(args.overlap), "settle_steps": SETTLE_STEPS if mode == "ccd" else 0, "seed": 1234,
         },
         "roofline": {"bound": "hbm", "kernel": "skin_kernel (4-weight LBS)", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -218,12 +243,18 @@ def main():
 
 def _build_world(sge, e, ybot, args):
     """Character assets + static scene, identical for the GPU context and the CPU-baseline oracle."""
-    if args.assets == "real":
-        sge.crowd.upload_ybot_mesh(e, ybot)  # Y Bot.fbx: 35,440 welded vertices, 65 bones, mesh inverse-bind re-bind
-        which = ("cheese", "mirror", "semla") if args.workload == "mixed" else ("cheese",)
-        return sge.crowd.upload_asset_scene(e, which)  # 71,680 (+2 ground) or 135,928 (+2) triangles
-    sge.crowd.upload_character_assets(e, ybot)  # 22 x 10 vertices on 64 bones = 14,080
-    return sge.crowd.upload_terrain(e)          # 224 x 160 x 2 = 71,680 triangles
+    if args.mesh == "ybot":
+        sge.crowd.upload_ybot_mesh(e, ybot)      # Y Bot.fbx: 35,440 welded vertices, 65 bones, mesh inverse-bind re-bind
+    else:
+        sge.crowd.upload_character_assets(e, ybot)  # 22 x 10 vertices on 64 bones = 14,080
+    if args.scene == "synthetic":
+        return sge.crowd.upload_terrain(e)       # 224 x 160 x 2 = 71,680 triangles
+    # the props are modelled for one character (the cheese is 3.7 units long): crowd.asset_scene_entities scales each to a
+    # 200-unit footprint (the factor is reported as config.scene_scale) and lays them over the demo's ground quad
+    which = ("cheese", "mirror", "semla") if args.scene == "merged" else ("cheese",)
+    scene = sge.crowd.upload_asset_scene(e, which)  # 71,680 (+2 ground) or 135,928 (+2) triangles
+    scene["scales"] = {b["name"]: round(b["scale"], 4) for b in scene["bounds"]}
+    return scene
 
 
 def _spawn_block(sge, eng, ybot, n_total, first, count, terrain, mode, agents, mixed=False):
@@ -245,12 +276,22 @@ def _spawn_block(sge, eng, ybot, n_total, first, count, terrain, mode, agents, m
     return block
 
 
+def skin_source_hash():
+    """Identifies the LBS kernel a PMC record was taken from (sge_skin.hip + the layouts it includes)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("sge_skin.hip", "sge_internal.hpp", "sge_blas_dev.hpp"):
+        h.update(open(os.path.join(ROOT, "swift-game-engine_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _recorded_traffic(count, V):
-    """HBM bytes per LBS launch from the committed rocprofv3 --pmc pass, if it matches this shape."""
+    """HBM bytes per LBS launch from the committed rocprofv3 --pmc passes (tools/collect_profiles.sh writes the record).
+    Only a record taken from THIS kernel source and this shape counts; anything else reports null."""
     path = os.path.join(ROOT, "profiles", "lbs_traffic.json")
     try:
         rec = json.load(open(path))
-        if rec.get("characters") == count and rec.get("vertices") == V:
+        if rec.get("characters") == count and rec.get("vertices") == V and rec.get("skin_source_hash") == skin_source_hash():
             return rec["hbm_bytes_per_launch"]
     except Exception:
         pass

@@ -573,6 +573,7 @@ typedef struct sge_move_stats {
     uint64_t overflow;         /* traversal-stack or candidate overflows (must stay 0) */
     uint64_t traversalSteps;   /* wave-wide node-expansion steps */
     uint64_t sweepTrips;       /* wave-wide trips of the sweep loop (one distance evaluation per active lane each) */
+    uint64_t prunedPairs;      /* (cast, triangle) pairs of vertical casts skipped by the conservative XZ reject (no result changes) */
 } sge_move_stats;
 int sge_move_stats_read(sge_context* ctx, sge_move_stats* out, int reset);
 

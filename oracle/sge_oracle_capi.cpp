@@ -410,6 +410,7 @@ int sgeo_move_stats_read(sgeo_world* h, sge_move_stats* out, int reset) {
     out->overflow = 0;
     out->traversalSteps = 0;
     out->sweepTrips = 0;
+    out->prunedPairs = 0;
     if (reset) h->stats = QueryStats();
     return SGE_OK;
 }

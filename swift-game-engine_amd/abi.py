@@ -182,7 +182,7 @@ class StageTimes(C.Structure):
 
 class MoveStats(C.Structure):
     _fields_ = [("queries", u64), ("candidates", u64), ("sweepIterations", u64), ("overflow", u64),
-                ("traversalSteps", u64), ("sweepTrips", u64)]
+                ("traversalSteps", u64), ("sweepTrips", u64), ("prunedPairs", u64)]
 
 
 # sizes the C side static_asserts as well

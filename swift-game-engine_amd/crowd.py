@@ -99,7 +99,7 @@ def asset_scene_entities(which=("cheese",), footprint=200.0, gap=30.0, ground=Tr
                      translation=(t["translation"] * scale + shift).astype(np.float32))
             entities.append({"positions": part["positions"], "indices": part["indices"], "modelMatrix": F.model_matrix(t),
                              "material": (0.6, 0.5, 0), "layer": 1 << layer_bit, "name": "%s:%s" % (name, part["name"])})
-        bounds.append({"name": name, "lo": lo * scale + shift, "hi": hi * scale + shift})
+        bounds.append({"name": name, "lo": lo * scale + shift, "hi": hi * scale + shift, "scale": float(scale)})
         cursor += width + gap
     if ground:
         total = cursor - gap

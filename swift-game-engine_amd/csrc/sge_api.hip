@@ -1316,11 +1316,11 @@ int sge_move_stats_read(sge_context* c, sge_move_stats* out, int reset) {
     std::vector<unsigned long long> shards((size_t)kStatShards * 8);
     SGE_HIP(hipMemcpyAsync(shards.data(), c->dStats.p, shards.size() * 8, hipMemcpyDeviceToHost, c->stream));
     SGE_HIP(hipStreamSynchronize(c->stream));
-    unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long h[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int sdx = 0; sdx < kStatShards; ++sdx)
-        for (int k = 0; k < 6; ++k) h[k] += shards[(size_t)sdx * 8 + k];
+        for (int k = 0; k < 7; ++k) h[k] += shards[(size_t)sdx * 8 + k];
     out->queries = h[0]; out->candidates = h[1]; out->sweepIterations = h[2]; out->overflow = h[3];
-    out->traversalSteps = h[4]; out->sweepTrips = h[5];
+    out->traversalSteps = h[4]; out->sweepTrips = h[5]; out->prunedPairs = h[6];
     if (reset) { SGE_HIP(hipMemsetAsync(c->dStats.p, 0, (size_t)kStatShards * 64, c->stream)); SGE_HIP(hipStreamSynchronize(c->stream)); }
     return SGE_OK;
 }

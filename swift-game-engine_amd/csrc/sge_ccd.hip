@@ -52,13 +52,14 @@ struct WaveShared {
     F3 rayFrom[kMaxRays], rayDelta[kMaxRays], rayDir[kMaxRays], rayMin[kMaxRays], rayMax[kMaxRays];
     float rayLen[kMaxRays];
     int rayMaxIter[kMaxRays], rayValid[kMaxRays];
+    int rayVertical[kMaxRays];  // delta = (0, dy, 0): the ground probe's casts (verticalSweepMisses)
     unsigned long long rayKey[kMaxRays]; // (toi bits << 32) | visit rank of the best accepted hit so far
     CastRec rayRec[kMaxRays];
     OverlapRec ovl[SGE_MAX_OVERLAP_HITS];
     OverlapRec ovlTmp[SGE_MAX_OVERLAP_HITS];
 };
 
-struct WaveStats { unsigned int queries, candidates, evals, overflow, steps, trips; };
+struct WaveStats { unsigned int queries, candidates, evals, overflow, steps, trips, pruned; };
 // The counters are sharded over kStatShards cache lines (8 x u64 each): thousands of waves adding to ONE line
 // serialise at ~11 ns per atomic on this chip, which would cost more than the collision work itself.
 __device__ __forceinline__ unsigned long long* statShard(unsigned long long* stats) {
@@ -158,6 +159,35 @@ __device__ __forceinline__ void expandNodes(const DevCollision& col, F3 minP, F3
 __device__ __forceinline__ int initTraversal(const DevCollision& col) {
     if (laneId() == 0) { sh.stack[0] = 0; sh.stack[1] = col.dynWide; }
     return col.dynWide >= 0 ? 2 : 1;
+}
+
+// Conservative reject for a VERTICAL sweep (delta = (0, dy, 0), the ground probe's snap / fall / offset casts, Systems.swift:844-921).
+// center = from + dir * t keeps x and z exactly, so at every t of the march the capsule axis lies on the vertical line through
+// (px, pz) and its distance to the triangle is at least the XZ-plane distance from (px, pz) to the triangle's projection. When that
+// 2-D distance exceeds radius + contactEps by a margin that covers the rounding of both computations, no evaluation of
+// sweepCapsuleTriangle (CollisionQuery.swift:1303-1322) can report contact: the reference marches such a triangle to `t > maxDistance`
+// or to its iteration cap and returns nil. Skipping it changes no result — and it is what a capsule falling beside a wall is made
+// of: hundreds of near-vertical triangles a skin width away that each crawl through up to 256 advancement steps.
+// No division: an edge's distance test is cross^2 > R^2 |e|^2. A point inside the projection (or a projection that degenerates to a
+// line through the point) is never rejected.
+__device__ __forceinline__ bool edgeFarXZ(float px, float pz, float ax, float az, float bx, float bz, float R2, float& crossOut) {
+    const float ex = bx - ax, ez = bz - az, wx = px - ax, wz = pz - az;
+    const float c1 = wx * ex + wz * ez, c2 = ex * ex + ez * ez;
+    const float cr = ex * wz - ez * wx;
+    crossOut = cr;
+    const float ux = px - bx, uz = pz - bz;
+    const float dv = c1 <= 0 ? wx * wx + wz * wz : ux * ux + uz * uz;   // nearest end point
+    return (c1 <= 0 || c1 >= c2) ? dv > R2 : cr * cr > R2 * c2;
+}
+__device__ __forceinline__ bool verticalSweepMisses(float px, float pz, float radius, F3 v0, F3 v1, F3 v2) {
+    const float R = radius + 1e-5f + (0.01f + 4e-5f * (fabsf(px) + fabsf(pz)));
+    const float R2 = R * R;
+    float k0, k1, k2;
+    const bool f0 = edgeFarXZ(px, pz, v0.x, v0.z, v1.x, v1.z, R2, k0);
+    const bool f1 = edgeFarXZ(px, pz, v1.x, v1.z, v2.x, v2.z, R2, k1);
+    const bool f2 = edgeFarXZ(px, pz, v2.x, v2.z, v0.x, v0.z, R2, k2);
+    const bool inside = (k0 >= 0 && k1 >= 0 && k2 >= 0) || (k0 <= 0 && k1 <= 0 && k2 <= 0);
+    return f0 && f1 && f2 && !inside;
 }
 
 struct Tri { F3 v0, v1, v2; int triIndex, rank; };
@@ -334,6 +364,7 @@ __device__ __forceinline__ void waveCastRays(const DevCollision& col, float radi
         F3 ext{radius, radius, radius};
         sh.rayMin[lane] = minP - ext; sh.rayMax[lane] = maxP + ext;
         sh.rayDir[lane] = dir; sh.rayLen[lane] = len; sh.rayValid[lane] = valid ? 1 : 0;
+        sh.rayVertical[lane] = (delta.x == 0.0f && delta.z == 0.0f) ? 1 : 0;
         const float minAdv = smax(radius * 0.02f, 1e-4f);
         int maxIter = (int)ceilf(len / minAdv) + 1; // :1296
         sh.rayMaxIter[lane] = maxIter < 256 ? maxIter : 256;
@@ -372,16 +403,17 @@ __device__ __forceinline__ void waveCastRays(const DevCollision& col, float radi
                 candCount -= n;
                 st.candidates += n;
                 int slot = -1;
-                F3 bmin{0, 0, 0}, bmax{0, 0, 0};
+                F3 v0{0, 0, 0}, v1{0, 0, 0}, v2{0, 0, 0};
                 if (lane < n) {
                     slot = sh.cand[candCount + lane];
                     const float4* tp = reinterpret_cast<const float4*>(col.tris + slot);
                     float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
-                    F3 v0{t0.x, t0.y, t0.z}, v1{t0.w, t1.x, t1.y}, v2{t1.z, t1.w, t2.x};
-                    bmin = vmin(v0, vmin(v1, v2)); bmax = vmax(v0, vmax(v1, v2));
+                    v0 = F3{t0.x, t0.y, t0.z}; v1 = F3{t0.w, t1.x, t1.y}; v2 = F3{t1.z, t1.w, t2.x};
                 }
+                const F3 bmin = vmin(v0, vmin(v1, v2)), bmax = vmax(v0, vmax(v1, v2));
                 for (int r = 0; r < R; ++r) {
                     bool c = slot >= 0 && sh.rayValid[r] && !boxDisjoint(bmin, bmax, sh.rayMin[r], sh.rayMax[r]);
+                    if (c && sh.rayVertical[r]) { c = !verticalSweepMisses(sh.rayFrom[r].x, sh.rayFrom[r].z, radius, v0, v1, v2); st.pruned += c ? 0 : 1; }
                     unsigned long long mc = __ballot(c);
                     if (c) hv.items[hCount + prefixCount(mc)] = (r << 28) | slot;
                     hCount += __popcll(mc);
@@ -442,16 +474,17 @@ __device__ __forceinline__ void waveCastRays(const DevCollision& col, float radi
             candCount -= n;
             st.candidates += n;
             int slot = -1;
-            F3 bmin{0, 0, 0}, bmax{0, 0, 0};
+            F3 v0{0, 0, 0}, v1{0, 0, 0}, v2{0, 0, 0};
             if (lane < n) {
                 slot = sh.cand[candCount + lane];
                 const float4* tp = reinterpret_cast<const float4*>(col.tris + slot);
                 float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
-                F3 v0{t0.x, t0.y, t0.z}, v1{t0.w, t1.x, t1.y}, v2{t1.z, t1.w, t2.x};
-                bmin = vmin(v0, vmin(v1, v2)); bmax = vmax(v0, vmax(v1, v2));
+                v0 = F3{t0.x, t0.y, t0.z}; v1 = F3{t0.w, t1.x, t1.y}; v2 = F3{t1.z, t1.w, t2.x};
             }
+            const F3 bmin = vmin(v0, vmin(v1, v2)), bmax = vmax(v0, vmax(v1, v2));
             for (int r = 0; r < R; ++r) {
                 bool c = slot >= 0 && sh.rayValid[r] && !boxDisjoint(bmin, bmax, sh.rayMin[r], sh.rayMax[r]);
+                if (c && sh.rayVertical[r]) { c = !verticalSweepMisses(sh.rayFrom[r].x, sh.rayFrom[r].z, radius, v0, v1, v2); st.pruned += c ? 0 : 1; }
                 unsigned long long mc = __ballot(c);
                 if (c) sh.items[itemCount + prefixCount(mc)] = (r << 28) | slot;
                 itemCount += __popcll(mc);
@@ -811,6 +844,9 @@ __device__ __forceinline__ bool waveAgentBestHit(const DevAgents& ag, F3 positio
     int cz0 = (int)floorf((position.z - reach - G.originZ) * G.invCell), cz1 = (int)floorf((position.z + reach - G.originZ) * G.invCell);
     cx0 = cx0 < 0 ? 0 : cx0; cz0 = cz0 < 0 ? 0 : cz0;
     cx1 = cx1 >= G.nx ? G.nx - 1 : cx1; cz1 = cz1 >= G.nz ? G.nz - 1 : cz1;
+    // a character carried or pushed beyond the snapshot's bounds by more than its reach meets nobody (and must not index
+    // cellStart past the grid)
+    if (cx0 > cx1 || cz0 > cz1) return false;
     unsigned long long bestKey = ~0ull;
     F3 bestN{0, 0, 0};
     for (int cz = cz0; cz <= cz1; ++cz) {
@@ -1354,7 +1390,7 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? 4 
     const int e = (PART == 1 && K.list) ? K.list[blockIdx.x] : K.first + xcdRemap((int)blockIdx.x, K.count);
     if (PART == 1 && !K.list && K.heavyFlags && K.heavyFlags[e]) return; // this character runs in the multi-wave launch
     const int lane = laneId();
-    WaveStats st{0, 0, 0, 0, 0, 0};
+    WaveStats st{0, 0, 0, 0, 0, 0, 0};
     const DevCollision& col = K.col;
     if (HEAVY) {
         if (threadIdx.x == 0) { hv.cmd = HCMD_NONE; hv.evalSum = 0; }
@@ -1560,9 +1596,10 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? 4 
     }
     if (K.stats) {
         // evals are counted per lane; sum over the wave
-        unsigned v = st.evals;
+        unsigned v = st.evals, pr = st.pruned; // per-lane counts
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+        for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o, kWave); pr += __shfl_xor(pr, o, kWave); }
+        (void)pr;
         if (lane == 0) {
             unsigned long long* sp = statShard(K.stats);
             if (st.queries) atomicAdd(&sp[0], (unsigned long long)st.queries);
@@ -1575,6 +1612,7 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? 4 
             if (v) atomicAdd(&sp[2], (unsigned long long)v);
             if (st.steps) atomicAdd(&sp[4], (unsigned long long)st.steps);
             if (st.trips) atomicAdd(&sp[5], (unsigned long long)st.trips);
+            if (pr) atomicAdd(&sp[6], (unsigned long long)pr);
 #endif
         }
     }
@@ -1630,7 +1668,7 @@ void launch_move(const MoveLaunch& L, hipStream_t s) {
 __global__ __launch_bounds__(kWave, 3) void cast_query_kernel(DevCollision col, const sge_capsule_query* q, int n,
                                                            sge_capsule_cast_hit* out, unsigned long long* stats) {
     const int i = blockIdx.x;
-    WaveStats st{0, 0, 0, 0, 0, 0};
+    WaveStats st{0, 0, 0, 0, 0, 0, 0};
     sge_capsule_query Q = q[i];
     sh.rayCount = 1;
     sh.rayFrom[0] = F3{Q.from[0], Q.from[1], Q.from[2]};
@@ -1666,7 +1704,7 @@ __global__ __launch_bounds__(kWave, 3) void overlap_query_kernel(DevCollision co
                                                               unsigned long long* stats) {
     const int i = blockIdx.x;
     const int lane = laneId();
-    WaveStats st{0, 0, 0, 0, 0, 0};
+    WaveStats st{0, 0, 0, 0, 0, 0, 0};
     sge_capsule_query Q = q[i];
     int cnt = waveCapsuleOverlapAll(col, F3{Q.from[0], Q.from[1], Q.from[2]}, Q.radius, Q.halfHeight, maxHits, Q.mask, st);
     if (lane < maxHits) {
@@ -1700,7 +1738,7 @@ __global__ __launch_bounds__(kWave, 3) void overlap_deepest_kernel(DevCollision 
                                                                    unsigned long long* stats) {
     const int i = blockIdx.x;
     const int lane = laneId();
-    WaveStats st{0, 0, 0, 0, 0, 0};
+    WaveStats st{0, 0, 0, 0, 0, 0, 0};
     const sge_capsule_query Q = q[i];
     const F3 from{Q.from[0], Q.from[1], Q.from[2]};
     unsigned long long bestKey = ~0ull; // (~depth bits << 32) | rank: deeper first, then earlier visit

@@ -35,6 +35,9 @@ class _ProductTable:
     def last_error(self):
         return (self.lib.sge_last_error() or b"").decode()
 
+    def skinning_encode(self, handle, out_positions, out_normals, out_tangents, out_layout, jobs, count):
+        return self.lib.sge_skinning_encode(handle, out_positions, out_normals, out_tangents, out_layout, jobs, count)
+
     def close(self):
         if self.handle:
             self.lib.sge_context_destroy(self.handle)
@@ -167,12 +170,9 @@ class CharacterEngine:
             arr[k] = abi.SkinningJob(j["sourcePositions"], j["sourceNormals"], j["sourceTangents"], j["sourceBoneIndices"],
                                      j["sourceBoneWeights"], j["palette"], j["paletteCount"], j["vertexCount"], j["dstBaseVertex"],
                                      j.get("sourceLayout", abi.LAYOUT_PACKED))
-        if self.t.is_product:
-            self._call("skinning_encode", C.c_void_p(out_positions), C.c_void_p(out_normals), C.c_void_p(out_tangents), int(out_layout), arr, len(jobs))
-        else:
-            rc = self.t.lib.sgeo_skinning_encode(C.c_void_p(out_positions), C.c_void_p(out_normals), C.c_void_p(out_tangents), arr, len(jobs))
-            if rc != abi.SGE_OK:
-                raise SgeError("skinning_encode failed")
+        rc = self.t.skinning_encode(self.h, C.c_void_p(out_positions), C.c_void_p(out_normals), C.c_void_p(out_tangents), int(out_layout), arr, len(jobs))
+        if rc != abi.SGE_OK:
+            raise SgeError(f"skinning_encode failed with code {rc}: {self.t.last_error()}")
 
     # -- collision world --------------------------------------------------- #
     def rebuild_static(self, entities):

@@ -68,6 +68,10 @@ class OracleTable:
     def last_error(self):
         return ""
 
+    def skinning_encode(self, handle, out_positions, out_normals, out_tangents, out_layout, jobs, count):
+        # the oracle's encode is context-free and writes packed host arrays
+        return self.lib.sgeo_skinning_encode(out_positions, out_normals, out_tangents, jobs, count)
+
     def close(self):
         if self.handle:
             self.lib.sgeo_world_destroy(self.handle)

@@ -288,6 +288,49 @@ def test_character_vs_character_sweeps(sge, engines):
     free.close()
 
 
+def test_agent_carried_beyond_the_snapshot_grid(sge, engines):
+    """A solid agent that platform carry moves far outside the bounding box of the gathered snapshot (the XZ grid is built
+    over the snapshot, the sweep starts from the carried position): it meets nobody, like in the oracle's all-pairs loop,
+    and the grid lookup stays inside its cell table."""
+    import torch
+
+    gpu, cpu = engines
+    n = 48
+    ix, iz = np.meshgrid(np.arange(8), np.arange(6), indexing="ij")
+    pos = np.stack([ix.reshape(-1) * 5.0 - 17.5, np.full(n, -0.45), iz.reshape(-1) * 5.0 - 12.5], -1)
+    for e in engines:
+        ybot, _, _ = build_scene(sge, e, 1, terrain_cells=None, rings=3, segments=3)
+        e.resize(n)
+        params = sge.assets.default_controller_params(n)
+        params["agentFlags"] = sge.abi.AGENT_PRESENT | sge.abi.AGENT_SOLID
+        ctrl = sge.assets.default_controller_state(n)
+        ctrl["flags"] = sge.abi.CTRL_GROUNDED | sge.abi.CTRL_GROUNDED_NEAR
+        vel = np.zeros((n, 3), np.float32)
+        vel[:, 0] = 4.5
+        e.upload(bodies=sge.assets.default_bodies(n, pos), params=params, controllers=ctrl, intents=sge.assets.default_intents(n, vel),
+                 locomotion=sge.assets.default_locomotion(n, ybot), actions=sge.assets.default_actions(n, ybot, present=True))
+    ex = sge.parallel.AgentExchange(gpu, n, 0, 1, torch.device("cuda", 0), None)
+    # kinematic "platforms" whose top is flush with the ground quad under the outermost columns, each moving once, very far
+    events = {3: ((15.0, -4.0, -40.0), (21.0, -3.0, 40.0), (400.0, 0.0, 250.0)),
+              7: ((-21.0, -4.0, -40.0), (-15.0, -3.0, 40.0), (-400.0, 0.0, -250.0))}
+    for s in range(12):
+        pf = None
+        if s in events:
+            pf = np.zeros(1, sge.abi.platform_dtype)
+            pf["aabbMin"], pf["aabbMax"], pf["delta"] = events[s]
+            pf["kinematic"], pf["hasAABB"] = 1, 1
+        for e in engines:
+            e.upload_platforms(pf)
+        ex.step()
+        cpu.tick(stages=sge.abi.STAGE_ALL | sge.abi.STAGE_AGENTS)
+        gpu.synchronize()
+        compare_states(sge, gpu, cpu, n)
+    x = gpu.download(what=("bodies",))["bodies"]["position"][:, 0]
+    assert (x > 200).sum() >= 6 and (x < -200).sum() >= 6, "agents must have been carried away on both sides"
+    for e in engines:
+        e.upload_platforms(None)
+
+
 def test_real_asset_scene_bvh_and_queries(sge, engines):
     """The engine's own static assets (17-Cheese + ornate mirror + Semla from the FBX sources, merged as in
     configs[3]: 135,928 triangles + the ground quad): BVH bit-exact, casts / overlaps bit-exact."""
@@ -739,6 +782,88 @@ def test_full_size_properties(sge):
     gp = gpu.skinned(int(pick[5]) * V, V)[0]
     cp = cpu.skinned(5 * V, V)[0]
     assert np.abs(gp - cp).max() <= REL * np.abs(cp).max()
+    gpu.close()
+    cpu.close()
+
+
+def _lbs_stages(sge):
+    A = sge.abi
+    return A.STAGE_LOCOMOTION | A.STAGE_ACTION | A.STAGE_POSE | A.STAGE_WRITEBACK | A.STAGE_SKIN
+
+
+def test_config_lbs_only_parity(sge, engines):
+    """BASELINE.json configs[1] at a size the oracle finishes: clones in steady Running state with
+    per-clone phase offsets, pose + palette + LBS, no MOVE stage — the stage set `bench.py --workload lbs` times."""
+    gpu, cpu = engines
+    n = 64
+    for e in engines:
+        ybot, _, st = build_scene(sge, e, n, terrain_cells=None, mode="lbs", rings=9, segments=7)
+    assert (st["locomotion"]["state"] == sge.abi.LOCO_RUN).all() and len(np.unique(st["locomotion"]["motionTime"])) == n
+    stages = _lbs_stages(sge)
+    before = gpu.download(what=("bodies",))["bodies"]
+    for s in range(90):
+        for e in engines:
+            e.tick(stages=stages)
+        if s in (0, 1, 30, 89):
+            gpu.synchronize()
+            compare_states(sge, gpu, cpu, n)
+            gp, gn, gt = gpu.skinned()
+            cp, cn, ct = cpu.skinned()
+            assert np.abs(gp - cp).max() <= REL * np.abs(cp).max()
+            assert np.abs(gn - cn).max() <= 2e-5 and np.abs(gt - ct).max() <= 2e-5
+    # no collision stage ran: bodies are untouched, the pose moved
+    assert_struct_equal(gpu.download(what=("bodies",))["bodies"], before, "bodies")
+    pal, _, _ = gpu.palettes()
+    assert np.abs(pal[0] - pal[1]).max() > 1e-3, "clones run at different phases"
+
+
+def test_config_lbs_only_full_size(sge):
+    """configs[1] at BASELINE's full size (10k clones x 14,080 vertices), through size-independent properties: a random
+    subset re-run on the oracle reproduces the GPU's palettes / skinned vertices for those clones (1e-5), two runs give
+    identical checksums, clones with equal clocks are identical, every normal is unit length."""
+    gpu = sge.CharacterEngine(0)
+    cpu = ob.oracle_engine()
+    ybot = sge.assets.YBotAssets()
+    n, steps = 10000, 25
+    sge.crowd.upload_character_assets(gpu, ybot)
+    assert gpu.vertex_count == 14080
+    state0 = sge.crowd.spawn_crowd(gpu, ybot, n, None, mode="lbs")
+    for k in state0:
+        state0[k][1] = state0[k][0]
+    stages = _lbs_stages(sge)
+    V = gpu.vertex_count
+
+    def run():
+        gpu.upload(**state0)
+        for _ in range(steps):
+            gpu.tick(stages=stages)
+        gpu.synchronize()
+        chk = [gpu.skinned(i * V, 512)[0].view(np.uint32).sum(dtype=np.uint64) for i in range(0, n, 89)]
+        return gpu.download(what=("locomotion",))["locomotion"], np.asarray(chk)
+
+    l1, chk1 = run()
+    l2, chk2 = run()
+    assert np.array_equal(chk1, chk2)
+    assert_struct_equal(l1, l2, "locomotion(run1 vs run2)")
+    p, nrm, tan = gpu.skinned(0, 2 * V)
+    assert np.array_equal(p[:V], p[V:]) and np.array_equal(tan[:V], tan[V:])
+    assert np.isfinite(p).all() and np.allclose(np.linalg.norm(nrm, axis=1), 1, atol=1e-5)
+    last = gpu.skinned((n - 1) * V, V)[0]
+    assert np.isfinite(last).all() and np.abs(last - p[:V]).max() > 1e-3      # the last clone was written, at its own phase
+    rng = np.random.default_rng(1)
+    pick = np.sort(rng.choice(n, 48, replace=False))
+    sge.crowd.upload_character_assets(cpu, ybot)
+    cpu.resize(len(pick))
+    cpu.upload(**{k: v[pick] for k, v in state0.items()})
+    for _ in range(steps):
+        cpu.tick(stages=stages)
+    gpal = np.stack([gpu.palettes(int(i), 1)[0][0] for i in pick])
+    cpal, _, _ = cpu.palettes()
+    assert np.abs(gpal - cpal).max() <= REL * np.abs(cpal).max()
+    for k in (0, 17, 47):
+        gp = gpu.skinned(int(pick[k]) * V, V)[0]
+        cp = cpu.skinned(k * V, V)[0]
+        assert np.abs(gp - cp).max() <= REL * np.abs(cp).max()
     gpu.close()
     cpu.close()
 
