@@ -208,6 +208,7 @@ def main():
                 "distance_evals_per_query": stats.sweepIterations / max(stats.queries, 1),
                 "traversal_steps_per_query": stats.traversalSteps / max(stats.queries, 1),
                 "sweep_trips_per_query": stats.sweepTrips / max(stats.queries, 1),
+                "pairs_skipped_by_exact_rejects_per_query": stats.prunedPairs / max(stats.queries, 1),
                 "queries_per_s": stats.queries / max(prof.move_ms * 1e-3, 1e-9), "overflow": int(stats.overflow)},
     }
     if args.refit:

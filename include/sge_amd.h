@@ -576,6 +576,9 @@ typedef struct sge_move_stats {
     uint64_t prunedPairs;      /* (cast, triangle) pairs of vertical casts skipped by the conservative XZ reject (no result changes) */
 } sge_move_stats;
 int sge_move_stats_read(sge_context* ctx, sge_move_stats* out, int reset);
+/* Per-character share of CollisionQueryStats.capsuleSweepIterations (CollisionQuery.swift:280-318) for the LAST fixed step:
+   distance evaluations each of characters [first, first + count) spent in its casts (what the scheduler balances on). */
+int sge_move_cost_read(sge_context* ctx, int32_t first, int32_t count, int32_t* evaluations);
 
 /* ------------------------------------------------------------------------- */
 /* Skinned-geometry acceleration structures — the step after skinning:        */

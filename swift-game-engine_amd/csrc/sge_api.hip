@@ -1310,6 +1310,15 @@ int sge_profile_read(sge_context* c, sge_stage_times* out, int reset) {
     return SGE_OK;
 }
 
+int sge_move_cost_read(sge_context* c, int32_t first, int32_t count, int32_t* evaluations) {
+    SGE_RANGE_CHECK();
+    if (!evaluations) return SGE_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; }
+    if (count > 0) SGE_HIP(hipMemcpy(evaluations, c->dCost.as<int>() + first, (size_t)count * sizeof(int), hipMemcpyDeviceToHost));
+    return SGE_OK;
+}
+
 int sge_move_stats_read(sge_context* c, sge_move_stats* out, int reset) {
     if (!c || !out) return SGE_ERR_INVALID;
     (void)hipSetDevice(c->device);

@@ -179,6 +179,14 @@ __device__ __forceinline__ bool edgeFarXZ(float px, float pz, float ax, float az
     const float dv = c1 <= 0 ? wx * wx + wz * wz : ux * ux + uz * uz;   // nearest end point
     return (c1 <= 0 || c1 >= c2) ? dv > R2 : cr * cr > R2 * c2;
 }
+// A ground cast (capsuleCastGround: minNormalY set) drops every hit whose triangleNormal.y is below minNormalY WITHOUT lowering
+// bestT (CollisionQuery.swift:1095-1097), and triangleNormal is +-normalize(cross(v1 - v0, v2 - v0)) (:1335-1339, the sign follows
+// the contact normal). A triangle with |normal.y| < minNormalY is therefore rejected whichever way it is hit: its whole march —
+// for a wall below a capsule that walked off a ledge, a real contact found after ~17 evaluations, times the thousands of wall
+// triangles along a 200-unit fall probe — has no effect on the result. Same expression, same bits as the march's own triNormal.
+__device__ __forceinline__ bool tooSteepForGroundCast(F3 v0, F3 v1, F3 v2, float minNormalY) {
+    return fabsf(normalize(cross(v1 - v0, v2 - v0)).y) < minNormalY;
+}
 __device__ __forceinline__ bool verticalSweepMisses(float px, float pz, float radius, F3 v0, F3 v1, F3 v2) {
     const float R = radius + 1e-5f + (0.01f + 4e-5f * (fabsf(px) + fabsf(pz)));
     const float R2 = R * R;
@@ -409,6 +417,7 @@ __device__ __forceinline__ void waveCastRays(const DevCollision& col, float radi
                     const float4* tp = reinterpret_cast<const float4*>(col.tris + slot);
                     float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
                     v0 = F3{t0.x, t0.y, t0.z}; v1 = F3{t0.w, t1.x, t1.y}; v2 = F3{t1.z, t1.w, t2.x};
+                    if (hasMinNormalY && tooSteepForGroundCast(v0, v1, v2, minNormalY)) { slot = -1; st.pruned += R; }
                 }
                 const F3 bmin = vmin(v0, vmin(v1, v2)), bmax = vmax(v0, vmax(v1, v2));
                 for (int r = 0; r < R; ++r) {
@@ -480,6 +489,7 @@ __device__ __forceinline__ void waveCastRays(const DevCollision& col, float radi
                 const float4* tp = reinterpret_cast<const float4*>(col.tris + slot);
                 float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
                 v0 = F3{t0.x, t0.y, t0.z}; v1 = F3{t0.w, t1.x, t1.y}; v2 = F3{t1.z, t1.w, t2.x};
+                if (hasMinNormalY && tooSteepForGroundCast(v0, v1, v2, minNormalY)) { slot = -1; st.pruned += R; }
             }
             const F3 bmin = vmin(v0, vmin(v1, v2)), bmax = vmax(v0, vmax(v1, v2));
             for (int r = 0; r < R; ++r) {

@@ -420,6 +420,13 @@ class CharacterEngine:
         self._call("profile_read", C.byref(st), int(reset))
         return st
 
+    def move_cost(self, first=0, count=None):
+        """Distance evaluations each character spent in the casts of its last fixed step (product only)."""
+        count = self.count - first if count is None else count
+        out = np.zeros(count, np.int32)
+        self._call("move_cost_read", int(first), int(count), ptr(out))
+        return out
+
     def move_stats(self, reset=True):
         st = abi.MoveStats()
         self._call("move_stats_read", C.byref(st), int(reset))

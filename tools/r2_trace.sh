@@ -10,4 +10,4 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/trace -o run --output
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 cp $f $OUT/kernel_stats.csv
 find $OUT/trace -name "*_kernel_trace.csv" -size +20M -delete
-column -s, -t < $OUT/kernel_stats.csv | cut -c1-200 | head -20
+cut -c1-200 $OUT/kernel_stats.csv | head -20
