@@ -379,6 +379,7 @@ sge_context* sge_context_create(int device_index) {
     // the latency-bound collision / pose launches go first when they compete with a streaming skin launch (overlap option)
     int prLeast = 0, prGreatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest);
+    if (getenv("SGE_SKIN_STREAM_HIGH")) std::swap(prLeast, prGreatest); // experiment: the streaming kernel's queue first
     if (hipStreamCreateWithPriority(&c->ownStream, hipStreamNonBlocking, prGreatest) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
     c->stream = c->ownStream;
     if (hipStreamCreateWithPriority(&c->skinStream, hipStreamNonBlocking, prLeast) != hipSuccess ||

@@ -1669,8 +1669,9 @@ void launch_move(const MoveLaunch& L, hipStream_t s) {
     if (agents) hipLaunchKernelGGL((move_kernel<1, true, true>), dim3(heavyGrid), dim3(kWave * kHeavyWaves), 0, L.heavyStream, H);
     else hipLaunchKernelGGL((move_kernel<1, false, true>), dim3(heavyGrid), dim3(kWave * kHeavyWaves), 0, L.heavyStream, H);
     (void)hipEventRecord(L.evHeavyDone, L.heavyStream);
+    static const int ldsPad = getenv("SGE_MOVE_LDS_PAD") ? atoi(getenv("SGE_MOVE_LDS_PAD")) : 0; // experiments: caps workgroups per CU
     if (agents) hipLaunchKernelGGL((move_kernel<1, true>), dim3(L.count), dim3(kWave), 0, s, L); // skips flagged characters
-    else hipLaunchKernelGGL((move_kernel<1, false>), dim3(L.count), dim3(kWave), 0, s, L);
+    else hipLaunchKernelGGL((move_kernel<1, false>), dim3(L.count), dim3(kWave), ldsPad, s, L);
     (void)hipStreamWaitEvent(s, L.evHeavyDone, 0);
 }
 

@@ -197,8 +197,11 @@ __device__ __forceinline__ void skinRange(const SkinLaunch& L, const int c, cons
 }
 
 template <int SRC_STRIDE, int DST_STRIDE>
-__global__ __launch_bounds__(kSkinBlock) void skin_kernel(SkinLaunch L, int splits, int vertsPerSplit) {
+__global__ __launch_bounds__(kSkinBlock) void skin_kernel(SkinLaunch L, int splits, int vertsPerSplit, int prio) {
     __shared__ float4 pal[SGE_MAX_BONES * 3];
+    if (prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
     const int c = blockIdx.x / splits;
     const int sp = blockIdx.x - c * splits;
     const int vBegin = sp * vertsPerSplit;
@@ -262,10 +265,12 @@ void launch_skin(const SkinLaunch& L, hipStream_t s) {
     splits = (L.vertexCount + vertsPerSplit - 1) / vertsPerSplit;
     dim3 grid((unsigned)((size_t)splits * L.chars));
     int ss = L.srcLayout == SGE_LAYOUT_PADDED16 ? 4 : 3, ds = L.dstLayout == SGE_LAYOUT_PADDED16 ? 4 : 3;
-    if (ss == 3 && ds == 3) hipLaunchKernelGGL((skin_kernel<3, 3>), grid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit);
-    else if (ss == 3 && ds == 4) hipLaunchKernelGGL((skin_kernel<3, 4>), grid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit);
-    else if (ss == 4 && ds == 3) hipLaunchKernelGGL((skin_kernel<4, 3>), grid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit);
-    else hipLaunchKernelGGL((skin_kernel<4, 4>), grid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit);
+    static const int ldsPad = getenv("SGE_SKIN_LDS_PAD") ? atoi(getenv("SGE_SKIN_LDS_PAD")) : 0; // experiments: caps workgroups per CU
+    static const int prio = getenv("SGE_SKIN_SETPRIO") ? atoi(getenv("SGE_SKIN_SETPRIO")) : 0;
+    if (ss == 3 && ds == 3) hipLaunchKernelGGL((skin_kernel<3, 3>), grid, dim3(kSkinBlock), ldsPad, s, L, splits, vertsPerSplit, prio);
+    else if (ss == 3 && ds == 4) hipLaunchKernelGGL((skin_kernel<3, 4>), grid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit, prio);
+    else if (ss == 4 && ds == 3) hipLaunchKernelGGL((skin_kernel<4, 3>), grid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit, prio);
+    else hipLaunchKernelGGL((skin_kernel<4, 4>), grid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit, prio);
 }
 
 // ---------------------------------------------------------------------------

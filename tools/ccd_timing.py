@@ -6,7 +6,8 @@ sge.abi.LIB_NAME = "libsge_amd_timing.so"
 eng = sge.CharacterEngine(0)
 ybot = sge.assets.YBotAssets()
 sge.crowd.upload_character_assets(eng, ybot, rings=4, segments=4)
-terrain = sge.crowd.upload_terrain(eng)
+which = sys.argv[1] if len(sys.argv) > 1 else "synthetic"
+terrain = sge.crowd.upload_terrain(eng) if which == "synthetic" else sge.crowd.upload_asset_scene(eng, tuple(which.split(",")))
 n = 10000
 sge.crowd.spawn_crowd(eng, ybot, n, terrain)
 st = sge.abi.STAGE_ALL_FIXED
