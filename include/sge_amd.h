@@ -579,6 +579,12 @@ int sge_move_stats_read(sge_context* ctx, sge_move_stats* out, int reset);
 /* Per-character share of CollisionQueryStats.capsuleSweepIterations (CollisionQuery.swift:280-318) for the LAST fixed step:
    distance evaluations each of characters [first, first + count) spent in its casts (what the scheduler balances on). */
 int sge_move_cost_read(sge_context* ctx, int32_t first, int32_t count, int32_t* evaluations);
+/* Diagnostics (environment SGE_WAVE_PROF=1): shader-clock cycles of every wavefront of the last grouped move launch,
+   8 x uint64 per wavefront: total, gather (setup + traversal), sweep, consume, rounds, sweep trips, traversal steps, start clock. */
+int sge_debug_wave_profile(sge_context* ctx, uint64_t* out, int32_t waves);
+/* Diagnostics: the scheduling lists of the last move launch: lists[0 .. counts[0]) = the grouped launch's characters ordered by last
+   step's cost, lists[count .. count + counts[1]) = the multi-wave launch's characters (lists holds 2 * count entries). */
+int sge_debug_move_lists(sge_context* ctx, int32_t* lists, int32_t* counts);
 
 /* ------------------------------------------------------------------------- */
 /* Skinned-geometry acceleration structures — the step after skinning:        */

@@ -96,7 +96,7 @@ struct sge_context {
            dBlasIndices, dBlasBounds, dBlasInstances, dBlasRays, dBlasHits, dBlasTileStart, dBlasRoundLen, dBlasRoundCluster, dBlasRoundIds, dBlasWorldBoxes, dBlasUVs;
     bool blasHasUVs = false;
     // stats / profiling
-    DevBuf dStats;
+    DevBuf dStats, dWaveProf, dOrderHist;
     Events evMove, evPose, evSkin, evAgents, evBlas;
 };
 
@@ -376,6 +376,7 @@ sge_context* sge_context_create(int device_index) {
     if (hipSetDevice(device_index) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
     sge_context* c = new sge_context();
     c->device = device_index;
+    if (getenv("SGE_HEAVY_THRESHOLD")) c->heavyThreshold = atoi(getenv("SGE_HEAVY_THRESHOLD")); // experiments
     // the latency-bound collision / pose launches go first when they compete with a streaming skin launch (overlap option)
     int prLeast = 0, prGreatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest);
@@ -400,7 +401,7 @@ void sge_context_destroy(sge_context* c) {
     drainEvents(c->evMove); drainEvents(c->evPose); drainEvents(c->evSkin); drainEvents(c->evAgents); drainEvents(c->evBlas);
     DevBuf* bufs[] = {&c->dParent, &c->dDepth, &c->dLeanChain, &c->dPath, &c->dBindLocal, &c->dInvBind, &c->dRestT, &c->dRawRestT, &c->dPreRot,
                       &c->dCoeffs, &c->dCoeffCount, &c->dBonePresent, &c->dMeshPos, &c->dMeshNrm, &c->dMeshTan, &c->dMeshIdx, &c->dMeshWgt,
-                      &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dSlotOfRank, &c->dCost, &c->dHint, &c->dHeavyFlags, &c->dJobTable, &c->dBlockJob, &c->dLists, &c->dListCounts, &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
+                      &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dSlotOfRank, &c->dCost, &c->dHint, &c->dHeavyFlags, &c->dJobTable, &c->dBlockJob, &c->dLists, &c->dListCounts, &c->dOrderHist, &c->dWaveProf, &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
                       &c->dPalettes, &c->dPoseModel, &c->dPoseLocal, &c->dMoveScratch, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
                       &c->dCellCursor, &c->dAgentMinMax, &c->dAgentGrid, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats,
                       &c->dBlasEntryLink, &c->dBlasWideFirst, &c->dBlasWideParent, &c->dBlasWideLevel, &c->dBlasSlotIdx, &c->dBlasSlotTri,
@@ -718,6 +719,8 @@ int uploadCollisionAll(sge_context* c) {
     if (c->hostCol.maxDepth > 120 || c->hostDyn.maxDepth > 120) { set_error("BVH deeper than the traversal stack policy allows"); return SGE_ERR_CAPACITY; }
     // a traversal pops the newest node first, so at most 63 siblings stay pending per wide level (+ the other set's root)
     if (std::max(c->hostCol.wideLevels, c->hostDyn.wideLevels) * 63 + 2 > kTraversalStackCap) { set_error("triangle set too large for the traversal stack"); return SGE_ERR_CAPACITY; }
+    // a sweep work item packs (ray slot << 27 | triangle slot) into 32 bits (sge_ccd.hip)
+    if (c->hostCol.triOrder.size() + c->hostDyn.triOrder.size() >= ((size_t)1 << 27)) { set_error("more than 2^27 collision triangles"); return SGE_ERR_CAPACITY; }
     std::vector<DevTri> ts, td;
     std::vector<DevNode> ws, wd;
     std::vector<DevMaterial> ms, md;
@@ -952,6 +955,7 @@ int sge_characters_resize(sge_context* c, int32_t count) {
     SGE_ZALLOC(c->dHeavyFlags, N);
     SGE_ZALLOC(c->dLists, 2 * N * sizeof(int));
     SGE_ZALLOC(c->dListCounts, 2 * sizeof(int));
+    SGE_ZALLOC(c->dOrderHist, 64 * sizeof(int));
     if (c->storePoseDebug) { SGE_ZALLOC(c->dPoseModel, N * B * 64); SGE_ZALLOC(c->dPoseLocal, N * B * 64); }
 #undef SGE_ZALLOC
     c->crowd = DevCrowd{count, c->dBodies.as<sge_body_state>(), c->dParams.as<sge_controller_params>(),
@@ -1057,8 +1061,13 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         }
         MoveLaunch L{c->crowd, c->col, c->agents, d->dt, d->gravity[0], d->gravity[1], d->gravity[2], st, first, count,
                      c->dStats.as<unsigned long long>(), c->dMoveScratch.p, c->dPlatforms.as<sge_platform_state>(), c->platformCount,
-                     c->dCost.as<int>(), c->dHint.as<uint8_t>(), c->heavyThreshold >= 0 ? c->dLists.as<int>() : nullptr, c->dListCounts.as<int>(), c->dHeavyFlags.as<uint8_t>(),
-                     c->heavyThreshold, 2048, c->heavyStream, c->evClassified, c->evHeavyDone, nullptr, nullptr};
+                     c->dCost.as<int>(), getenv("SGE_NO_SPEC") ? nullptr : c->dHint.as<uint8_t>(), c->dLists.as<int>(), c->dListCounts.as<int>(), c->dHeavyFlags.as<uint8_t>(),
+                     c->heavyThreshold, 2048, c->heavyStream, c->evClassified, c->evHeavyDone, nullptr, nullptr, nullptr, nullptr, c->dOrderHist.as<int>(), nullptr};
+        if (getenv("SGE_WAVE_PROF")) {
+            if (c->dWaveProf.alloc((size_t)c->crowd.count * 64) != SGE_OK) return SGE_ERR_DEVICE;
+            SGE_HIP(hipMemsetAsync(c->dWaveProf.p, 0, (size_t)c->crowd.count * 64, c->stream));
+            L.waveProf = c->dWaveProf.as<unsigned long long>();
+        }
         if (!(st & SGE_STAGE_AGENTS) || !c->agents.grid) L.agents.all = nullptr;
         Bracket br(c, &c->evMove);
         launch_move(L, c->stream);
@@ -1317,6 +1326,25 @@ int sge_move_cost_read(sge_context* c, int32_t first, int32_t count, int32_t* ev
     (void)hipSetDevice(c->device);
     { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; }
     if (count > 0) SGE_HIP(hipMemcpy(evaluations, c->dCost.as<int>() + first, (size_t)count * sizeof(int), hipMemcpyDeviceToHost));
+    return SGE_OK;
+}
+
+// diagnostics: per-wavefront cycle counters of the last grouped move launch (SGE_WAVE_PROF=1), 8 x u64 per wavefront
+int sge_debug_wave_profile(sge_context* c, uint64_t* out, int32_t waves) {
+    if (!c || !out || !c->dWaveProf.p || (size_t)waves * 64 > c->dWaveProf.bytes) return SGE_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; }
+    SGE_HIP(hipMemcpy(out, c->dWaveProf.p, (size_t)waves * 64, hipMemcpyDeviceToHost));
+    return SGE_OK;
+}
+
+// diagnostics: the order / heavy lists of the last move launch: lists[2 * count], counts[2] (listed, heavy)
+int sge_debug_move_lists(sge_context* c, int32_t* lists, int32_t* counts) {
+    if (!c || !lists || !counts) return SGE_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; }
+    SGE_HIP(hipMemcpy(lists, c->dLists.p, (size_t)c->crowd.count * 8, hipMemcpyDeviceToHost));
+    SGE_HIP(hipMemcpy(counts, c->dListCounts.p, 8, hipMemcpyDeviceToHost));
     return SGE_OK;
 }
 

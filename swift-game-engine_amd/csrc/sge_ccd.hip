@@ -35,8 +35,18 @@ constexpr int kWave = 64;
 constexpr int kStackCap = kTraversalStackCap; // wide nodes pending (each pop adds <= 64; sge_api checks the tree depth against it)
 constexpr int kCandCap = 512;
 constexpr int kRangeCap = 128;
-constexpr int kItemCap = 512;
+constexpr int kItemCap = 1024;
 constexpr int kMaxRays = 6;
+#ifndef SGE_GROUP
+#define SGE_GROUP 4
+#endif
+#ifndef SGE_GROUP_WAVES
+#define SGE_GROUP_WAVES 3
+#endif
+constexpr int kGroup = SGE_GROUP;             // characters per wavefront in move_group_kernel
+constexpr int kRaySlots = kMaxRays * kGroup;  // ray slots [g * kMaxRays, (g + 1) * kMaxRays) belong to character g of the wavefront
+constexpr int kItemRayShift = 27;             // work item = (ray slot << 27) | triangle slot (sge_api checks triCount < 2^27)
+constexpr int kItemSlotMask = (1 << kItemRayShift) - 1;
 constexpr int kRefillIdle = 16;  // idle lanes that trigger a queue top-up while others still march
 
 struct OverlapRec { float depth; F3 position, normal, triNormal; int triIndex, rank; };
@@ -49,12 +59,15 @@ struct WaveShared {
     int items[kItemCap];     // (ray << 28) | slot work items of a multi-ray cast
     // up to kMaxRays casts that share radius/halfHeight/filters run as ONE traversal + shared sweep batches
     int rayCount;
-    F3 rayFrom[kMaxRays], rayDelta[kMaxRays], rayDir[kMaxRays], rayMin[kMaxRays], rayMax[kMaxRays];
-    float rayLen[kMaxRays];
-    int rayMaxIter[kMaxRays], rayValid[kMaxRays];
-    int rayVertical[kMaxRays];  // delta = (0, dy, 0): the ground probe's casts (verticalSweepMisses)
-    unsigned long long rayKey[kMaxRays]; // (toi bits << 32) | visit rank of the best accepted hit so far
-    CastRec rayRec[kMaxRays];
+    F3 rayFrom[kRaySlots], rayDelta[kRaySlots], rayDir[kRaySlots], rayMin[kRaySlots], rayMax[kRaySlots];
+    float rayLen[kRaySlots];
+    int rayMaxIter[kRaySlots], rayValid[kRaySlots];
+    int rayVertical[kRaySlots];  // delta = (0, dy, 0): the ground probe's casts (verticalSweepMisses)
+    // capsule and acceptance filters of the cast a ray belongs to (move_group_kernel sweeps rays of several characters together)
+    float rayRadius[kRaySlots], rayHalfHeight[kRaySlots], rayMinNormalY[kRaySlots];
+    int rayFilter[kRaySlots];    // bit 0: blockingOnly, bit 1: minNormalY set
+    unsigned long long rayKey[kRaySlots]; // (toi bits << 32) | visit rank of the best accepted hit so far
+    CastRec rayRec[kRaySlots];
     OverlapRec ovl[SGE_MAX_OVERLAP_HITS];
     OverlapRec ovlTmp[SGE_MAX_OVERLAP_HITS];
 };
@@ -79,9 +92,10 @@ __device__ unsigned long long g_cycTraverse, g_cycSweep, g_cycTotal;
 __shared__ WaveShared sh;
 // The wave-uniform per-character state lives in LDS, not in registers: it is touched only
 // between queries, and every lane reads/writes the same value in lockstep.
-__shared__ sge_body_state sBody;
-__shared__ sge_controller_params sParams;
-__shared__ sge_controller_state sCtrl;
+// (indexed by the character's place g in its wavefront: always 0 in the one-character kernels)
+__shared__ sge_body_state sBodyA[kGroup];
+__shared__ sge_controller_params sParamsA[kGroup];
+__shared__ sge_controller_state sCtrlA[kGroup];
 
 __device__ __forceinline__ int laneId() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ int prefixCount(unsigned long long m) {
@@ -266,8 +280,8 @@ __device__ __forceinline__ void heavyMarch(const DevCollision& col, WaveStats& s
                 const int idx = base + prefixCount(want);
                 if (idx < total) {
                     const int it = hv.items[idx];
-                    myRay = (unsigned)it >> 28;
-                    tri = loadTri(col, it & 0x0fffffff);
+                    myRay = (unsigned)it >> kItemRayShift;
+                    tri = loadTri(col, it & kItemSlotMask);
                     triNormal = normalize(cross(tri.v1 - tri.v0, tri.v2 - tri.v0));
                     len = sh.rayLen[myRay];
                     maxIter = sh.rayMaxIter[myRay];
@@ -424,7 +438,7 @@ __device__ __forceinline__ void waveCastRays(const DevCollision& col, float radi
                     bool c = slot >= 0 && sh.rayValid[r] && !boxDisjoint(bmin, bmax, sh.rayMin[r], sh.rayMax[r]);
                     if (c && sh.rayVertical[r]) { c = !verticalSweepMisses(sh.rayFrom[r].x, sh.rayFrom[r].z, radius, v0, v1, v2); st.pruned += c ? 0 : 1; }
                     unsigned long long mc = __ballot(c);
-                    if (c) hv.items[hCount + prefixCount(mc)] = (r << 28) | slot;
+                    if (c) hv.items[hCount + prefixCount(mc)] = (int)(((unsigned)r << kItemRayShift) | (unsigned)slot);
                     hCount += __popcll(mc);
                 }
                 __syncthreads();
@@ -496,7 +510,7 @@ __device__ __forceinline__ void waveCastRays(const DevCollision& col, float radi
                 bool c = slot >= 0 && sh.rayValid[r] && !boxDisjoint(bmin, bmax, sh.rayMin[r], sh.rayMax[r]);
                 if (c && sh.rayVertical[r]) { c = !verticalSweepMisses(sh.rayFrom[r].x, sh.rayFrom[r].z, radius, v0, v1, v2); st.pruned += c ? 0 : 1; }
                 unsigned long long mc = __ballot(c);
-                if (c) sh.items[itemCount + prefixCount(mc)] = (r << 28) | slot;
+                if (c) sh.items[itemCount + prefixCount(mc)] = (int)(((unsigned)r << kItemRayShift) | (unsigned)slot);
                 itemCount += __popcll(mc);
             }
             __syncthreads();
@@ -509,8 +523,8 @@ __device__ __forceinline__ void waveCastRays(const DevCollision& col, float radi
             const int p = prefixCount(idleMask);
             if (phase == PH_DONE && p < take) {
                 const int it = sh.items[itemCount - 1 - p];
-                myRay = (unsigned)it >> 28;
-                tri = loadTri(col, it & 0x0fffffff);
+                myRay = (unsigned)it >> kItemRayShift;
+                tri = loadTri(col, it & kItemSlotMask);
                 triNormal = normalize(cross(tri.v1 - tri.v0, tri.v2 - tri.v0));
                 len = sh.rayLen[myRay];
                 maxIter = sh.rayMaxIter[myRay];
@@ -1074,17 +1088,19 @@ struct MoveState {
     float dt; F3 gravity; const DevMaterial* materials;
     int aHave; float aToi; F3 aNormal;
 };
-__shared__ MoveState ms;
+__shared__ MoveState msA[kGroup];
 
 enum { MP_DEPEN = 0, MP_SLIDE = 1, MP_GROUND_CENTER = 2, MP_GROUND_EVAL = 4, MP_GROUND_SAMPLE = 5,
        MP_FINISH = 6, MP_DONE = 7 };
 
 // ---- consume steps of the per-character state machine. They work on the LDS-resident state only and are
 // deliberately NOT inlined: the kernel body then holds just the two query loops within its register budget. ----
-__device__ __noinline__ void consumeDepen(int nOverlap) { // DepenetrationResolver.resolve :734-808, one iteration
-    sge_body_state& body = sBody; (void)body;
-    const sge_controller_params& P = sParams; (void)P;
-    sge_controller_state& C = sCtrl; (void)C;
+__device__ __noinline__ void consumeDepen(int g, int nOverlap) { // DepenetrationResolver.resolve :734-808, one iteration
+    sge_body_state& body = sBodyA[g]; (void)body;
+    const sge_controller_params& P = sParamsA[g]; (void)P;
+    sge_controller_state& C = sCtrlA[g]; (void)C;
+    MoveState& ms = msA[g];
+    const int rb = g * kMaxRays; (void)rb; // first ray slot of this character
     const float dt = ms.dt; (void)dt;
     bool stop = nOverlap == 0;
     if (!stop) {
@@ -1147,17 +1163,19 @@ __device__ __noinline__ void consumeDepen(int nOverlap) { // DepenetrationResolv
     }
 }
 
-__device__ __noinline__ void consumeSlide() { // one iteration of resolveKinematicSweep :1674-1764
-    sge_body_state& body = sBody; (void)body;
-    const sge_controller_params& P = sParams; (void)P;
-    sge_controller_state& C = sCtrl; (void)C;
+__device__ __noinline__ void consumeSlide(int g) { // one iteration of resolveKinematicSweep :1674-1764
+    sge_body_state& body = sBodyA[g]; (void)body;
+    const sge_controller_params& P = sParamsA[g]; (void)P;
+    sge_controller_state& C = sCtrlA[g]; (void)C;
+    MoveState& ms = msA[g];
+    const int rb = g * kMaxRays; (void)rb; // first ray slot of this character
     const float dt = ms.dt; (void)dt;
     F3 remaining = ms.remaining, position = ms.position;
     D3 velocity = ms.velocity;
     const float len = length(remaining);
     SlideHit hit;
-    hit.s = sh.rayRec[0]; hit.aToi = 0; hit.aNormal = F3{0, 0, 0}; hit.isStatic = true;
-    bool haveStatic = rayHit(0);
+    hit.s = sh.rayRec[rb]; hit.aToi = 0; hit.aNormal = F3{0, 0, 0}; hit.isStatic = true;
+    bool haveStatic = rayHit(rb);
     if (haveStatic && hit.s.normal.y < P.minGroundDot && C.sideContactFrames > 0) {
         F3 cached;
         if (cachedNormal(C, hit.s.triIndex, cached)) {
@@ -1210,26 +1228,30 @@ __device__ __noinline__ void consumeSlide() { // one iteration of resolveKinemat
     if (endSlide) ms.phase = MP_GROUND_CENTER;
 }
 
-__device__ __noinline__ void consumeGroundCenter() { // GroundProbe.resolve :844-866
-    sge_body_state& body = sBody; (void)body;
-    const sge_controller_params& P = sParams; (void)P;
-    sge_controller_state& C = sCtrl; (void)C;
+__device__ __noinline__ void consumeGroundCenter(int g) { // GroundProbe.resolve :844-866
+    sge_body_state& body = sBodyA[g]; (void)body;
+    const sge_controller_params& P = sParamsA[g]; (void)P;
+    sge_controller_state& C = sCtrlA[g]; (void)C;
+    MoveState& ms = msA[g];
+    const int rb = g * kMaxRays; (void)rb; // first ray slot of this character
     const float dt = ms.dt; (void)dt;
-    ms.haveCenter = rayHit(0) ? 1 : 0;
-    if (rayHit(0)) ms.centerHit = sh.rayRec[0];
-    if (rayHit(1)) ms.gDistance = sh.rayRec[1].toi;
+    ms.haveCenter = rayHit(rb) ? 1 : 0;
+    if (rayHit(rb)) ms.centerHit = sh.rayRec[rb];
+    if (rayHit(rb + 1)) ms.gDistance = sh.rayRec[rb + 1].toi;
     ms.phase = MP_GROUND_EVAL;
 }
 
-__device__ __noinline__ void consumeGroundSample() { // :906-921, in the reference's sample order
-    sge_body_state& body = sBody; (void)body;
-    const sge_controller_params& P = sParams; (void)P;
-    sge_controller_state& C = sCtrl; (void)C;
+__device__ __noinline__ void consumeGroundSample(int g) { // :906-921, in the reference's sample order
+    sge_body_state& body = sBodyA[g]; (void)body;
+    const sge_controller_params& P = sParamsA[g]; (void)P;
+    sge_controller_state& C = sCtrlA[g]; (void)C;
+    MoveState& ms = msA[g];
+    const int rb = g * kMaxRays; (void)rb; // first ray slot of this character
     const float dt = ms.dt; (void)dt;
     const CastRec c = ms.centerHit;
     float combineTol = smax(smax(P.groundSnapSkin, P.skinWidth), 0.05f);
     F3 normalSum = ms.gNormalSum;
-    const int base = ms.sampleK; // 2 when the samples rode along with the centre pass, 0 after a pass of their own
+    const int base = rb + ms.sampleK; // sampleK: 2 when the samples rode along with the centre pass, 0 after a pass of their own
     for (int k = 0; k < 4; ++k) {
         if (rayHit(base + k) && sh.rayRec[base + k].toi <= c.toi + combineTol) {
             if (dot(sh.rayRec[base + k].triNormal, c.triNormal) > 0.98f) normalSum = normalSum + sh.rayRec[base + k].triNormal;
@@ -1239,10 +1261,12 @@ __device__ __noinline__ void consumeGroundSample() { // :906-921, in the referen
     ms.phase = MP_FINISH;
 }
 
-__device__ __noinline__ void groundEval() { // :868-894 — decides whether the four offset casts are needed
-    sge_body_state& body = sBody; (void)body;
-    const sge_controller_params& P = sParams; (void)P;
-    sge_controller_state& C = sCtrl; (void)C;
+__device__ __noinline__ void groundEval(int g) { // :868-894 — decides whether the four offset casts are needed
+    sge_body_state& body = sBodyA[g]; (void)body;
+    const sge_controller_params& P = sParamsA[g]; (void)P;
+    sge_controller_state& C = sCtrlA[g]; (void)C;
+    MoveState& ms = msA[g];
+    const int rb = g * kMaxRays; (void)rb; // first ray slot of this character
     const float dt = ms.dt; (void)dt;
     const CastRec centerHit = ms.centerHit;
     if (ms.haveCenter && centerHit.toi <= P.snapDistance) {
@@ -1275,10 +1299,12 @@ __device__ __noinline__ void groundEval() { // :868-894 — decides whether the 
     __syncthreads();
 }
 
-__device__ __noinline__ void finishStep() { // ground state, GroundSnap, SlopeFriction, writeBack
-    sge_body_state& body = sBody; (void)body;
-    const sge_controller_params& P = sParams; (void)P;
-    sge_controller_state& C = sCtrl; (void)C;
+__device__ __noinline__ void finishStep(int g) { // ground state, GroundSnap, SlopeFriction, writeBack
+    sge_body_state& body = sBodyA[g]; (void)body;
+    const sge_controller_params& P = sParamsA[g]; (void)P;
+    sge_controller_state& C = sCtrlA[g]; (void)C;
+    MoveState& ms = msA[g];
+    const int rb = g * kMaxRays; (void)rb; // first ray slot of this character
     const float dt = ms.dt; (void)dt;
     const F3 gravity = ms.gravity;
     F3 position = ms.position;
@@ -1418,14 +1444,15 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? 4 
         const uint32_t* gb = reinterpret_cast<const uint32_t*>(K.crowd.bodies + e);
         const uint32_t* gp = reinterpret_cast<const uint32_t*>(K.crowd.params + e);
         const uint32_t* gc = reinterpret_cast<const uint32_t*>(K.crowd.controllers + e);
-        if (lane < 24) reinterpret_cast<uint32_t*>(&sBody)[lane] = gb[lane];
-        if (lane < 16) reinterpret_cast<uint32_t*>(&sParams)[lane] = gp[lane];
-        if (lane < 32) reinterpret_cast<uint32_t*>(&sCtrl)[lane] = gc[lane];
+        if (lane < 24) reinterpret_cast<uint32_t*>(&sBodyA[0])[lane] = gb[lane];
+        if (lane < 16) reinterpret_cast<uint32_t*>(&sParamsA[0])[lane] = gp[lane];
+        if (lane < 32) reinterpret_cast<uint32_t*>(&sCtrlA[0])[lane] = gc[lane];
         __syncthreads();
     }
-    sge_body_state& body = sBody;
-    const sge_controller_params& P = sParams;
-    sge_controller_state& C = sCtrl;
+    sge_body_state& body = sBodyA[0];
+    const sge_controller_params& P = sParamsA[0];
+    sge_controller_state& C = sCtrlA[0];
+    MoveState& ms = msA[0];
     const float dt = K.dt;
     const F3 gravity{K.gx, K.gy, K.gz};
     uint32_t* const scratch = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(K.scratch) + (size_t)e * kMoveScratchBytes);
@@ -1521,7 +1548,7 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? 4 
             // near the ground (groundEval). A character that stood on a slope last step will almost surely need them again,
             // so they ride along as rays 2..5 of this pass (casts are pure: unused results are simply dropped); everyone
             // else casts them in a pass of their own if the condition comes true.
-            const bool spec = ms.wasGroundedNear && P.snapDistance > 0 && K.hint && K.hint[e] != 0;
+            const bool spec = __builtin_amdgcn_readfirstlane((int)(ms.wasGroundedNear && P.snapDistance > 0 && K.hint && K.hint[e] != 0)) != 0;
             sh.rayCount = spec ? 6 : 2;
             ms.sampleK = spec ? 2 : 0;
             if (spec) {
@@ -1555,7 +1582,14 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? 4 
         if (PART == 0 && doOverlap) nOverlap = waveCapsuleOverlapAll(col, ms.position, P.radius, P.halfHeight, 8, P.collisionMask, st);
         if (PART == 1 && doCast) waveCastRays<HEAVY>(col, P.radius, P.halfHeight, blocking, !blocking, P.minGroundDot, P.collisionMask, st);
         // ---------------- 3. consume ----------------
-        if (PART == 0) consumeDepen(nOverlap);
+#ifdef SGE_DEBUG_RAYS
+        if (PART == 1 && lane == 0 && (e == 42 || e == 84) && phase == MP_GROUND_CENTER) {
+            printf("O e %d sampleK %d pos %.9g %.9g %.9g :", e, ms.sampleK, ms.position.x, ms.position.y, ms.position.z);
+            for (int r = 0; r < 6; ++r) printf(" [%d toi %.9g tri %d]", rayHit(r) ? 1 : 0, sh.rayRec[r].toi, sh.rayRec[r].triIndex);
+            printf("\n");
+        }
+#endif
+        if (PART == 0) consumeDepen(0, nOverlap);
         else if (phase == MP_SLIDE) {
             if (AGENTS && useAgents) { // AgentSweepSolver.bestHit :1053-1091 (independent of the static hit)
                 const F3 remaining = ms.remaining;
@@ -1565,12 +1599,12 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? 4 
                                              selfRadius, P.halfHeight, aToi, aNormal);
                 ms.aHave = have ? 1 : 0; ms.aToi = aToi; ms.aNormal = aNormal;
             }
-            consumeSlide();
-        } else if (phase == MP_GROUND_CENTER) consumeGroundCenter();
-        else if (phase == MP_GROUND_SAMPLE) consumeGroundSample();
+            consumeSlide(0);
+        } else if (phase == MP_GROUND_CENTER) consumeGroundCenter(0);
+        else if (phase == MP_GROUND_SAMPLE) consumeGroundSample(0);
         __syncthreads();
-        if (PART == 1 && ms.phase == MP_GROUND_EVAL) { groundEval(); __syncthreads(); }
-        if (PART == 1 && ms.phase == MP_FINISH) { finishStep(); __syncthreads(); }
+        if (PART == 1 && ms.phase == MP_GROUND_EVAL) { groundEval(0); __syncthreads(); }
+        if (PART == 1 && ms.phase == MP_FINISH) { finishStep(0); __syncthreads(); }
     }
 
     if (ms.phase == MP_DONE) { // the step (or, without SGE_STAGE_MOVE, the velocity update) is complete
@@ -1582,8 +1616,8 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? 4 
     {
         uint32_t* gb = reinterpret_cast<uint32_t*>(K.crowd.bodies + e);
         uint32_t* gc = reinterpret_cast<uint32_t*>(K.crowd.controllers + e);
-        if (lane < 24) gb[lane] = reinterpret_cast<const uint32_t*>(&sBody)[lane];
-        if (lane < 32) gc[lane] = reinterpret_cast<const uint32_t*>(&sCtrl)[lane];
+        if (lane < 24) gb[lane] = reinterpret_cast<const uint32_t*>(&sBodyA[0])[lane];
+        if (lane < 32) gc[lane] = reinterpret_cast<const uint32_t*>(&sCtrlA[0])[lane];
     }
 #ifdef SGE_CCD_TIMING
     if (lane == 0) {
@@ -1602,6 +1636,9 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? 4 
         // this step's sweep cost decides which kernel takes the character next step
         if (PART == 1 && K.cost && lane == 0) K.cost[e] = HEAVY ? (int)hv.evalSum : (int)v;
         // did this step need the four offset ground casts? (next step's centre pass then carries them along)
+#ifdef SGE_DEBUG_RAYS
+        if (PART == 1 && lane == 0 && e == 42) printf("OEND e %d hintWas %d sampled %d haveCenter %d ctoi %.9g ny %.9g wasNear %d near %d pos %.9g\n", e, (int)K.hint[e], ms.sampled, ms.haveCenter, ms.centerHit.toi, ms.centerHit.triNormal.y, ms.wasGroundedNear, ms.nearGround, ms.position.x);
+#endif
         if (PART == 1 && K.hint && lane == 0) K.hint[e] = (uint8_t)(ms.sampled != 0);
     }
     if (K.stats) {
@@ -1628,21 +1665,492 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? 4 
     }
 }
 
+// ---------------------------------------------------------------------------
+// move_group_kernel: part 1 of the step for kGroup characters per wavefront
+// ---------------------------------------------------------------------------
+// With one character per wavefront the sweep trips — two thirds of the kernel's vector instructions — run with ~14 of 64
+// lanes active: a cast pass meets ~10 (ray, triangle) pairs once the exact rejects have run (rocprofv3: SQ_THREAD_CYCLES_VALU /
+// (64 x SQ_INSTS_VALU) = 0.30, profiles/r2_move_pmc_*.json). Here a wavefront steps kGroup characters together: per round every
+// unfinished character sets up its next cast pass (whatever its phase: slide, ground centre, ground samples) and traverses for
+// its work items, all items go into ONE queue tagged with their ray slot, the 64 lanes sweep that queue together, then every
+// character consumes its rays' results. Each character still performs exactly its own sequence of queries and arithmetic
+// (ray slots [g * kMaxRays, +kMaxRays) and the LDS state arrays carry its place g), so results stay bit-identical.
+__shared__ int sGroupCost[kGroup]; // distance evaluations of each character's casts this step
+__shared__ int sGroupE[kGroup];    // character index of every member (-1: none)
+// Near pass / far pass of the ground-centre cast: the 200-unit fall probe (Systems.swift:855-866) shares its origin with the 0.8-unit
+// snap cast, so the triangles around the capsule are gathered and swept first (box of the snap ray and the offset rays; the fall
+// probe gets its items from the same candidates), and only then is the rest of the fall probe's box traversed — clipped to the
+// best hit found so far. A grounded character's clipped box lies inside the near box and the far pass disappears, with it the walk
+// through every wall triangle below a ledge. Exact: a triangle entirely below the capsule's lowest point at t = bestToi (+ margin)
+// cannot be touched before bestToi, and a later or equal hit with a higher visit rank never wins.
+__shared__ F3 sNearMin[kGroup], sNearMax[kGroup];
+
+// One cast pass of character g, rays rb .. rb + R - 1 already in sh.rayFrom / sh.rayDelta: the per-ray setup of waveCastRays
+// (CollisionQuery.swift:1021-1035). Returns the number of valid rays and their union box.
+__device__ __forceinline__ int groupSetupRays(const DevCollision& col, int rb, int R, float radius, float halfHeight, bool blockingOnly,
+                                              bool hasMinNormalY, float minNormalY, F3& minP, F3& maxP) {
+    const int lane = laneId();
+    if (lane < R) {
+        const int r = rb + lane;
+        F3 from = sh.rayFrom[r], delta = sh.rayDelta[r];
+        float len = length(delta);
+        bool valid = !(len < 1e-6f) && col.root >= 0; // :987-988, :1020
+        F3 dir = delta / len;
+        F3 up{0, 1, 0};
+        F3 a0 = from + up * halfHeight, b0 = from - up * halfHeight;
+        F3 a1 = a0 + delta, b1 = b0 + delta;
+        F3 mn = vmin(vmin(a0, b0), vmin(a1, b1));
+        F3 mx = vmax(vmax(a0, b0), vmax(a1, b1));
+        F3 ext{radius, radius, radius};
+        sh.rayMin[r] = mn - ext; sh.rayMax[r] = mx + ext;
+        sh.rayDir[r] = dir; sh.rayLen[r] = len; sh.rayValid[r] = valid ? 1 : 0;
+        sh.rayVertical[r] = (delta.x == 0.0f && delta.z == 0.0f) ? 1 : 0;
+        const float minAdv = smax(radius * 0.02f, 1e-4f);
+        int maxIter = (int)ceilf(len / minAdv) + 1; // :1296
+        sh.rayMaxIter[r] = maxIter < 256 ? maxIter : 256;
+        sh.rayKey[r] = ((unsigned long long)__float_as_uint(len) << 32) | 0xffffffffull;
+        sh.rayRadius[r] = radius; sh.rayHalfHeight[r] = halfHeight; sh.rayMinNormalY[r] = minNormalY;
+        sh.rayFilter[r] = (blockingOnly ? 1 : 0) | (hasMinNormalY ? 2 : 0);
+    }
+    __syncthreads();
+    minP = F3{kFloatMax, kFloatMax, kFloatMax}; maxP = F3{-kFloatMax, -kFloatMax, -kFloatMax};
+    int nValid = 0;
+    for (int r = rb; r < rb + R; ++r) {
+        if (!sh.rayValid[r]) continue;
+        minP = vmin(minP, sh.rayMin[r]); maxP = vmax(maxP, sh.rayMax[r]);
+        nValid += 1;
+    }
+    return nValid;
+}
+
+// Sweeps every queued (ray slot, triangle) item: the streaming lane state machine of waveCastRays with the capsule and the
+// acceptance filters taken from the item's ray slot. Leaves the queue empty.
+__device__ __forceinline__ void groupSweep(const DevCollision& col, int& itemCount, WaveStats& st) {
+    const float contactEps = 1e-5f;
+    int phase = PH_DONE, myRay = 0, iter = 0, refineK = 0, maxIter = 0;
+    Tri tri;
+    tri.v0 = tri.v1 = tri.v2 = F3{0, 0, 0}; tri.triIndex = -1; tri.rank = 0x7fffffff;
+    F3 triNormal{0, 0, 0};
+    float t = 0, lastSafeT = 0, lo = 0, hi = 0, tEval = 0, len = 0, bestToi = 0, radius = 0, halfHeight = 0, minAdvance = 0;
+    unsigned evals = 0; // of this lane's current item
+    while (true) {
+        const unsigned long long idleMask = __ballot(phase == PH_DONE);
+        const int nIdle = __popcll(idleMask);
+        if (nIdle > 0 && itemCount > 0) {
+            const int take = nIdle < itemCount ? nIdle : itemCount;
+            const int p = prefixCount(idleMask);
+            if (phase == PH_DONE && p < take) {
+                if (evals) { atomicAdd(&sGroupCost[myRay / kMaxRays], (int)evals); st.evals += evals; evals = 0; }
+                const int it = sh.items[itemCount - 1 - p];
+                myRay = (unsigned)it >> kItemRayShift;
+                tri = loadTri(col, it & kItemSlotMask);
+                triNormal = normalize(cross(tri.v1 - tri.v0, tri.v2 - tri.v0));
+                len = sh.rayLen[myRay];
+                maxIter = sh.rayMaxIter[myRay];
+                radius = sh.rayRadius[myRay]; halfHeight = sh.rayHalfHeight[myRay];
+                minAdvance = smax(radius * 0.02f, 1e-4f); // :1295
+                bestToi = __uint_as_float((unsigned)(sh.rayKey[myRay] >> 32));
+                phase = PH_MARCH;
+                t = 0; lastSafeT = 0; lo = 0; hi = 0; tEval = 0; iter = 0; refineK = 0;
+            }
+            itemCount -= take;
+            __syncthreads();
+        } else if (nIdle == kWave) {
+            break;
+        }
+        st.trips += 1;
+        if (phase == PH_MARCH) {
+            if (iter >= maxIter || t > len || lastSafeT > bestToi) phase = PH_DONE;
+            else { iter += 1; tEval = t; }
+        } else if (phase == PH_REFINE) {
+            if (lo > bestToi) phase = PH_DONE;
+            else tEval = 0.5f * (lo + hi);
+        }
+        bool finished = false;
+        unsigned long long myKey = ~0ull;
+        CastRec rec;
+        rec.toi = 0; rec.position = rec.normal = rec.triNormal = F3{0, 0, 0}; rec.triIndex = -1;
+        if (phase != PH_DONE) {
+            evals += 1;
+            const F3 from = sh.rayFrom[myRay], dir = sh.rayDir[myRay];
+            F3 center = from + dir * tEval;
+            F3 segP, triP;
+            float dist = segmentTriangleDistance(center, halfHeight, tri.v0, tri.v1, tri.v2, segP, triP);
+            if (phase == PH_MARCH) {
+                if (dist <= radius + contactEps) {
+                    float c0 = smax(0.0f, smin(lastSafeT, len));
+                    float c1 = smax(0.0f, smin(t, len));
+                    lo = smin(c0, c1);
+                    hi = smax(c0, c1);
+                    if (hi - lo < 1e-5f) { phase = PH_FINAL; tEval = hi; }
+                    else { phase = PH_REFINE; refineK = 0; }
+                } else {
+                    lastSafeT = t;
+                    float advance = smax(dist - radius, minAdvance);
+                    if (advance <= 0) t += minAdvance; else t += advance;
+                }
+            } else if (phase == PH_REFINE) {
+                if (dist <= radius) hi = tEval; else lo = tEval;
+                refineK += 1;
+                if (refineK == 10) { phase = PH_FINAL; tEval = hi; }
+            } else { // PH_FINAL :1325-1346
+                float tHit = tEval;
+                F3 nrm;
+                if (dist < 1e-6f) nrm = dot(triNormal, dir) > 0 ? -triNormal : triNormal;
+                else nrm = normalize(segP - triP);
+                F3 triN = triNormal;
+                if (dot(triN, nrm) < 0) triN = -triN;
+                phase = PH_DONE;
+                const int filter = sh.rayFilter[myRay];
+                bool ok = tHit < len;
+                if (ok && (filter & 1)) {
+                    F3 delta = sh.rayDelta[myRay];
+                    ok = !(dot(delta, nrm) >= 0) && !(dot(delta, triN) >= 0);
+                }
+                if (ok && (filter & 2)) ok = !(triN.y < sh.rayMinNormalY[myRay]);
+                if (ok) {
+                    rec = CastRec{tHit, triP, nrm, triN, tri.triIndex};
+                    myKey = ((unsigned long long)__float_as_uint(tHit) << 32) | (unsigned)tri.rank;
+                    atomicMin(&sh.rayKey[myRay], myKey);
+                    finished = true;
+                }
+            }
+        }
+        if (__any(finished)) {
+            __syncthreads();
+            if (finished && sh.rayKey[myRay] == myKey) sh.rayRec[myRay] = rec;
+            bestToi = __uint_as_float((unsigned)(sh.rayKey[myRay] >> 32));
+        }
+    }
+    if (evals) { atomicAdd(&sGroupCost[myRay / kMaxRays], (int)evals); st.evals += evals; }
+    __syncthreads();
+}
+
+// Traversal of one cast pass (rays rb .. rb + R - 1, union box minP / maxP): its (ray, triangle) items join the shared queue;
+// the queue is swept whenever the next batch might not fit.
+// skipBox: triangles whose AABB overlaps [skipMin, skipMax] were already handled by an earlier pass of the same rays.
+__device__ __forceinline__ void groupGather(const DevCollision& col, int rb, int R, F3 minP, F3 maxP, float radius, bool hasMinNormalY,
+                                            float minNormalY, uint32_t mask, int& itemCount, WaveStats& st, bool skipBox = false,
+                                            F3 skipMin = F3{0, 0, 0}, F3 skipMax = F3{0, 0, 0}) {
+    const int lane = laneId();
+    int stackSize = initTraversal(col), rangeCount = 0, candCount = 0;
+    __syncthreads();
+    while (stackSize > 0 || rangeCount > 0 || candCount > 0) {
+        while ((stackSize > 0 || rangeCount > 0) && candCount < kWave) expandNodes(col, minP, maxP, mask, stackSize, rangeCount, candCount, st);
+        const int n = candCount < kWave ? candCount : kWave;
+        candCount -= n;
+        st.candidates += n;
+        if (itemCount + kWave * R > kItemCap) groupSweep(col, itemCount, st);
+        int slot = -1;
+        F3 v0{0, 0, 0}, v1{0, 0, 0}, v2{0, 0, 0};
+        if (lane < n) {
+            slot = sh.cand[candCount + lane];
+            const float4* tp = reinterpret_cast<const float4*>(col.tris + slot);
+            float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+            v0 = F3{t0.x, t0.y, t0.z}; v1 = F3{t0.w, t1.x, t1.y}; v2 = F3{t1.z, t1.w, t2.x};
+            if (hasMinNormalY && tooSteepForGroundCast(v0, v1, v2, minNormalY)) { slot = -1; st.pruned += R; }
+        }
+        const F3 bmin = vmin(v0, vmin(v1, v2)), bmax = vmax(v0, vmax(v1, v2));
+        if (skipBox && !boxDisjoint(bmin, bmax, skipMin, skipMax)) slot = -1;
+        for (int r = rb; r < rb + R; ++r) {
+            bool c = slot >= 0 && sh.rayValid[r] && !boxDisjoint(bmin, bmax, sh.rayMin[r], sh.rayMax[r]);
+            if (c && sh.rayVertical[r]) { c = !verticalSweepMisses(sh.rayFrom[r].x, sh.rayFrom[r].z, radius, v0, v1, v2); st.pruned += c ? 0 : 1; }
+            unsigned long long mc = __ballot(c);
+            if (c) sh.items[itemCount + prefixCount(mc)] = (int)(((unsigned)r << kItemRayShift) | (unsigned)slot);
+            itemCount += __popcll(mc);
+        }
+        __syncthreads();
+    }
+}
+
+template <bool AGENTS>
+__global__ __launch_bounds__(kWave, SGE_GROUP_WAVES) void move_group_kernel(MoveLaunch K) {
+    const int lane = laneId();
+    WaveStats st{0, 0, 0, 0, 0, 0, 0};
+    const DevCollision& col = K.col;
+    const float dt = K.dt;
+    // Members of this wavefront. With an order list (characters sorted by last step's cost, most expensive first; the multi-wave
+    // launch's characters left out) wavefront w of W takes ranks w, 2W-1-w, 2W+w, 4W-1-w, ...: one character from every cost
+    // stratum, the expensive end paired with the cheap end, so that no wavefront collects a cluster of expensive neighbours and
+    // the launch's first wavefronts hold the most expensive characters. Without a list: kGroup consecutive characters.
+    unsigned actMask = 0;
+    {
+        const int W = (int)gridDim.x, w = (int)blockIdx.x;
+        // (agent-scope loads: the list was written by the kernels just before this one)
+        const int n = K.order ? __hip_atomic_load(K.orderCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : K.count;
+        for (int g = 0; g < kGroup; ++g) {
+            const int rank = (g & 1) ? (g + 1) * W - 1 - w : g * W + w;
+            int e = -1;
+            if (rank < n) e = K.order ? __hip_atomic_load(K.order + rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : K.first + rank;
+            if (e >= 0) actMask |= 1u << g;
+            if (lane == 0) sGroupE[g] = e;
+        }
+    }
+    if (actMask == 0) return;
+    __syncthreads();
+    long long pT0 = (long long)__builtin_amdgcn_s_memtime(), pGather = 0, pSweep = 0, pConsume = 0, pRounds = 0, pT;
+    for (int g = 0; g < kGroup; ++g) {
+        if (!((actMask >> g) & 1)) continue;
+        const int e = sGroupE[g];
+        const uint32_t* gb = reinterpret_cast<const uint32_t*>(K.crowd.bodies + e);
+        const uint32_t* gp = reinterpret_cast<const uint32_t*>(K.crowd.params + e);
+        const uint32_t* gc = reinterpret_cast<const uint32_t*>(K.crowd.controllers + e);
+        const uint32_t* gs = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(K.scratch) + (size_t)e * kMoveScratchBytes);
+        if (lane < 24) reinterpret_cast<uint32_t*>(&sBodyA[g])[lane] = gb[lane];
+        if (lane < 16) reinterpret_cast<uint32_t*>(&sParamsA[g])[lane] = gp[lane];
+        if (lane < 32) reinterpret_cast<uint32_t*>(&sCtrlA[g])[lane] = gc[lane];
+        if (lane < (int)(sizeof(MoveState) / 4)) reinterpret_cast<uint32_t*>(&msA[g])[lane] = gs[lane];
+    }
+    if (lane < kGroup) sGroupCost[lane] = 0;
+    __syncthreads();
+
+    while (true) {
+        unsigned phasePack = 0; // 4 bits per character: its phase at the head of this round (0xF: nothing to do)
+        unsigned farMask = 0;   // characters whose fall probe still has its far pass to do this round
+        bool any = false;
+        int itemCount = 0;
+        pT = (long long)__builtin_amdgcn_s_memtime();
+        // ---------------- 1. every unfinished character sets up its next cast pass and gathers its work items ----------------
+        for (int g = 0; g < kGroup; ++g) {
+            unsigned myPhase = 0xF;
+            if ((actMask >> g) & 1) {
+                MoveState& ms = msA[g];
+                const sge_controller_params& P = sParamsA[g];
+                const int e = sGroupE[g], rb = g * kMaxRays;
+                if (ms.phase == MP_SLIDE) { // head of the slide loop :1674-1676
+                    float len = length(ms.remaining);
+                    if (ms.it >= P.maxSlideIterations || len < 1e-6f) { __syncthreads(); ms.phase = MP_GROUND_CENTER; __syncthreads(); }
+                }
+                const int phase = ms.phase;
+                if (phase != MP_DONE) {
+                    myPhase = (unsigned)phase;
+                    any = true;
+                    int R = 0;
+                    bool blocking = false;
+                    if (phase == MP_SLIDE) {
+                        blocking = true; R = 1;
+                        sh.rayFrom[rb] = ms.position; sh.rayDelta[rb] = ms.remaining;
+                    } else if (phase == MP_GROUND_CENTER) { // snap cast + fall probe (+ speculative offset casts), see move_kernel
+                        sh.rayFrom[rb] = ms.position; sh.rayFrom[rb + 1] = ms.position;
+                        sh.rayDelta[rb] = P.snapDistance > 0 ? F3{0, -1, 0} * P.snapDistance : F3{0, 0, 0};
+                        sh.rayDelta[rb + 1] = P.fallProbeDistance > 0 ? F3{0, -1, 0} * P.fallProbeDistance : F3{0, 0, 0};
+                        // (the flag goes through readfirstlane: hipcc 7.2 otherwise selects `spec ? 2 : 0` with s_cselect on a stale SCC
+                        // after comparing the loaded hint byte in VCC)
+                        const bool spec = __builtin_amdgcn_readfirstlane((int)(ms.wasGroundedNear && P.snapDistance > 0 && K.hint && K.hint[e] != 0)) != 0;
+                        R = spec ? 6 : 2;
+                        ms.sampleK = spec ? 2 : 0;
+                        if (spec) {
+                            const float offset = P.radius * 0.6f;
+                            const F3 snapDelta = F3{0, -1, 0} * P.snapDistance;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                float ox = k == 0 ? offset : (k == 1 ? -offset : 0.0f);
+                                float oz = k == 2 ? offset : (k == 3 ? -offset : 0.0f);
+                                sh.rayFrom[rb + 2 + k] = ms.position + F3{ox, 0, oz};
+                                sh.rayDelta[rb + 2 + k] = snapDelta;
+                            }
+                        }
+                    } else if (phase == MP_GROUND_SAMPLE && ms.sampleK == 0) { // the four offset casts of :898-921
+                        R = 4;
+                        const float offset = P.radius * 0.6f;
+                        const F3 snapDelta = F3{0, -1, 0} * P.snapDistance;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float ox = k == 0 ? offset : (k == 1 ? -offset : 0.0f);
+                            float oz = k == 2 ? offset : (k == 3 ? -offset : 0.0f);
+                            sh.rayFrom[rb + k] = ms.position + F3{ox, 0, oz};
+                            sh.rayDelta[rb + k] = snapDelta;
+                        }
+                    }
+                    __syncthreads();
+                    if (R > 0) {
+                        F3 minP, maxP;
+                        const int nValid = groupSetupRays(col, rb, R, P.radius, P.halfHeight, blocking, !blocking, P.minGroundDot, minP, maxP);
+                        if (nValid > 0) {
+                            st.queries += nValid;
+                            if (phase == MP_GROUND_CENTER && sh.rayValid[rb] && sh.rayValid[rb + 1]) {
+                                // near pass: everything but the fall probe decides the traversal box
+                                F3 nMin = sh.rayMin[rb], nMax = sh.rayMax[rb];
+                                for (int r = rb + 2; r < rb + R; ++r)
+                                    if (sh.rayValid[r]) { nMin = vmin(nMin, sh.rayMin[r]); nMax = vmax(nMax, sh.rayMax[r]); }
+                                __syncthreads();
+                                sNearMin[g] = nMin; sNearMax[g] = nMax;
+                                farMask |= 1u << g;
+                                minP = nMin; maxP = nMax;
+                            }
+                            groupGather(col, rb, R, minP, maxP, P.radius, !blocking, P.minGroundDot, P.collisionMask, itemCount, st);
+                        }
+                    }
+                }
+            }
+            phasePack |= myPhase << (4 * g);
+        }
+        if (!any) break;
+        pRounds += 1;
+        pGather += (long long)__builtin_amdgcn_s_memtime() - pT; pT = (long long)__builtin_amdgcn_s_memtime();
+        // ---------------- 2. all lanes sweep all characters' items ----------------
+        groupSweep(col, itemCount, st);
+        pSweep += (long long)__builtin_amdgcn_s_memtime() - pT; pT = (long long)__builtin_amdgcn_s_memtime();
+        // ---------------- 2b. far pass of the fall probes, clipped to what the near pass found ----------------
+        if (farMask) {
+            for (int g = 0; g < kGroup; ++g) {
+                if (!((farMask >> g) & 1)) continue;
+                const sge_controller_params& P = sParamsA[g];
+                const int r = g * kMaxRays + 1;
+                const F3 from = sh.rayFrom[r];
+                const float len = sh.rayLen[r];
+                float reach = len;
+                if (rayHit(r)) reach = smin(len, __uint_as_float((unsigned)(sh.rayKey[r] >> 32)) + (0.05f + 1e-4f * fabsf(from.y)));
+                // the capsule's AABB swept over [0, reach] along -Y
+                const F3 ext{P.radius, P.radius, P.radius};
+                const F3 fMin = F3{from.x, from.y - P.halfHeight - reach, from.z} - ext;
+                const F3 fMax = F3{from.x, from.y + P.halfHeight, from.z} + ext;
+                const F3 nMin = sNearMin[g], nMax = sNearMax[g];
+                if (fMin.y >= nMin.y) continue; // inside the near box (same x / z extent: same origin and capsule)
+                __syncthreads();
+                sh.rayMin[r] = vmax(sh.rayMin[r], fMin); sh.rayMax[r] = vmin(sh.rayMax[r], fMax);
+                __syncthreads();
+                groupGather(col, r, 1, sh.rayMin[r], sh.rayMax[r], P.radius, true, P.minGroundDot, P.collisionMask, itemCount, st, true, nMin, nMax);
+            }
+            groupSweep(col, itemCount, st);
+        }
+#ifdef SGE_DEBUG_RAYS
+        for (int g = 0; g < kGroup; ++g) {
+            const int phase = (int)((phasePack >> (4 * g)) & 0xF);
+            const int e = sGroupE[g];
+            if (lane == 0 && (e == 42) && (phase == MP_GROUND_CENTER || phase == MP_GROUND_SAMPLE)) {
+                printf("G e %d phase %d sampleK %d pos %.9g %.9g %.9g pack %x:", e, phase, msA[g].sampleK, msA[g].position.x, msA[g].position.y, msA[g].position.z, phasePack);
+                for (int r = g * kMaxRays; r < g * kMaxRays + 6; ++r) printf(" [%d toi %.9g tri %d ny %.6g from %.6g %.6g]", rayHit(r) ? 1 : 0, sh.rayRec[r].toi, sh.rayRec[r].triIndex, sh.rayRec[r].triNormal.y, sh.rayFrom[r].x, sh.rayFrom[r].z);
+                printf("\n");
+            }
+        }
+#endif
+        // ---------------- 3. every character consumes its rays ----------------
+        for (int g = 0; g < kGroup; ++g) {
+            const int phase = (int)((phasePack >> (4 * g)) & 0xF);
+            if (phase == 0xF) continue;
+            MoveState& ms = msA[g];
+            const sge_controller_params& P = sParamsA[g];
+            if (phase == MP_SLIDE) {
+                if (AGENTS) { // AgentSweepSolver.bestHit :1053-1091 (independent of the static hit)
+                    const bool hasAgent = (P.agentFlags & SGE_AGENT_PRESENT) != 0;
+                    const bool selfSolid = hasAgent && (P.agentFlags & SGE_AGENT_SOLID);
+                    if ((K.stages & SGE_STAGE_AGENTS) && selfSolid && K.agents.all != nullptr) {
+                        const F3 remaining = ms.remaining;
+                        const float selfRadius = (hasAgent && (P.agentFlags & SGE_AGENT_RADIUS_OVERRIDE)) ? P.agentRadiusOverride : P.radius;
+                        float aToi = 0; F3 aNormal{0, 0, 0};
+                        bool have = waveAgentBestHit(K.agents, ms.position, remaining, length(remaining), ms.baseMoveLen, dt,
+                                                     K.agents.selfOffset + sGroupE[g], selfRadius, P.halfHeight, aToi, aNormal);
+                        __syncthreads();
+                        ms.aHave = have ? 1 : 0; ms.aToi = aToi; ms.aNormal = aNormal;
+                        __syncthreads();
+                    }
+                }
+                consumeSlide(g);
+            } else if (phase == MP_GROUND_CENTER) consumeGroundCenter(g);
+            else if (phase == MP_GROUND_SAMPLE) consumeGroundSample(g);
+            __syncthreads();
+            if (ms.phase == MP_GROUND_EVAL) { groundEval(g); __syncthreads(); }
+            // the offset casts rode along with the centre pass: their results are already there
+            if (ms.phase == MP_GROUND_SAMPLE && ms.sampleK != 0) { consumeGroundSample(g); __syncthreads(); }
+            if (ms.phase == MP_FINISH) { finishStep(g); __syncthreads(); }
+        }
+        pConsume += (long long)__builtin_amdgcn_s_memtime() - pT;
+    }
+    if (K.waveProf && lane == 0) {
+        unsigned long long* w = K.waveProf + (size_t)blockIdx.x * 8;
+        w[0] = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - pT0); w[1] = (unsigned long long)pGather; w[2] = (unsigned long long)pSweep;
+        w[3] = (unsigned long long)pConsume; w[4] = (unsigned long long)pRounds; w[5] = st.trips; w[6] = st.steps; w[7] = (unsigned long long)pT0;
+    }
+
+    // ---------------- write-back ----------------
+    for (int g = 0; g < kGroup; ++g) {
+        if (!((actMask >> g) & 1)) continue;
+        const int e = sGroupE[g];
+        MoveState& ms = msA[g];
+        if (ms.phase == MP_DONE) {
+            D3 velocity = ms.velocity;
+            __syncthreads();
+            sBodyA[g].linearVelocity[0] = velocity.x; sBodyA[g].linearVelocity[1] = velocity.y; sBodyA[g].linearVelocity[2] = velocity.z;
+        }
+        __syncthreads();
+        uint32_t* gb = reinterpret_cast<uint32_t*>(K.crowd.bodies + e);
+        uint32_t* gc = reinterpret_cast<uint32_t*>(K.crowd.controllers + e);
+        if (lane < 24) gb[lane] = reinterpret_cast<const uint32_t*>(&sBodyA[g])[lane];
+        if (lane < 32) gc[lane] = reinterpret_cast<const uint32_t*>(&sCtrlA[g])[lane];
+        if (lane == 0) {
+#ifdef SGE_DEBUG_RAYS
+            if (e == 42) printf("GEND e %d hintWas %d sampled %d haveCenter %d ctoi %.9g ny %.9g wasNear %d near %d pos %.9g\n", e, (int)K.hint[e], ms.sampled, ms.haveCenter, ms.centerHit.toi, ms.centerHit.triNormal.y, ms.wasGroundedNear, ms.nearGround, ms.position.x);
+#endif
+            if (K.cost) K.cost[e] = sGroupCost[g];
+            if (K.hint) K.hint[e] = (uint8_t)(ms.sampled != 0);
+        }
+    }
+    if (K.stats) {
+        unsigned v = st.evals, pr = st.pruned; // per-lane counts
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o, kWave); pr += __shfl_xor(pr, o, kWave); }
+        if (lane == 0) {
+            unsigned long long* sp = statShard(K.stats);
+            if (st.queries) atomicAdd(&sp[0], (unsigned long long)st.queries);
+            if (st.candidates) atomicAdd(&sp[1], (unsigned long long)st.candidates);
+            if (v) atomicAdd(&sp[2], (unsigned long long)v);
+            if (st.overflow) atomicAdd(&sp[3], (unsigned long long)st.overflow);
+            if (st.steps) atomicAdd(&sp[4], (unsigned long long)st.steps);
+            if (st.trips) atomicAdd(&sp[5], (unsigned long long)st.trips);
+            if (pr) atomicAdd(&sp[6], (unsigned long long)pr);
+        }
+    }
+}
+
 // Picks this step's heavy characters by last step's sweep cost: flags[e] = 1 and an entry in the heavy list (at most
-// heavyCap; the rest stay with the one-wave launch). counts[1] is zeroed before the launch; list order is arbitrary
-// (atomics) and results do not depend on it.
+// heavyCap; the rest stay with the grouped launch). counts[1] is zeroed before the launch; list order is arbitrary
+// (atomics) and results do not depend on it. Everybody else is counted into a histogram of cost classes for the order list.
+constexpr int kCostBuckets = 32;
+__device__ __forceinline__ int costBucket(int cost) { const int b = cost >> 7; return b < 0 ? 0 : (b >= kCostBuckets ? kCostBuckets - 1 : b); }
 __global__ void classify_kernel(const int* cost, int first, int count, int threshold, int heavyCap, int* lists, int* counts,
-                                uint8_t* flags) {
+                                uint8_t* flags, int* hist) {
+    __shared__ int h[kCostBuckets];
+    if (threadIdx.x < kCostBuckets) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) {
+        const int e = first + i;
+        uint8_t heavy = 0;
+        if (threshold >= 0 && cost[e] > threshold) {
+            int pos = atomicAdd(&counts[1], 1);
+            if (pos < heavyCap) { lists[count + pos] = e; heavy = 1; }
+            else atomicSub(&counts[1], 1);
+        }
+        flags[e] = heavy;
+        if (!heavy) atomicAdd(&h[costBucket(cost[e])], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < kCostBuckets && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+// hist[0..32) -> start of every class in the order list, most expensive class first (hist[32..64) = scatter cursors); zeroes the
+// histogram for the next step; counts[0] = number of listed characters. One lane per class, loads with agent scope: written as a
+// one-thread loop hipcc 7.2 turns the reads into scalar loads (s_load_dwordx16) and issues the zeroing vector stores of the same
+// words before those loads have returned.
+__global__ void order_scan_kernel(int* hist, int* counts) {
+    const int lane = threadIdx.x;
+    const int b = kCostBuckets - 1 - lane; // lane 0 = most expensive class
+    int c = 0;
+    if (lane < kCostBuckets) c = __hip_atomic_load(&hist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane < kCostBuckets) { hist[kCostBuckets + b] = incl - c; hist[b] = 0; }
+    if (lane == kCostBuckets - 1) counts[0] = incl;
+}
+__global__ void order_scatter_kernel(const int* cost, int first, int count, const uint8_t* flags, int* hist, int* order) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const int e = first + i;
-    uint8_t heavy = 0;
-    if (cost[e] > threshold) {
-        int pos = atomicAdd(&counts[1], 1);
-        if (pos < heavyCap) { lists[count + pos] = e; heavy = 1; }
-        else atomicSub(&counts[1], 1);
-    }
-    flags[e] = heavy;
+    if (!flags[e]) order[atomicAdd(&hist[kCostBuckets + costBucket(cost[e])], 1)] = e;
 }
 
 void launch_move(const MoveLaunch& L, hipStream_t s) {
@@ -1650,29 +2158,37 @@ void launch_move(const MoveLaunch& L, hipStream_t s) {
     hipLaunchKernelGGL((move_kernel<0, false>), dim3(L.count), dim3(kWave), 0, s, L);
     if (!(L.stages & SGE_STAGE_MOVE)) return;
     const bool agents = (L.stages & SGE_STAGE_AGENTS) && L.agents.all;
-    if (!L.lists) {
-        MoveLaunch N = L;
-        N.heavyFlags = nullptr;
-        if (agents) hipLaunchKernelGGL((move_kernel<1, true>), dim3(L.count), dim3(kWave), 0, s, N);
-        else hipLaunchKernelGGL((move_kernel<1, false>), dim3(L.count), dim3(kWave), 0, s, N);
-        return;
-    }
-    // heavy characters first, on their own stream, so that their long single-character sweeps overlap the rest
-    (void)hipMemsetAsync(L.listCounts, 0, 2 * sizeof(int), s);
-    hipLaunchKernelGGL(classify_kernel, dim3((L.count + 255) / 256), dim3(256), 0, s, L.cost, L.first, L.count, L.heavyThreshold,
-                       L.heavyCap, L.lists, L.listCounts, L.heavyFlags);
-    (void)hipEventRecord(L.evClassified, s);
-    (void)hipStreamWaitEvent(L.heavyStream, L.evClassified, 0);
-    MoveLaunch H = L;
-    H.list = L.lists + L.count; H.listCount = L.listCounts + 1;
-    const int heavyGrid = L.count < L.heavyCap ? L.count : L.heavyCap;
-    if (agents) hipLaunchKernelGGL((move_kernel<1, true, true>), dim3(heavyGrid), dim3(kWave * kHeavyWaves), 0, L.heavyStream, H);
-    else hipLaunchKernelGGL((move_kernel<1, false, true>), dim3(heavyGrid), dim3(kWave * kHeavyWaves), 0, L.heavyStream, H);
-    (void)hipEventRecord(L.evHeavyDone, L.heavyStream);
+    static const bool grouped = !(getenv("SGE_MOVE_GROUP") && atoi(getenv("SGE_MOVE_GROUP")) == 0);
     static const int ldsPad = getenv("SGE_MOVE_LDS_PAD") ? atoi(getenv("SGE_MOVE_LDS_PAD")) : 0; // experiments: caps workgroups per CU
-    if (agents) hipLaunchKernelGGL((move_kernel<1, true>), dim3(L.count), dim3(kWave), 0, s, L); // skips flagged characters
+    const int groups = (L.count + kGroup - 1) / kGroup;
+    const int blocks = (L.count + 255) / 256;
+    // last step's costs -> heavy list (multi-wave launch) + order list of everybody else (grouped launch)
+    (void)hipMemsetAsync(L.listCounts, 0, 2 * sizeof(int), s);
+    hipLaunchKernelGGL(classify_kernel, dim3(blocks), dim3(256), 0, s, L.cost, L.first, L.count, L.heavyThreshold, L.heavyCap, L.lists,
+                       L.listCounts, L.heavyFlags, L.orderHist);
+    MoveLaunch G = L;
+    if (grouped) {
+        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, s, L.orderHist, L.listCounts);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, s, L.cost, L.first, L.count, L.heavyFlags, L.orderHist, L.lists);
+        G.order = L.lists; G.orderCount = L.listCounts;
+    }
+    const bool heavy = L.heavyThreshold >= 0;
+    if (heavy) { // heavy characters first, on their own stream, so that their long single-character sweeps overlap the rest
+        (void)hipEventRecord(L.evClassified, s);
+        (void)hipStreamWaitEvent(L.heavyStream, L.evClassified, 0);
+        MoveLaunch H = L;
+        H.list = L.lists + L.count; H.listCount = L.listCounts + 1;
+        const int heavyGrid = L.count < L.heavyCap ? L.count : L.heavyCap;
+        if (agents) hipLaunchKernelGGL((move_kernel<1, true, true>), dim3(heavyGrid), dim3(kWave * kHeavyWaves), 0, L.heavyStream, H);
+        else hipLaunchKernelGGL((move_kernel<1, false, true>), dim3(heavyGrid), dim3(kWave * kHeavyWaves), 0, L.heavyStream, H);
+        (void)hipEventRecord(L.evHeavyDone, L.heavyStream);
+    }
+    if (grouped) { // kGroup characters per wavefront, members drawn from the order list
+        if (agents) hipLaunchKernelGGL((move_group_kernel<true>), dim3(groups), dim3(kWave), ldsPad, s, G);
+        else hipLaunchKernelGGL((move_group_kernel<false>), dim3(groups), dim3(kWave), ldsPad, s, G);
+    } else if (agents) hipLaunchKernelGGL((move_kernel<1, true>), dim3(L.count), dim3(kWave), 0, s, L); // skips flagged characters
     else hipLaunchKernelGGL((move_kernel<1, false>), dim3(L.count), dim3(kWave), ldsPad, s, L);
-    (void)hipStreamWaitEvent(s, L.evHeavyDone, 0);
+    if (heavy) (void)hipStreamWaitEvent(s, L.evHeavyDone, 0);
 }
 
 // ---- batched single queries (the CollisionQuery facade) ---------------------

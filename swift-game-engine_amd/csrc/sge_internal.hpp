@@ -221,6 +221,9 @@ struct MoveLaunch {
     int heavyThreshold, heavyCap;
     hipStream_t heavyStream; hipEvent_t evClassified, evHeavyDone;
     const int* list; const int* listCount; // what a part-1 launch iterates over (set by launch_move)
+    const int* order; const int* orderCount; // grouped launch: characters sorted by last step's cost (device), its length
+    int* orderHist;                        // [64] histogram / cursors of the order list (zero between steps)
+    unsigned long long* waveProf;          // diagnostics (SGE_WAVE_PROF=1): [ceil(count / kGroup)][8] cycles of each wavefront of move_group_kernel
 };
 constexpr int kMoveScratchBytes = 256;
 constexpr int kTraversalStackCap = 256; // LDS stack of pending wide nodes per query (sge_ccd.hip)
