@@ -53,7 +53,9 @@ def main():
     ap.add_argument("--assets", choices=["synthetic", "real"], default=None,
                     help="shorthand of round 1: real = --mesh ybot with the cheese / merged scene, synthetic = --mesh synthetic --scene synthetic")
     ap.add_argument("--layout", choices=["packed", "padded16"], default="packed")
-    ap.add_argument("--overlap", action="store_true", help="skin(n) on a second stream, overlapping move(n+1)")
+    ap.add_argument("--overlap", dest="overlap", action="store_true", default=True,
+                    help="(default) skin(n) runs on a second stream beside move(n+1) + pose(n+1): SGE_OPT_OVERLAP_SKIN")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false", help="one stream, stages strictly back to back")
     ap.add_argument("--refit", action="store_true",
                     help="also refit every character's acceleration structure after skinning (SURVEY 8 f2, the reference's next step; "
                          "not part of BASELINE.json's metric, so off by default); adds a `refit` object to the JSON line")
@@ -156,6 +158,13 @@ def main():
 
     prof = eng.profile_read(reset=True)
     stats = eng.move_stats(reset=True)
+    # the LBS kernel alone on the idle chip (outside the timed region): with --overlap its launches inside the timed region share
+    # the SIMDs with the next step's collision kernels and stretch; this is the kernel's own rate
+    alone_launches = 20
+    for _ in range(alone_launches):
+        eng.tick(dt=0.0, stages=abi.STAGE_SKIN)
+    eng.synchronize()
+    alone = eng.profile_read(reset=True)
     eng.set_option(abi.OPT_PROFILE, 0)
 
     V, B = eng.vertex_count, eng.bone_count
@@ -168,6 +177,8 @@ def main():
     lbs_bytes = count * (40.0 * V + B * 64.0) + 64.0 * V
     lbs_ms = prof.skin_ms / max(prof.skin_launches, 1)
     achieved = lbs_bytes / (lbs_ms * 1e-3) / 1e9 if lbs_ms > 0 else 0.0
+    alone_ms = alone.skin_ms / max(alone.skin_launches, 1)
+    alone_gbs = lbs_bytes / (alone_ms * 1e-3) / 1e9 if alone_ms > 0 else 0.0
     traffic = _recorded_traffic(count, V)
     value = n_total * args.steps / elapsed
     out = {
@@ -199,7 +210,11 @@ def main():
         },
         "roofline": {"bound": "hbm", "kernel": "skin_kernel (4-weight LBS)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "bytes_per_launch": lbs_bytes, "ms_per_launch": lbs_ms},
+                     "bytes_per_launch": lbs_bytes, "ms_per_launch": lbs_ms,
+                     "note": "HIP events on the skin stream over the timed region" + (
+                         "; the launches overlap the next step's collision + pose kernels (see lbs_alone for the kernel by itself)" if args.overlap and mode == "ccd" else "")},
+        "lbs_alone": {"ms_per_launch": alone_ms, "achieved": alone_gbs, "frac": alone_gbs / HBM_PEAK_GBS, "unit": "GB/s", "launches": alone_launches,
+                      "note": "the same kernel launched by itself after the timed region"},
         "whole_path_hbm_frac": (value / world) * (40.0 * V + 64.0 * V / count + 2 * B * 64.0 + 640.0) / (HBM_PEAK_GBS * 1e9),
         "kernels_ms_per_step": {"move_ccd": prof.move_ms / args.steps, "pose": prof.pose_ms / args.steps,
                                 "lbs": prof.skin_ms / args.steps, "agents_grid": prof.agents_ms / args.steps},

@@ -55,6 +55,7 @@ struct sge_context {
     hipEvent_t evClassified = nullptr, evHeavyDone = nullptr, evTablesCopied = nullptr;
     int placementProbes = 8;   // candidate placements of the skinned output streams compared at allocation time
     float placementMs = 0; int placementTried = 0;
+    int overlapSkinWorkgroups = 3; // LBS workgroups per CU while it shares the chip with the next step's collision kernels
     int heavyThreshold = 4000; // distance evaluations in a character's last step above which it takes the multi-wave kernel; < 0: off
     bool skinPending = false, overlapSkin = false, customStream = false;
     // options
@@ -377,10 +378,10 @@ sge_context* sge_context_create(int device_index) {
     sge_context* c = new sge_context();
     c->device = device_index;
     if (getenv("SGE_HEAVY_THRESHOLD")) c->heavyThreshold = atoi(getenv("SGE_HEAVY_THRESHOLD")); // experiments
+    if (getenv("SGE_OVERLAP_SKIN_WORKGROUPS")) c->overlapSkinWorkgroups = atoi(getenv("SGE_OVERLAP_SKIN_WORKGROUPS"));
     // the latency-bound collision / pose launches go first when they compete with a streaming skin launch (overlap option)
     int prLeast = 0, prGreatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest);
-    if (getenv("SGE_SKIN_STREAM_HIGH")) std::swap(prLeast, prGreatest); // experiment: the streaming kernel's queue first
     if (hipStreamCreateWithPriority(&c->ownStream, hipStreamNonBlocking, prGreatest) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
     c->stream = c->ownStream;
     if (hipStreamCreateWithPriority(&c->skinStream, hipStreamNonBlocking, prLeast) != hipSuccess ||
@@ -1110,7 +1111,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         } else {
             {
                 Bracket br(c, &c->evSkin, ss);
-                launch_skin(L, ss);
+                launch_skin(L, ss, overlap ? c->overlapSkinWorkgroups : 0);
             }
             if (refit) { // RTAccelerationBuilder.build is enqueued right behind the skinning encoder (RayTracingScene.swift:35-43)
                 Bracket br(c, &c->evBlas, ss);

@@ -251,7 +251,7 @@ struct SkinLaunch {
     int srcLayout, dstLayout;
     void* outPos; void* outNrm; void* outTan;
 };
-void launch_skin(const SkinLaunch& L, hipStream_t s);
+void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU = 0);
 // one record per RTSkinningJob of a batched encode (device copy)
 struct SkinJobDev {
     const void* srcPos; const void* srcNrm; const void* srcTan; const void* srcIdx; const void* srcWgt;

@@ -58,8 +58,8 @@ struct VertexIn { float3 p, n; float4 t; ushort4 idx; float4 w; };
 template <int SRC_STRIDE>
 __device__ __forceinline__ VertexIn loadVertex(const SkinLaunch& L, int gid) {
     VertexIn v;
-    const float* sp = reinterpret_cast<const float*>(L.srcPos) + (size_t)gid * SRC_STRIDE;
-    const float* sn = reinterpret_cast<const float*>(L.srcNrm) + (size_t)gid * SRC_STRIDE;
+    const float* sp = reinterpret_cast<const float*>(L.srcPos) + (unsigned)gid * SRC_STRIDE;
+    const float* sn = reinterpret_cast<const float*>(L.srcNrm) + (unsigned)gid * SRC_STRIDE;
     v.p = make_float3(sp[0], sp[1], sp[2]);
     v.n = make_float3(sn[0], sn[1], sn[2]);
     v.t = reinterpret_cast<const float4*>(L.srcTan)[gid];
@@ -68,10 +68,20 @@ __device__ __forceinline__ VertexIn loadVertex(const SkinLaunch& L, int gid) {
     return v;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 // One workgroup = one character (or 1/splits of its vertices): the palette is staged once,
 // then the 256 threads walk the vertex stream 256 at a time with the next chunk's source
 // attributes already in flight while the current chunk is transformed and stored.
 // The work of one workgroup: vertices [vBegin, vEnd) of character `c` of launch L (palette L.palettes[c]).
+//
+// LDS palette layout, 12 floats per bone (m_rc = row r, column c of the bone's 3x4 affine part):
+//     (m00 m10 | m01 m11) (m02 m12 | m03 m13) (m20 m21 | m22 m23)
+// so that one ds_read_b128 lands two ready-made register pairs for v_pk_fma_f32: the matrices are blended pair by pair
+// (6 packed ops per influence) and the x / y components of position, normal and tangent come out of packed column sums
+// A*v.x + B*v.y + C*v.z (+ D) without any register shuffling (the row-major layout of round 1 cost ~35 % of the kernel's vector
+// instructions in v_mov_b32). The kernel shares the SIMDs with the collision kernels of the next step (SGE_OPT_OVERLAP_SKIN), where
+// vector-issue slots, not HBM, are the contended resource.
 template <int SRC_STRIDE, int DST_STRIDE>
 __device__ __forceinline__ void skinRange(const SkinLaunch& L, const int c, const int vBegin, const int vEnd, float4* pal) {
     const int tid = threadIdx.x;
@@ -79,102 +89,87 @@ __device__ __forceinline__ void skinRange(const SkinLaunch& L, const int c, cons
     VertexIn cur{};
     if (gid < vEnd) cur = loadVertex<SRC_STRIDE>(L, gid);
 
-    // stage the palette: thread -> one float4 COLUMN (coalesced), scattered into rows
+    // stage the palette: thread -> one float4 COLUMN (coalesced), scattered into the pair layout
     const float4* gp = reinterpret_cast<const float4*>(L.palettes + (size_t)c * L.paletteCount * 16);
     float* palf = reinterpret_cast<float*>(pal);
     for (int i = tid; i < L.paletteCount * 4; i += kSkinBlock) {
         float4 col = gp[i];
         int bone = i >> 2, cc = i & 3;
-        palf[bone * 12 + 0 + cc] = col.x;
-        palf[bone * 12 + 4 + cc] = col.y;
+        palf[bone * 12 + 2 * cc + 0] = col.x;
+        palf[bone * 12 + 2 * cc + 1] = col.y;
         palf[bone * 12 + 8 + cc] = col.z;
     }
     __syncthreads();
 
+    // the character's slice of the three output streams: uniform 64-bit bases, 32-bit per-thread offsets
     const size_t obase = (size_t)L.dstBaseVertex + (size_t)c * L.vertexCount;
+    float* const opBase = reinterpret_cast<float*>(L.outPos) + obase * DST_STRIDE;
+    float* const onBase = reinterpret_cast<float*>(L.outNrm) + obase * DST_STRIDE;
+    v4f* const otBase = reinterpret_cast<v4f*>(L.outTan) + obase;
+    const v4f* P = reinterpret_cast<const v4f*>(pal);
 
-    // one vertex: blend the influences' matrices, transform position / normal / tangent once, stream the result out
+    // one vertex: blend the influences' matrices, transform position / normal / tangent once, stream the result out.
+    // sum_j w_j (M_j v) = (sum_j w_j M_j) v (the Metal kernel transforms per influence and blends the results, RayTracing.metalinc:
+    // 758-775); the first two influences are taken unconditionally with the weight clamped at 0 (a weight <= 0 contributes exactly
+    // nothing, as the reference's `w > 0` test does); the rarer third and fourth stay behind their tests.
     auto skinOne = [&](const VertexIn& v, int g) {
-        const float3 p = v.p, n = v.n;
-        const float3 tv = make_float3(v.t.x, v.t.y, v.t.z);
-#ifdef SGE_SKIN_PER_INFLUENCE
-        // the Metal kernel's literal order: transform by every influence's matrix, then blend the results
-        float3 acc = make_float3(0.f, 0.f, 0.f), nAcc = acc, tAcc = acc;
-#define SGE_INFLUENCE(BONE, WGT)                                              \
-        if ((WGT) > 0.0f) {                                                   \
-            Row3 m = loadRows(pal, (BONE));                                   \
-            float3 a = xform(m, p, 1.0f), b = xform(m, n, 0.0f), d = xform(m, tv, 0.0f); \
-            acc.x += a.x * (WGT); acc.y += a.y * (WGT); acc.z += a.z * (WGT); \
-            nAcc.x += b.x * (WGT); nAcc.y += b.y * (WGT); nAcc.z += b.z * (WGT); \
-            tAcc.x += d.x * (WGT); tAcc.y += d.y * (WGT); tAcc.z += d.z * (WGT); \
-        }
-        SGE_INFLUENCE(v.idx.x, v.w.x)
-        SGE_INFLUENCE(v.idx.y, v.w.y)
-        SGE_INFLUENCE(v.idx.z, v.w.z)
-        SGE_INFLUENCE(v.idx.w, v.w.w)
-#undef SGE_INFLUENCE
-#else
-        // sum_j w_j (M_j v) = (sum_j w_j M_j) v: blend the matrices (12 FMAs per influence), transform once. The first two
-        // influences are taken unconditionally with the weight clamped at 0 (a weight <= 0 contributes exactly nothing, as
-        // the reference's `w > 0` test does); the rarer third and fourth stay behind their tests.
         const float w0 = fmaxf(v.w.x, 0.0f), w1 = fmaxf(v.w.y, 0.0f);
-        Row3 M;
+        v2f A, B, C, D, E, F;
         {
-            const Row3 m = loadRows(pal, v.idx.x);
-            M.r0 = make_float4(m.r0.x * w0, m.r0.y * w0, m.r0.z * w0, m.r0.w * w0);
-            M.r1 = make_float4(m.r1.x * w0, m.r1.y * w0, m.r1.z * w0, m.r1.w * w0);
-            M.r2 = make_float4(m.r2.x * w0, m.r2.y * w0, m.r2.z * w0, m.r2.w * w0);
+            const v4f q0 = P[v.idx.x * 3 + 0], q1 = P[v.idx.x * 3 + 1], q2 = P[v.idx.x * 3 + 2];
+            A = q0.xy * w0; B = q0.zw * w0; C = q1.xy * w0; D = q1.zw * w0; E = q2.xy * w0; F = q2.zw * w0;
         }
-#define SGE_BLEND(BONE, WGT)                                                  \
-        {                                                                     \
-            const Row3 m = loadRows(pal, (BONE));                             \
-            M.r0.x += m.r0.x * (WGT); M.r0.y += m.r0.y * (WGT); M.r0.z += m.r0.z * (WGT); M.r0.w += m.r0.w * (WGT); \
-            M.r1.x += m.r1.x * (WGT); M.r1.y += m.r1.y * (WGT); M.r1.z += m.r1.z * (WGT); M.r1.w += m.r1.w * (WGT); \
-            M.r2.x += m.r2.x * (WGT); M.r2.y += m.r2.y * (WGT); M.r2.z += m.r2.z * (WGT); M.r2.w += m.r2.w * (WGT); \
+#define SGE_BLEND(BONE, WGT)                                                                   \
+        {                                                                                      \
+            const v4f q0 = P[(BONE) * 3 + 0], q1 = P[(BONE) * 3 + 1], q2 = P[(BONE) * 3 + 2];  \
+            A += q0.xy * (WGT); B += q0.zw * (WGT); C += q1.xy * (WGT); D += q1.zw * (WGT);    \
+            E += q2.xy * (WGT); F += q2.zw * (WGT);                                            \
         }
-#if SGE_SKIN_UNCOND >= 2
         SGE_BLEND(v.idx.y, w1)
-#else
-        if (v.w.y > 0.0f) SGE_BLEND(v.idx.y, v.w.y)
-#endif
-#if SGE_SKIN_UNCOND >= 3
-        { const float w2 = fmaxf(v.w.z, 0.0f); SGE_BLEND(v.idx.z, w2) }
-#else
         if (v.w.z > 0.0f) SGE_BLEND(v.idx.z, v.w.z)
-#endif
-#if SGE_SKIN_UNCOND >= 4
-        { const float w3 = fmaxf(v.w.w, 0.0f); SGE_BLEND(v.idx.w, w3) }
-#else
         if (v.w.w > 0.0f) SGE_BLEND(v.idx.w, v.w.w)
-#endif
 #undef SGE_BLEND
-        const float3 acc = xform(M, p, 1.0f), nAcc = xform(M, n, 0.0f), tAcc = xform(M, tv, 0.0f);
-#endif
-        const float3 nn = normalizeFast(nAcc);
-        const float3 tn = normalizeFast(tAcc);
-
-        const size_t o = obase + g;
-        float* op = reinterpret_cast<float*>(L.outPos) + o * DST_STRIDE;
-        float* on = reinterpret_cast<float*>(L.outNrm) + o * DST_STRIDE;
+        // x, y: packed column sums; z: row 2 = (E.x, E.y, F.x, F.y)
+        const v2f pxy = A * v.p.x + (B * v.p.y + (C * v.p.z + D));
+        const v2f pe = E * v2f{v.p.x, v.p.y};
+        const float pz = (pe.x + pe.y) + (F.x * v.p.z + F.y);
+        v2f nxy = A * v.n.x + (B * v.n.y + C * v.n.z);
+        const v2f ne = E * v2f{v.n.x, v.n.y};
+        float nz = (ne.x + ne.y) + F.x * v.n.z;
+        v2f txy = A * v.t.x + (B * v.t.y + C * v.t.z);
+        const v2f te = E * v2f{v.t.x, v.t.y};
+        float tz = (te.x + te.y) + F.x * v.t.z;
+        {
+            const v2f sq = nxy * nxy;
+            const float r = __builtin_amdgcn_rsqf((sq.x + sq.y) + nz * nz);
+            nxy *= r; nz *= r;
+        }
+        {
+            const v2f sq = txy * txy;
+            const float r = __builtin_amdgcn_rsqf((sq.x + sq.y) + tz * tz);
+            txy *= r; tz *= r;
+        }
+        float* op = opBase + (unsigned)g * DST_STRIDE;
+        float* on = onBase + (unsigned)g * DST_STRIDE;
 #ifndef SGE_SKIN_PLAIN_STORES
         // streaming output: non-temporal stores (0.95-1.07 ms vs 1.10 ms with plain stores on MI355X)
         if (DST_STRIDE == 4) {
-            __builtin_nontemporal_store(v4f{acc.x, acc.y, acc.z, 0.f}, reinterpret_cast<v4f*>(op));
-            __builtin_nontemporal_store(v4f{nn.x, nn.y, nn.z, 0.f}, reinterpret_cast<v4f*>(on));
+            __builtin_nontemporal_store(v4f{pxy.x, pxy.y, pz, 0.f}, reinterpret_cast<v4f*>(op));
+            __builtin_nontemporal_store(v4f{nxy.x, nxy.y, nz, 0.f}, reinterpret_cast<v4f*>(on));
         } else {
-            __builtin_nontemporal_store(acc.x, op); __builtin_nontemporal_store(acc.y, op + 1); __builtin_nontemporal_store(acc.z, op + 2);
-            __builtin_nontemporal_store(nn.x, on); __builtin_nontemporal_store(nn.y, on + 1); __builtin_nontemporal_store(nn.z, on + 2);
+            __builtin_nontemporal_store(pxy.x, op); __builtin_nontemporal_store(pxy.y, op + 1); __builtin_nontemporal_store(pz, op + 2);
+            __builtin_nontemporal_store(nxy.x, on); __builtin_nontemporal_store(nxy.y, on + 1); __builtin_nontemporal_store(nz, on + 2);
         }
-        __builtin_nontemporal_store(v4f{tn.x, tn.y, tn.z, v.t.w}, reinterpret_cast<v4f*>(L.outTan) + o);
+        __builtin_nontemporal_store(v4f{txy.x, txy.y, tz, v.t.w}, otBase + (unsigned)g);
 #else
         if (DST_STRIDE == 4) {
-            *reinterpret_cast<float4*>(op) = make_float4(acc.x, acc.y, acc.z, 0.f);
-            *reinterpret_cast<float4*>(on) = make_float4(nn.x, nn.y, nn.z, 0.f);
+            *reinterpret_cast<float4*>(op) = make_float4(pxy.x, pxy.y, pz, 0.f);
+            *reinterpret_cast<float4*>(on) = make_float4(nxy.x, nxy.y, nz, 0.f);
         } else {
-            op[0] = acc.x; op[1] = acc.y; op[2] = acc.z;
-            on[0] = nn.x; on[1] = nn.y; on[2] = nn.z;
+            op[0] = pxy.x; op[1] = pxy.y; op[2] = pz;
+            on[0] = nxy.x; on[1] = nxy.y; on[2] = nz;
         }
-        reinterpret_cast<float4*>(L.outTan)[o] = make_float4(tn.x, tn.y, tn.z, v.t.w);
+        reinterpret_cast<float4*>(otBase)[(unsigned)g] = make_float4(txy.x, txy.y, tz, v.t.w);
 #endif
     };
 
@@ -197,15 +192,16 @@ __device__ __forceinline__ void skinRange(const SkinLaunch& L, const int c, cons
 }
 
 template <int SRC_STRIDE, int DST_STRIDE>
-__global__ __launch_bounds__(kSkinBlock) void skin_kernel(SkinLaunch L, int splits, int vertsPerSplit, int prio) {
+__global__ __launch_bounds__(kSkinBlock) void skin_kernel(SkinLaunch L, int splits, int vertsPerSplit) {
     __shared__ float4 pal[SGE_MAX_BONES * 3];
-    if (prio == 3) __builtin_amdgcn_s_setprio(3);
-    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
-    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
-    const int c = blockIdx.x / splits;
-    const int sp = blockIdx.x - c * splits;
-    const int vBegin = sp * vertsPerSplit;
-    skinRange<SRC_STRIDE, DST_STRIDE>(L, c, vBegin, min(L.vertexCount, vBegin + vertsPerSplit), pal);
+    // persistent form (gridDim.x < chars * splits): a workgroup keeps its place on the CU and walks over the work units
+    for (int u = blockIdx.x; u < L.chars * splits; u += gridDim.x) {
+        const int c = u / splits;
+        const int sp = u - c * splits;
+        const int vBegin = sp * vertsPerSplit;
+        if (u != (int)blockIdx.x) __syncthreads(); // every thread is done with the previous palette
+        skinRange<SRC_STRIDE, DST_STRIDE>(L, c, vBegin, min(L.vertexCount, vBegin + vertsPerSplit), pal);
+    }
 }
 
 // RTSkinningEncoder.encode over a heterogeneous job list (RTSkinningEncoder.swift:37-54 dispatches once per job): ONE launch.
@@ -256,7 +252,10 @@ void launch_store_probe(void* outPos, void* outNrm, void* outTan, int chars, int
     else hipLaunchKernelGGL((store_probe_kernel<3>), dim3(chars), dim3(kSkinBlock), 0, s, (float*)outPos, (float*)outNrm, (v4f*)outTan, vertexCount);
 }
 
-void launch_skin(const SkinLaunch& L, hipStream_t s) {
+// maxWorkgroupsPerCU > 0 caps the kernel's residency with dynamic-LDS padding: beside the next step's collision kernels
+// (SGE_OPT_OVERLAP_SKIN) three workgroups per CU stream as fast as five do alone, and the rest of the register file goes to the
+// latency-bound side (measured: 1.50 ms per step uncapped, 1.31 ms capped at three, 1.74 ms without overlap).
+void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU) {
     if (L.chars <= 0 || L.vertexCount <= 0) return;
     // enough workgroups to fill 256 CUs x 8 resident blocks several times over; small crowds split characters
     int splits = 1;
@@ -265,12 +264,15 @@ void launch_skin(const SkinLaunch& L, hipStream_t s) {
     splits = (L.vertexCount + vertsPerSplit - 1) / vertsPerSplit;
     dim3 grid((unsigned)((size_t)splits * L.chars));
     int ss = L.srcLayout == SGE_LAYOUT_PADDED16 ? 4 : 3, ds = L.dstLayout == SGE_LAYOUT_PADDED16 ? 4 : 3;
-    static const int ldsPad = getenv("SGE_SKIN_LDS_PAD") ? atoi(getenv("SGE_SKIN_LDS_PAD")) : 0; // experiments: caps workgroups per CU
-    static const int prio = getenv("SGE_SKIN_SETPRIO") ? atoi(getenv("SGE_SKIN_SETPRIO")) : 0;
-    if (ss == 3 && ds == 3) hipLaunchKernelGGL((skin_kernel<3, 3>), grid, dim3(kSkinBlock), ldsPad, s, L, splits, vertsPerSplit, prio);
-    else if (ss == 3 && ds == 4) hipLaunchKernelGGL((skin_kernel<3, 4>), grid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit, prio);
-    else if (ss == 4 && ds == 3) hipLaunchKernelGGL((skin_kernel<4, 3>), grid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit, prio);
-    else hipLaunchKernelGGL((skin_kernel<4, 4>), grid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit, prio);
+    int ldsPad = 0;
+    if (maxWorkgroupsPerCU > 0) {
+        const int perWorkgroup = 160 * 1024 / maxWorkgroupsPerCU, own = (int)sizeof(float4) * SGE_MAX_BONES * 3;
+        ldsPad = perWorkgroup > own + 256 ? (perWorkgroup - own - 256) & ~255 : 0;
+    }
+    if (ss == 3 && ds == 3) hipLaunchKernelGGL((skin_kernel<3, 3>), grid, dim3(kSkinBlock), ldsPad, s, L, splits, vertsPerSplit);
+    else if (ss == 3 && ds == 4) hipLaunchKernelGGL((skin_kernel<3, 4>), grid, dim3(kSkinBlock), ldsPad, s, L, splits, vertsPerSplit);
+    else if (ss == 4 && ds == 3) hipLaunchKernelGGL((skin_kernel<4, 3>), grid, dim3(kSkinBlock), ldsPad, s, L, splits, vertsPerSplit);
+    else hipLaunchKernelGGL((skin_kernel<4, 4>), grid, dim3(kSkinBlock), ldsPad, s, L, splits, vertsPerSplit);
 }
 
 // ---------------------------------------------------------------------------

@@ -868,6 +868,38 @@ def test_config_lbs_only_full_size(sge):
     cpu.close()
 
 
+def test_overlap_mode_parity(sge):
+    """SGE_OPT_OVERLAP_SKIN (the bench's default): skin(n) runs on a second stream beside move(n+1) + pose(n+1). Scheduling only:
+    CCD state bit-exact with the oracle at every check, and the skinned vertices read after any step are that step's."""
+    gpu = sge.CharacterEngine(0)
+    cpu = ob.oracle_engine()
+    gpu.set_option(sge.abi.OPT_OVERLAP_SKIN, 1)
+    n = 160
+    for e in (gpu, cpu):
+        build_scene(sge, e, n, seed=13, mixed=True, rings=9, segments=7, asset_scene=("cheese",), footprint=120.0)
+    for s in range(120):
+        gpu.tick()
+        ob.tick_mt(cpu, 8)
+        if s in (0, 1, 2, 17, 60, 119):
+            compare_states(sge, gpu, cpu, n)      # downloads join both streams
+            gp, gn, gt = gpu.skinned()
+            cp, cn, ct = cpu.skinned()
+            assert np.abs(gp - cp).max() <= REL * np.abs(cp).max()
+            assert np.abs(gn - cn).max() <= 2e-5 and np.abs(gt - ct).max() <= 2e-5
+    # stage subsets and the non-overlapped path mid-run
+    gpu.tick(stages=sge.abi.STAGE_ALL & ~sge.abi.STAGE_SKIN)
+    ob.tick_mt(cpu, 8, stages=sge.abi.STAGE_ALL & ~sge.abi.STAGE_SKIN)
+    gpu.set_option(sge.abi.OPT_OVERLAP_SKIN, 0)
+    for s in range(5):
+        gpu.tick()
+        ob.tick_mt(cpu, 8)
+    compare_states(sge, gpu, cpu, n)
+    assert np.abs(gpu.skinned()[0] - cpu.skinned()[0]).max() <= REL * np.abs(cpu.skinned()[0]).max()
+    assert gpu.move_stats().overflow == 0
+    gpu.close()
+    cpu.close()
+
+
 def test_api_edge_cases(sge):
     """Empty crowd, empty world, state errors and argument checks of the C ABI (status codes, no crashes)."""
     gpu = sge.CharacterEngine(0)
