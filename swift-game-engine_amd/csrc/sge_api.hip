@@ -50,14 +50,17 @@ struct sge_context {
     hipStream_t ownStream = nullptr, stream = nullptr;
     // LBS of step n overlaps move/CCD of step n+1: skinning runs on its own stream, ordered by two events
     hipStream_t skinStream = nullptr;
-    hipEvent_t evPoseDone = nullptr, evSkinDone = nullptr;
+    hipEvent_t evPoseDone = nullptr, evSkinDone[2] = {nullptr, nullptr};
+    // two palette buffers: with the overlap option pose(n+1) writes one while skin(n) still reads the other, so that only
+    // skin(n+1) -> skin(n) and skin(n+1) -> pose(n+1) remain as dependencies (a single buffer chains pose(n+1) behind skin(n))
+    int palRead = 0;             // buffer holding the latest palettes
     hipStream_t heavyStream = nullptr; // part 1 of the move stage for the step's heavy characters
     hipEvent_t evClassified = nullptr, evHeavyDone = nullptr, evTablesCopied = nullptr;
     int placementProbes = 8;   // candidate placements of the skinned output streams compared at allocation time
     float placementMs = 0; int placementTried = 0;
     int overlapSkinWorkgroups = 3; // LBS workgroups per CU while it shares the chip with the next step's collision kernels
     int heavyThreshold = 4000; // distance evaluations in a character's last step above which it takes the multi-wave kernel; < 0: off
-    bool skinPending = false, overlapSkin = false, customStream = false;
+    bool skinPending[2] = {false, false}, overlapSkin = false, customStream = false;
     // options
     bool storePoseDebug = false, profile = false;
     int skinLayout = SGE_LAYOUT_PACKED;
@@ -79,7 +82,7 @@ struct sge_context {
     int platformCount = 0;
     // crowd
     DevCrowd crowd{};
-    DevBuf dBodies, dParams, dCtrl, dIntents, dLoco, dActions, dPalettes, dPoseModel, dPoseLocal, dMoveScratch;
+    DevBuf dBodies, dParams, dCtrl, dIntents, dLoco, dActions, dPalettes[2], dPoseModel, dPoseLocal, dMoveScratch;
     DevBuf dOutPos, dOutNrm, dOutTan;
     int outLayoutAllocated = -1;
     // agents
@@ -139,12 +142,13 @@ int syncAll(sge_context* c) {
     SGE_HIP(hipStreamSynchronize(c->stream));
     if (c->skinStream) SGE_HIP(hipStreamSynchronize(c->skinStream));
     if (c->heavyStream) SGE_HIP(hipStreamSynchronize(c->heavyStream));
-    c->skinPending = false;
+    c->skinPending[0] = c->skinPending[1] = false;
     return SGE_OK;
 }
 // The main stream must not touch palettes / skinned outputs while a skin launch is in flight.
 int joinSkin(sge_context* c) {
-    if (c->skinPending) { SGE_HIP(hipStreamWaitEvent(c->stream, c->evSkinDone, 0)); c->skinPending = false; }
+    for (int f = 0; f < 2; ++f)
+        if (c->skinPending[f]) { SGE_HIP(hipStreamWaitEvent(c->stream, c->evSkinDone[f], 0)); c->skinPending[f] = false; }
     return SGE_OK;
 }
 
@@ -386,7 +390,8 @@ sge_context* sge_context_create(int device_index) {
     c->stream = c->ownStream;
     if (hipStreamCreateWithPriority(&c->skinStream, hipStreamNonBlocking, prLeast) != hipSuccess ||
         hipEventCreateWithFlags(&c->evPoseDone, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->evSkinDone, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evSkinDone[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evSkinDone[1], hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithPriority(&c->heavyStream, hipStreamNonBlocking, prGreatest) != hipSuccess ||
         hipEventCreateWithFlags(&c->evClassified, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evHeavyDone, hipEventDisableTiming) != hipSuccess ||
@@ -403,14 +408,14 @@ void sge_context_destroy(sge_context* c) {
     DevBuf* bufs[] = {&c->dParent, &c->dDepth, &c->dLeanChain, &c->dPath, &c->dBindLocal, &c->dInvBind, &c->dRestT, &c->dRawRestT, &c->dPreRot,
                       &c->dCoeffs, &c->dCoeffCount, &c->dBonePresent, &c->dMeshPos, &c->dMeshNrm, &c->dMeshTan, &c->dMeshIdx, &c->dMeshWgt,
                       &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dSlotOfRank, &c->dCost, &c->dHint, &c->dHeavyFlags, &c->dJobTable, &c->dBlockJob, &c->dLists, &c->dListCounts, &c->dOrderHist, &c->dWaveProf, &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
-                      &c->dPalettes, &c->dPoseModel, &c->dPoseLocal, &c->dMoveScratch, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
+                      &c->dPalettes[0], &c->dPalettes[1], &c->dPoseModel, &c->dPoseLocal, &c->dMoveScratch, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
                       &c->dCellCursor, &c->dAgentMinMax, &c->dAgentGrid, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats,
                       &c->dBlasEntryLink, &c->dBlasWideFirst, &c->dBlasWideParent, &c->dBlasWideLevel, &c->dBlasSlotIdx, &c->dBlasSlotTri,
                       &c->dBlasIndices, &c->dBlasBounds, &c->dBlasInstances, &c->dBlasRays, &c->dBlasHits, &c->dBlasTileStart,
                       &c->dBlasRoundLen, &c->dBlasRoundCluster, &c->dBlasRoundIds, &c->dBlasWorldBoxes, &c->dBlasUVs};
     for (DevBuf* b : bufs) b->release();
     if (c->evPoseDone) (void)hipEventDestroy(c->evPoseDone);
-    if (c->evSkinDone) (void)hipEventDestroy(c->evSkinDone);
+    for (hipEvent_t e : c->evSkinDone) if (e) (void)hipEventDestroy(e);
     if (c->skinStream) (void)hipStreamDestroy(c->skinStream);
     if (c->evClassified) (void)hipEventDestroy(c->evClassified);
     if (c->evHeavyDone) (void)hipEventDestroy(c->evHeavyDone);
@@ -615,7 +620,7 @@ int sge_skinned_mesh_buffers(sge_context* c, void** p, void** n, void** t, void*
 
 int sge_crowd_buffers(sge_context* c, void** pal, void** op, void** on, void** ot) {
     if (!c || c->crowd.count == 0) { set_error("no characters"); return SGE_ERR_STATE; }
-    if (pal) *pal = c->dPalettes.p; if (op) *op = c->dOutPos.p; if (on) *on = c->dOutNrm.p; if (ot) *ot = c->dOutTan.p;
+    if (pal) *pal = c->dPalettes[c->palRead].p; if (op) *op = c->dOutPos.p; if (on) *on = c->dOutNrm.p; if (ot) *ot = c->dOutTan.p;
     return SGE_OK;
 }
 
@@ -949,7 +954,9 @@ int sge_characters_resize(sge_context* c, int32_t count) {
     SGE_ZALLOC(c->dIntents, N * sizeof(sge_move_intent));
     SGE_ZALLOC(c->dLoco, N * sizeof(sge_locomotion_state));
     SGE_ZALLOC(c->dActions, N * sizeof(sge_action_state));
-    SGE_ZALLOC(c->dPalettes, N * B * 64);
+    SGE_ZALLOC(c->dPalettes[0], N * B * 64);
+    SGE_ZALLOC(c->dPalettes[1], N * B * 64);
+    c->palRead = 0;
     SGE_ZALLOC(c->dMoveScratch, N * (size_t)kMoveScratchBytes);
     SGE_ZALLOC(c->dCost, N * sizeof(int));
     SGE_ZALLOC(c->dHint, N);
@@ -961,7 +968,7 @@ int sge_characters_resize(sge_context* c, int32_t count) {
 #undef SGE_ZALLOC
     c->crowd = DevCrowd{count, c->dBodies.as<sge_body_state>(), c->dParams.as<sge_controller_params>(),
                         c->dCtrl.as<sge_controller_state>(), c->dIntents.as<sge_move_intent>(),
-                        c->dLoco.as<sge_locomotion_state>(), c->dActions.as<sge_action_state>(), c->dPalettes.as<float>(),
+                        c->dLoco.as<sge_locomotion_state>(), c->dActions.as<sge_action_state>(), c->dPalettes[0].as<float>(),
                         c->storePoseDebug ? c->dPoseModel.as<float>() : nullptr, c->storePoseDebug ? c->dPoseLocal.as<float>() : nullptr};
     if (c->mesh.vertexCount > 0 && (rc = allocCrowdOutputs(c)) != SGE_OK) return rc;
     if ((rc = ensureBlasBuffers(c)) != SGE_OK) return rc;
@@ -1016,7 +1023,7 @@ int sge_palettes_download(sge_context* c, int32_t first, int32_t count, float* p
     (void)hipSetDevice(c->device);
     const size_t B = (size_t)c->boneCount, off = (size_t)first * B * 16, n = (size_t)count * B * 64;
     { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; }
-    if (palette) SGE_HIP(hipMemcpyAsync(palette, c->dPalettes.as<float>() + off, n, hipMemcpyDeviceToHost, c->stream));
+    if (palette) SGE_HIP(hipMemcpyAsync(palette, c->dPalettes[c->palRead].as<float>() + off, n, hipMemcpyDeviceToHost, c->stream));
     if (model) SGE_HIP(hipMemcpyAsync(model, c->dPoseModel.as<float>() + off, n, hipMemcpyDeviceToHost, c->stream));
     if (local) SGE_HIP(hipMemcpyAsync(local, c->dPoseLocal.as<float>() + off, n, hipMemcpyDeviceToHost, c->stream));
     SGE_HIP(hipStreamSynchronize(c->stream));
@@ -1075,8 +1082,19 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
     }
     if (st & (SGE_STAGE_LOCOMOTION | SGE_STAGE_ACTION | SGE_STAGE_POSE | SGE_STAGE_WRITEBACK)) {
         if ((st & SGE_STAGE_POSE) && (c->boneCount == 0 || c->prof.count == 0)) { set_error("pose stage needs a skeleton and motion profiles"); return SGE_ERR_STATE; }
+        if (st & SGE_STAGE_POSE) {
+            const bool flip = c->overlapSkin && !c->customStream && first == 0 && count == c->crowd.count;
+            if (flip) { // write the buffer no skin launch newer than skin(n-1) reads
+                const int f = c->palRead ^ 1;
+                if (c->skinPending[f]) { SGE_HIP(hipStreamWaitEvent(c->stream, c->evSkinDone[f], 0)); c->skinPending[f] = false; }
+                c->palRead = f;
+            } else { // palettes are rewritten in place
+                int rcj = joinSkin(c);
+                if (rcj != SGE_OK) return rcj;
+            }
+            c->crowd.palettes = c->dPalettes[c->palRead].as<float>();
+        }
         PoseLaunch L{c->crowd, c->sk, c->prof, d->dt, st, first, count};
-        if (st & SGE_STAGE_POSE) { int rcj = joinSkin(c); if (rcj != SGE_OK) return rcj; } // palettes are about to be rewritten
         Bracket br(c, &c->evPose);
         launch_pose(L, c->stream);
     }
@@ -1093,12 +1111,14 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         hipStream_t ss = c->stream;
         const bool overlap = c->overlapSkin && !c->customStream;
         if (overlap) {
-            // skin(n) on its own stream after pose(n); move(n+1) may start on the main stream meanwhile
-            int rcj = joinSkin(c);
-            if (rcj != SGE_OK) return rcj;
+            // skin(n) on its own stream after pose(n) (and, stream order, after skin(n-1)); move(n+1) and pose(n+1) may run on
+            // the main stream meanwhile
             SGE_HIP(hipEventRecord(c->evPoseDone, c->stream));
             SGE_HIP(hipStreamWaitEvent(c->skinStream, c->evPoseDone, 0));
             ss = c->skinStream;
+        } else { // the output streams may still be written by an overlapped launch of an earlier tick
+            int rcj = joinSkin(c);
+            if (rcj != SGE_OK) return rcj;
         }
         const bool refit = (st & SGE_STAGE_BLAS_REFIT) != 0;
         if (refit && c->blas.entryCount == 0) { set_error("SGE_STAGE_BLAS_REFIT needs sge_blas_build"); return SGE_ERR_STATE; }
@@ -1119,7 +1139,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
                 if (rc != SGE_OK) return rc;
             }
         }
-        if (overlap) { SGE_HIP(hipEventRecord(c->evSkinDone, c->skinStream)); c->skinPending = true; }
+        if (overlap) { SGE_HIP(hipEventRecord(c->evSkinDone[c->palRead], c->skinStream)); c->skinPending[c->palRead] = true; }
     } else if (st & SGE_STAGE_BLAS_REFIT) {
         int rc = sge_blas_refit(c, first, count);
         if (rc != SGE_OK) return rc;
