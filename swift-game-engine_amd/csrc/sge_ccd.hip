@@ -1726,16 +1726,19 @@ __device__ __forceinline__ int groupSetupRays(const DevCollision& col, int rb, i
 // Sweeps every queued (ray slot, triangle) item: the streaming lane state machine of waveCastRays with the capsule and the
 // acceptance filters taken from the item's ray slot. Leaves the queue empty.
 __device__ __forceinline__ void groupSweep(const DevCollision& col, int& itemCount, WaveStats& st) {
+    const int lane = laneId();
     const float contactEps = 1e-5f;
     int phase = PH_DONE, myRay = 0, iter = 0, refineK = 0, maxIter = 0;
     Tri tri;
     tri.v0 = tri.v1 = tri.v2 = F3{0, 0, 0}; tri.triIndex = -1; tri.rank = 0x7fffffff;
     F3 triNormal{0, 0, 0};
     float t = 0, lastSafeT = 0, lo = 0, hi = 0, tEval = 0, len = 0, bestToi = 0, radius = 0, halfHeight = 0, minAdvance = 0;
-    unsigned evals = 0; // of this lane's current item
+    int crawlRun = 0;    // consecutive march steps that advanced by exactly minAdvance
+    unsigned evals = 0;  // of this lane's current item
     while (true) {
         const unsigned long long idleMask = __ballot(phase == PH_DONE);
-        const int nIdle = __popcll(idleMask);
+        int nIdle = __popcll(idleMask);
+        unsigned long long takenMask = 0;
         if (nIdle > 0 && itemCount > 0) {
             const int take = nIdle < itemCount ? nIdle : itemCount;
             const int p = prefixCount(idleMask);
@@ -1751,42 +1754,83 @@ __device__ __forceinline__ void groupSweep(const DevCollision& col, int& itemCou
                 minAdvance = smax(radius * 0.02f, 1e-4f); // :1295
                 bestToi = __uint_as_float((unsigned)(sh.rayKey[myRay] >> 32));
                 phase = PH_MARCH;
-                t = 0; lastSafeT = 0; lo = 0; hi = 0; tEval = 0; iter = 0; refineK = 0;
+                t = 0; lastSafeT = 0; lo = 0; hi = 0; tEval = 0; iter = 0; refineK = 0; crawlRun = 0;
             }
+            takenMask = __ballot(phase == PH_MARCH) & idleMask;
             itemCount -= take;
+            nIdle -= take;
             __syncthreads();
         } else if (nIdle == kWave) {
             break;
         }
         st.trips += 1;
         if (phase == PH_MARCH) {
+            // loop head of :1303-1307 — iteration budget, then `if t > maxDistance return nil`
             if (iter >= maxIter || t > len || lastSafeT > bestToi) phase = PH_DONE;
             else { iter += 1; tEval = t; }
         } else if (phase == PH_REFINE) {
             if (lo > bestToi) phase = PH_DONE;
             else tEval = 0.5f * (lo + hi);
         }
+        // ---- speculative crawl ------------------------------------------------------------------------------------------
+        // A march that creeps along a surface advances by exactly minAdvance per evaluation (advance = max(dist - r, minAdvance),
+        // :1316-1321), up to the reference's 256-iteration cap: hundreds of dependent evaluations on one lane while the wavefront
+        // idles — the tail of the whole launch. While advance == minAdvance the evaluation points do not depend on the distances:
+        // t_{k+1} = t_k + minAdvance. When at least half the lanes are idle and nothing is queued, the idle lanes evaluate the
+        // creeping item ("owner") at t_{k+1}, t_{k+2}, ... (the same sequential float additions the march makes) in the trip in
+        // which the owner evaluates t_k, and the owner then takes over the prefix up to the first evaluation that ends the loop,
+        // makes contact, or advances by more than minAdvance — exactly the states the sequential march goes through.
+        const unsigned long long crawlMask = __ballot(phase == PH_MARCH && crawlRun >= 3);
+        const unsigned long long helpMask = idleMask & __ballot(phase == PH_DONE) & ~takenMask;
+        const int nHelp = __popcll(helpMask);
+        const bool spec = itemCount == 0 && crawlMask != 0 && nHelp >= kWave / 2;
+        const int owner = spec ? __ffsll((long long)crawlMask) - 1 : 0;
+        const bool helper = spec && ((helpMask >> lane) & 1);
+        const int h = prefixCount(helpMask); // rank among the helpers: helper h evaluates t_{k+1+h}
+        // what this lane evaluates in this trip
+        bool cEval = phase != PH_DONE;
+        float cT = tEval, cPrev = 0, cHalf = halfHeight, bMinAdv = 0, bRadius = 0;
+        F3 cFrom = sh.rayFrom[myRay], cDir = sh.rayDir[myRay], c0 = tri.v0, c1 = tri.v1, c2 = tri.v2;
+        if (spec) {
+            const int bRay = __shfl(myRay, owner, kWave), bIter = __shfl(iter, owner, kWave), bMaxIter = __shfl(maxIter, owner, kWave);
+            const float bT = __shfl(t, owner, kWave), bLen = __shfl(len, owner, kWave), bHalf = __shfl(halfHeight, owner, kWave);
+            bMinAdv = __shfl(minAdvance, owner, kWave); bRadius = __shfl(radius, owner, kWave);
+            const F3 b0{__shfl(tri.v0.x, owner, kWave), __shfl(tri.v0.y, owner, kWave), __shfl(tri.v0.z, owner, kWave)};
+            const F3 b1{__shfl(tri.v1.x, owner, kWave), __shfl(tri.v1.y, owner, kWave), __shfl(tri.v1.z, owner, kWave)};
+            const F3 b2{__shfl(tri.v2.x, owner, kWave), __shfl(tri.v2.y, owner, kWave), __shfl(tri.v2.z, owner, kWave)};
+            if (helper) {
+                cHalf = bHalf; c0 = b0; c1 = b1; c2 = b2;
+                cFrom = sh.rayFrom[bRay]; cDir = sh.rayDir[bRay];
+                cT = bT;
+            }
+            for (int k = 0; k < nHelp; ++k) if (helper && k <= h) { cPrev = cT; cT += bMinAdv; } // sequential additions, as the march makes them
+            // loop head of :1303-1307 for the helper's evaluation: the owner's count already includes its own evaluation of this trip
+            if (helper) cEval = (bIter + h < bMaxIter) && !(cT > bLen);
+        }
         bool finished = false;
         unsigned long long myKey = ~0ull;
         CastRec rec;
         rec.toi = 0; rec.position = rec.normal = rec.triNormal = F3{0, 0, 0}; rec.triIndex = -1;
+        float dist = 0;
+        F3 segP{0, 0, 0}, triP{0, 0, 0};
+        if (cEval) dist = segmentTriangleDistance(cFrom + cDir * cT, cHalf, c0, c1, c2, segP, triP);
         if (phase != PH_DONE) {
             evals += 1;
-            const F3 from = sh.rayFrom[myRay], dir = sh.rayDir[myRay];
-            F3 center = from + dir * tEval;
-            F3 segP, triP;
-            float dist = segmentTriangleDistance(center, halfHeight, tri.v0, tri.v1, tri.v2, segP, triP);
+            const F3 dir = cDir;
             if (phase == PH_MARCH) {
                 if (dist <= radius + contactEps) {
-                    float c0 = smax(0.0f, smin(lastSafeT, len));
-                    float c1 = smax(0.0f, smin(t, len));
-                    lo = smin(c0, c1);
-                    hi = smax(c0, c1);
+                    // refineTOI(t0: lastSafeT, t1: t) :1361-1377
+                    float k0 = smax(0.0f, smin(lastSafeT, len));
+                    float k1 = smax(0.0f, smin(t, len));
+                    lo = smin(k0, k1);
+                    hi = smax(k0, k1);
                     if (hi - lo < 1e-5f) { phase = PH_FINAL; tEval = hi; }
                     else { phase = PH_REFINE; refineK = 0; }
+                    crawlRun = 0;
                 } else {
                     lastSafeT = t;
                     float advance = smax(dist - radius, minAdvance);
+                    crawlRun = advance == minAdvance ? crawlRun + 1 : 0;
                     if (advance <= 0) t += minAdvance; else t += advance;
                 }
             } else if (phase == PH_REFINE) {
@@ -1813,6 +1857,38 @@ __device__ __forceinline__ void groupSweep(const DevCollision& col, int& itemCou
                     myKey = ((unsigned long long)__float_as_uint(tHit) << 32) | (unsigned)tri.rank;
                     atomicMin(&sh.rayKey[myRay], myKey);
                     finished = true;
+                }
+            }
+        }
+        if (spec) {
+            // did the owner's own evaluation of this trip creep (still marching, advance == minAdvance)? then the helpers' points are its
+            const int ownerCrept = __shfl((int)(phase == PH_MARCH && crawlRun > 0), owner, kWave);
+            if (ownerCrept) {
+                const bool contact = helper && cEval && dist <= bRadius + contactEps;
+                const float adv = smax(dist - bRadius, bMinAdv);
+                const bool breaks = helper && cEval && !contact && adv != bMinAdv;
+                const unsigned long long ev = __ballot(helper && (!cEval || contact || breaks));
+                const int lastHelper = 63 - __clzll((long long)helpMask);
+                const int jl = ev ? __ffsll((long long)ev) - 1 : lastHelper; // the helper whose evaluation decides
+                const int rJ = __shfl(h, jl, kWave);
+                const float tJ = __shfl(cT, jl, kWave), tPrev = __shfl(cPrev, jl, kWave), advJ = __shfl(adv, jl, kWave);
+                const int evalJ = __shfl((int)cEval, jl, kWave), contactJ = __shfl((int)contact, jl, kWave);
+                if (lane == owner) {
+                    if (!ev) {                    // every helper found another creeping step
+                        iter += nHelp; evals += nHelp; crawlRun += nHelp; lastSafeT = tJ; t = tJ + bMinAdv;
+                    } else if (!evalJ) {          // the loop ends at helper rJ's evaluation (budget or t > maxDistance): the next head sees it
+                        iter += rJ; evals += rJ; lastSafeT = tPrev; t = tJ; crawlRun = 0;
+                    } else if (contactJ) {        // contact: refineTOI(t0: lastSafeT, t1: t) :1361-1377
+                        iter += rJ + 1; evals += rJ + 1; lastSafeT = tPrev; t = tJ; crawlRun = 0;
+                        float k0 = smax(0.0f, smin(lastSafeT, len));
+                        float k1 = smax(0.0f, smin(t, len));
+                        lo = smin(k0, k1);
+                        hi = smax(k0, k1);
+                        if (hi - lo < 1e-5f) { phase = PH_FINAL; tEval = hi; }
+                        else { phase = PH_REFINE; refineK = 0; }
+                    } else {                      // this evaluation advances further than minAdvance: back to the ordinary march
+                        iter += rJ + 1; evals += rJ + 1; lastSafeT = tJ; t = tJ + advJ; crawlRun = 0;
+                    }
                 }
             }
         }
@@ -2146,11 +2222,22 @@ __global__ void order_scan_kernel(int* hist, int* counts) {
     if (lane < kCostBuckets) { hist[kCostBuckets + b] = incl - c; hist[b] = 0; }
     if (lane == kCostBuckets - 1) counts[0] = incl;
 }
+// Scatter with one global atomic per (workgroup, class): 10k single atomics on ~10 hot cursors took 76 us per step.
 __global__ void order_scatter_kernel(const int* cost, int first, int count, const uint8_t* flags, int* hist, int* order) {
+    __shared__ int h[kCostBuckets], base[kCostBuckets];
+    if (threadIdx.x < kCostBuckets) h[threadIdx.x] = 0;
+    __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const int e = first + i;
-    if (!flags[e]) order[atomicAdd(&hist[kCostBuckets + costBucket(cost[e])], 1)] = e;
+    int e = -1, b = 0, local = 0;
+    if (i < count && !flags[first + i]) {
+        e = first + i;
+        b = costBucket(cost[e]);
+        local = atomicAdd(&h[b], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < kCostBuckets && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&hist[kCostBuckets + threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (e >= 0) order[base[b] + local] = e;
 }
 
 void launch_move(const MoveLaunch& L, hipStream_t s) {
