@@ -524,6 +524,8 @@ enum {
     SGE_STAGE_SKIN = 1u << 7,       /* RTSkinningEncoder.encode over the crowd */
     SGE_STAGE_AGENTS = 1u << 8,     /* capsule-capsule sweep vs the imported agent set, Systems.swift:1053-1091 */
     SGE_STAGE_BLAS_REFIT = 1u << 9, /* RTAccelerationBuilder dynamic-slice refit, RTAccelerationBuilder.swift:113-145 (not in SGE_STAGE_ALL) */
+    SGE_STAGE_SEPARATION = 1u << 10, /* AgentSeparationSystem, Systems.swift:1906-2210: between the move stage and the locomotion stage,
+                                      * as in DemoScene.swift:66-68 (not in SGE_STAGE_ALL; whole crowd only: first = 0, count = all) */
     SGE_STAGE_ALL_FIXED = 0x7Fu,
     SGE_STAGE_ALL = 0xFFu
 };
@@ -575,6 +577,13 @@ typedef struct sge_move_stats {
     uint64_t sweepTrips;       /* wave-wide trips of the sweep loop (one distance evaluation per active lane each) */
     uint64_t prunedPairs;      /* (cast, triangle) pairs of vertical casts skipped by the conservative XZ reject (no result changes) */
 } sge_move_stats;
+/* AgentSeparationSystem.init(iterations:separationMargin:heightMargin:) (Systems.swift:2146-2152; defaults 2, 0.2, 0.1).
+   The stage resolves overlaps between the context's solid agents in CHARACTER-INDEX order — the reference iterates a Swift
+   Dictionary, whose order is hash-seed dependent, so it has no canonical result of its own. The pair loop is
+   sequential by definition (every pair reads what the pairs before it wrote), so one wavefront walks it; the stage is meant for the
+   reference's scale of agents (at most SGE_MAX_SEPARATION_AGENTS solid agents per context, else SGE_ERR_CAPACITY). */
+#define SGE_MAX_SEPARATION_AGENTS 1024
+int sge_separation_params(sge_context* ctx, int32_t iterations, float separation_margin, float height_margin);
 int sge_move_stats_read(sge_context* ctx, sge_move_stats* out, int reset);
 /* Per-character share of CollisionQueryStats.capsuleSweepIterations (CollisionQuery.swift:280-318) for the LAST fixed step:
    distance evaluations each of characters [first, first + count) spent in its casts (what the scheduler balances on). */

@@ -112,6 +112,9 @@ struct World {
     std::vector<sge_agent_state> importedAgents;
     int agentSelfOffset = 0;
     bool agentsImported = false;
+    // AgentSeparationSystem.init defaults (Systems.swift:2146-2152)
+    int separationIterations = 2;
+    float separationMargin = 0.2f, separationHeightMargin = 0.1f;
 };
 
 // pose.cpp
@@ -132,5 +135,7 @@ void collect_agent_states(const World& w, std::vector<AgentSweepState>& agents, 
 void kinematic_move_fixed_update(World& w, int first, int count, float dt, V3 gravity,
                                  const std::vector<AgentSweepState>* agents, int selfOffset);
 void writeback_fixed_update(World& w, int first, int count);
+// AgentSeparationSystem (Systems.swift:1906-2210) over the whole crowd, canonical order = character index
+void agent_separation_fixed_update(World& w, int iterations, float separationMargin, float heightMargin);
 
 } // namespace sgeo

@@ -328,6 +328,9 @@ static void run_range(sgeo_world* h, const sge_tick_desc& d, int first, int coun
     if (d.stages & SGE_STAGE_SKIN) skin_characters(w, first, count);
 }
 
+static int sgeo_tick_mt_stages(sgeo_world* h, const sge_tick_desc& dd, int first, int count, int threads,
+                               const std::vector<AgentSweepState>* agentsPtr, int selfOffset);
+
 // One fixed step on `threads` host threads (1 = the reference's main-actor execution).
 int sgeo_tick_mt(sgeo_world* h, const sge_tick_desc* d, int32_t threads) {
     World& w = h->w;
@@ -354,8 +357,32 @@ int sgeo_tick_mt(sgeo_world* h, const sge_tick_desc* d, int32_t threads) {
     }
     sge_tick_desc dd = *d;
     if (useAgents && !w.agentsImported) dd.stages &= ~(SGE_STAGE_INTENT | SGE_STAGE_GRAVITY);
+    if (d->stages & SGE_STAGE_SEPARATION) {
+        // AgentSeparationSystem sits between KinematicMoveStopSystem and the animation systems (DemoScene.swift:66-71) and sees the
+        // whole crowd: run the stages before it for everybody, then it, then the rest
+        if (first != 0 || (size_t)count != w.bodies.size()) return SGE_ERR_INVALID;
+        const uint32_t before = SGE_STAGE_INTENT | SGE_STAGE_GRAVITY | SGE_STAGE_MOVE | SGE_STAGE_AGENTS;
+        sge_tick_desc a = dd, b = dd;
+        a.stages = dd.stages & before;
+        b.stages = dd.stages & ~(before | SGE_STAGE_SEPARATION);
+        if (a.stages & ~(uint32_t)SGE_STAGE_AGENTS) {
+            int rc = sgeo_tick_mt_stages(h, a, first, count, threads, useAgents ? &agents : nullptr, selfOffset);
+            if (rc != SGE_OK) return rc;
+        }
+        agent_separation_fixed_update(w, w.separationIterations, w.separationMargin, w.separationHeightMargin);
+        QueryStats s = take_thread_stats();
+        h->stats.candidates += s.candidates; h->stats.sweeps += s.sweeps; h->stats.iterations += s.iterations; h->stats.queries += s.queries;
+        if (b.stages) return sgeo_tick_mt_stages(h, b, first, count, threads, nullptr, 0);
+        return SGE_OK;
+    }
+    return sgeo_tick_mt_stages(h, dd, first, count, threads, useAgents ? &agents : nullptr, selfOffset);
+}
+
+// the stages of `dd` over [first, first + count) on `threads` host threads
+static int sgeo_tick_mt_stages(sgeo_world* h, const sge_tick_desc& dd, int first, int count, int threads,
+                               const std::vector<AgentSweepState>* agentsPtr, int selfOffset) {
     if (threads <= 1) {
-        run_range(h, dd, first, count, useAgents ? &agents : nullptr, selfOffset);
+        run_range(h, dd, first, count, agentsPtr, selfOffset);
         QueryStats s = take_thread_stats();
         h->stats.candidates += s.candidates; h->stats.sweeps += s.sweeps; h->stats.iterations += s.iterations; h->stats.queries += s.queries;
         return SGE_OK;
@@ -367,7 +394,7 @@ int sgeo_tick_mt(sgeo_world* h, const sge_tick_desc* d, int32_t threads) {
         int f = first + t * chunk, c = std::min(chunk, first + count - f);
         if (c <= 0) break;
         pool.emplace_back([&, f, c]() {
-            run_range(h, dd, f, c, useAgents ? &agents : nullptr, selfOffset);
+            run_range(h, dd, f, c, agentsPtr, selfOffset);
             QueryStats s = take_thread_stats();
             std::lock_guard<std::mutex> lk(mu);
             h->stats.candidates += s.candidates; h->stats.sweeps += s.sweeps; h->stats.iterations += s.iterations; h->stats.queries += s.queries;
@@ -400,6 +427,14 @@ int sgeo_agents_import(sgeo_world* h, const sge_agent_state* all, int32_t total,
     h->w.importedAgents.assign(all, all + total);
     h->w.agentSelfOffset = selfOffset;
     h->w.agentsImported = total > 0;
+    return SGE_OK;
+}
+
+int sgeo_separation_params(sgeo_world* h, int32_t iterations, float separationMargin, float heightMargin) {
+    if (!h) return SGE_ERR_INVALID;
+    h->w.separationIterations = iterations < 1 ? 1 : iterations; // max(1, iterations) :2146
+    h->w.separationMargin = separationMargin;
+    h->w.separationHeightMargin = heightMargin;
     return SGE_OK;
 }
 

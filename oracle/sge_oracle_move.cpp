@@ -17,6 +17,7 @@
 // (World.swift:99-117); here it is ascending character index.
 // Parity unpinned (no reference tests); see DESIGN.md.
 #include <algorithm>
+#include <map>
 #include "sge_oracle.h"
 
 namespace sgeo {
@@ -311,11 +312,19 @@ static bool agentBestHit(V3 position, V3 remaining, float remainingLen, float ba
     return have;
 }
 
-// ---- SlideResolver.resolveHit :1229-1375, options = .kinematicMove ----
+// ---- SlideResolver.resolveHit :1229-1375 ----
+struct SlideOptions { bool allowHorizontalGroundPass, adjustVelocity, useGroundSnapSkinForStatic, allowTriangleNormalGroundLike; }; // :1208-1222
+static const SlideOptions kKinematicMove{false, true, true, true};
+static const SlideOptions kAgentSeparation{true, false, false, false};
 struct SlideHit { bool isStatic; CapsuleCastHit s; CapsuleCapsuleHit a; };
 static bool resolveHit(V3& remaining, float len, const SlideHit& hit, const sge_controller_params& P,
                        const sge_controller_state& C, bool wasGrounded, bool wasGroundedNear, D3& velocity,
-                       V3& position, bool hasCachedSideNormal, V3 cachedSideNormal) {
+                       V3& position, bool hasCachedSideNormal, V3 cachedSideNormal, const SlideOptions& options = kKinematicMove) {
+    if (options.allowHorizontalGroundPass && hit.isStatic && fabsf(remaining.y) < 1e-5f && hit.s.normal.y >= P.minGroundDot) { // :1240-1247
+        position += remaining;
+        remaining = V3{0, 0, 0};
+        return true;
+    }
     float contactSkin, hitToi;
     V3 slideNormal, hitTriNormal = V3{0, 0, 0};
     bool hitIsStatic = false, hitIsGroundLike = false;
@@ -323,7 +332,7 @@ static bool resolveHit(V3& remaining, float len, const SlideHit& hit, const sge_
         hitToi = hit.s.toi;
         slideNormal = hit.s.normal;
         hitIsGroundLike = hit.s.triangleNormal.y >= P.minGroundDot;
-        contactSkin = hitIsGroundLike ? P.groundSnapSkin : P.skinWidth; // useGroundSnapSkinForStatic
+        contactSkin = (options.useGroundSnapSkinForStatic && hitIsGroundLike) ? P.groundSnapSkin : P.skinWidth;
         hitTriNormal = hit.s.triangleNormal;
         hitIsStatic = true;
     } else {
@@ -347,7 +356,7 @@ static bool resolveHit(V3& remaining, float len, const SlideHit& hit, const sge_
         }
     }
     if (slideNormal.y < P.minGroundDot) {
-        if (hitIsStatic && hitIsGroundLike) slideNormal = hitTriNormal; // allowTriangleNormalGroundLike
+        if (hitIsStatic && hitIsGroundLike && options.allowTriangleNormalGroundLike) slideNormal = hitTriNormal;
         if (slideNormal.y < P.minGroundDot) {
             slideNormal.y = 0;
             float nLen = length(slideNormal);
@@ -401,9 +410,11 @@ static bool resolveHit(V3& remaining, float len, const SlideHit& hit, const sge_
         return true;
     }
     remaining = leftover;
-    D3 snD = d3(slideNormal); // adjustVelocity
-    double vInto = dot(velocity, snD);
-    if (vInto < 0) velocity -= snD * vInto;
+    if (options.adjustVelocity) {
+        D3 snD = d3(slideNormal);
+        double vInto = dot(velocity, snD);
+        if (vInto < 0) velocity -= snD * vInto;
+    }
     return false;
 }
 
@@ -728,6 +739,171 @@ void kinematic_move_fixed_update(World& w, int first, int count, float dt, V3 gr
         st3(C.groundNormal, gs.grounded ? gs.normal : V3{0, 1, 0});
         C.groundDistance = gs.distance;
         if (gs.grounded) C.groundTriangleIndex = gs.triangleIndex;
+    }
+}
+
+
+
+// ---- AgentSeparationSystem (Systems.swift:1906-2210) ----
+// The reference iterates `world.query(...)`, i.e. Swift Dictionary order, which is hash-seed dependent; the canonical order
+// here is the character index. Everything else follows the Swift line by line: the agent list (solid agents;
+// an entity without AgentCollisionComponent counts as a default one, :2171), the per-iteration grid rebuild (:2192-2199), the
+// resolver's stale copy `a` of agent i beside the live agents[i] / agents[j] (:1952-2043), and the post-process (:2047-2140).
+namespace {
+struct SepAgent { int entity; V3 position, velocity; float radius, halfHeight, invWeight; };
+struct CellKey { long long x, z; bool operator<(const CellKey& o) const { return x != o.x ? x < o.x : z < o.z; } };
+CellKey cellCoord(V3 pos, float cellSize) { // :1939-1943
+    return CellKey{(long long)floorf(pos.x / cellSize), (long long)floorf(pos.z / cellSize)};
+}
+}
+
+void agent_separation_fixed_update(World& w, int iterations, float separationMargin, float heightMargin) {
+    const CollisionQuery& query = w.query;
+    const int N = (int)w.bodies.size();
+    if (N <= 1) return; // guard entities.count > 1 (:2153)
+    if (iterations < 1) iterations = 1; // :2146
+    std::vector<SepAgent> agents;
+    std::vector<V3> originalPositions;
+    float maxRadius = 0;
+    for (int e = 0; e < N; ++e) { // :2166-2187
+        const sge_controller_params& P = w.params[e];
+        const bool present = (P.agentFlags & SGE_AGENT_PRESENT) != 0;
+        const bool solid = present ? (P.agentFlags & SGE_AGENT_SOLID) != 0 : true; // aStore[e] ?? AgentCollisionComponent()
+        if (!solid) continue;
+        const float radius = (present && (P.agentFlags & SGE_AGENT_RADIUS_OVERRIDE)) ? P.agentRadiusOverride : P.radius;
+        const float massWeight = present ? P.agentMassWeight : 1.0f;
+        const float invWeight = massWeight > 0 ? 1.0f / massWeight : 0.0f;
+        maxRadius = fmax_s(maxRadius, radius);
+        V3 pos = f3(ldd3(w.bodies[e].position)), vel = f3(ldd3(w.bodies[e].linearVelocity));
+        agents.push_back(SepAgent{e, pos, vel, radius, P.halfHeight, invWeight});
+        originalPositions.push_back(pos);
+    }
+    if (agents.size() <= 1) return; // :2189
+    const float cellSize = fmax_s(maxRadius * 2 + separationMargin, 0.001f);
+    const int n = (int)agents.size();
+    for (int it = 0; it < iterations; ++it) {
+        std::map<CellKey, std::vector<int>> cells; // rebuild :1930-1936 (lists in agent order)
+        for (int i = 0; i < n; ++i) cells[cellCoord(agents[i].position, cellSize)].push_back(i);
+        for (int i = 0; i < n; ++i) { // AgentSeparationResolver.resolve :1947-2046
+            const SepAgent a = agents[i];
+            const sge_controller_params& Pa = w.params[a.entity];
+            const CellKey cell = cellCoord(a.position, cellSize);
+            for (int dz = -1; dz <= 1; ++dz) {
+                for (int dx = -1; dx <= 1; ++dx) {
+                    auto found = cells.find(CellKey{cell.x + dx, cell.z + dz});
+                    if (found == cells.end()) continue;
+                    for (int j : found->second) {
+                        if (!(j > i)) continue;
+                        const SepAgent b = agents[j];
+                        const sge_controller_params& Pb = w.params[b.entity];
+                        float aMin = a.position.y - a.halfHeight, aMax = a.position.y + a.halfHeight;
+                        float bMin = b.position.y - b.halfHeight, bMax = b.position.y + b.halfHeight;
+                        float ddx = a.position.x - b.position.x, ddz = a.position.z - b.position.z;
+                        float distSq = ddx * ddx + ddz * ddz;
+                        float skinAllowance = fmin_s(Pa.skinWidth, Pb.skinWidth);
+                        float margin = fmin_s(separationMargin, skinAllowance);
+                        float minDist = a.radius + b.radius + margin;
+                        bool heightSeparated = aMax < bMin - heightMargin || aMin > bMax + heightMargin;
+                        if (heightSeparated) continue;
+                        if (distSq >= minDist * minDist) continue;
+                        float dist = sqrtf(fmax_s(distSq, 1e-8f));
+                        float nx = ddx / dist, nz = ddz / dist;
+                        float penetration = minDist - dist;
+                        float wSum = a.invWeight + b.invWeight;
+                        if (wSum <= 0) continue;
+                        float corr = penetration / wSum;
+                        V3 moveA{nx * corr * a.invWeight, 0, nz * corr * a.invWeight};
+                        V3 moveB{-nx * corr * b.invWeight, 0, -nz * corr * b.invWeight};
+                        V3 relV = a.velocity - b.velocity;
+                        float vn = relV.x * nx + relV.z * nz;
+                        if (vn < 0) {
+                            float impulse = -vn;
+                            float scaleA = a.invWeight / wSum, scaleB = b.invWeight / wSum;
+                            agents[i].velocity.x += nx * impulse * scaleA;
+                            agents[i].velocity.z += nz * impulse * scaleA;
+                            agents[j].velocity.x -= nx * impulse * scaleB;
+                            agents[j].velocity.z -= nz * impulse * scaleB;
+                        }
+                        { // `if let query` :2003
+                            const float eps = 1e-6f;
+                            bool blockedA = false, blockedB = false;
+                            CapsuleCastHit hit;
+                            if (length(moveA) > eps &&
+                                query.capsuleCastCombined(agents[i].position, moveA, a.radius, a.halfHeight, true, false, 0, Pa.collisionMask, hit) &&
+                                hit.toi <= Pa.skinWidth && hit.normal.y < Pa.minGroundDot)
+                                blockedA = true;
+                            if (length(moveB) > eps &&
+                                query.capsuleCastCombined(agents[j].position, moveB, b.radius, b.halfHeight, true, false, 0, Pb.collisionMask, hit) &&
+                                hit.toi <= Pb.skinWidth && hit.normal.y < Pb.minGroundDot)
+                                blockedB = true;
+                            if (blockedA && !blockedB) {
+                                moveA = V3{0, 0, 0};
+                                moveB = V3{-nx * penetration, 0, -nz * penetration};
+                            } else if (blockedB && !blockedA) {
+                                moveB = V3{0, 0, 0};
+                                moveA = V3{nx * penetration, 0, nz * penetration};
+                            } else if (blockedA && blockedB) {
+                                continue;
+                            }
+                        }
+                        agents[i].position += moveA;
+                        agents[j].position += moveB;
+                    }
+                }
+            }
+        }
+    }
+    for (int idx = 0; idx < n; ++idx) { // :2201-2215 + AgentSeparationPostProcessor.apply :2048-2139
+        const SepAgent& agent = agents[idx];
+        sge_body_state& body = w.bodies[agent.entity];
+        const sge_controller_params& P = w.params[agent.entity];
+        sge_controller_state& C = w.controllers[agent.entity];
+        const V3 start = originalPositions[idx];
+        V3 position = agent.position;
+        D3 bodyVelocity = ldd3(body.linearVelocity);
+        V3 delta = position - start;
+        float len = length(delta);
+        bool moved = false;
+        if (len > 1e-6f) {
+            moved = true;
+            V3 remaining = delta;
+            position = start;
+            for (int s = 0; s < 2; ++s) { // slideIterations
+                float segLen = length(remaining);
+                if (segLen < 1e-6f) break;
+                CapsuleCastHit hit;
+                if (query.capsuleCastCombined(position, remaining, agent.radius, agent.halfHeight, true, false, 0, P.collisionMask, hit)) {
+                    SlideHit sh;
+                    sh.isStatic = true; sh.s = hit; sh.a = CapsuleCapsuleHit{0, V3{0, 0, 0}, -1};
+                    bool done = resolveHit(remaining, segLen, sh, P, C, false, false, bodyVelocity, position, false, V3{0, 0, 0}, kAgentSeparation);
+                    if (done) break;
+                } else {
+                    position += remaining;
+                    remaining = V3{0, 0, 0};
+                    break;
+                }
+            }
+        }
+        if (moved && bodyVelocity.y <= 0) { // :2108-2136
+            if (P.snapDistance > 0) {
+                V3 down{0, -1, 0};
+                CapsuleCastHit hit;
+                if (query.capsuleCastCombined(position, down * P.snapDistance, agent.radius, agent.halfHeight, false, true, P.minGroundDot, P.collisionMask, hit) &&
+                    hit.toi <= P.snapDistance) {
+                    float rawMove = fmax_s(hit.toi - P.groundSnapSkin, 0.0f);
+                    float moveDist = fmin_s(rawMove, P.groundSnapMaxStep);
+                    position += down * moveDist;
+                    C.flags |= SGE_CTRL_GROUNDED;
+                    if (hit.toi <= fmax_s(P.groundSnapSkin, P.skinWidth)) C.flags |= SGE_CTRL_GROUNDED_NEAR; else C.flags &= ~(uint32_t)SGE_CTRL_GROUNDED_NEAR;
+                    V3 gn = hit.material.flattenGround ? V3{0, 1, 0} : hit.triangleNormal;
+                    C.groundNormal[0] = gn.x; C.groundNormal[1] = gn.y; C.groundNormal[2] = gn.z;
+                    C.groundTriangleIndex = hit.triangleIndex;
+                }
+            }
+        }
+        D3 pd = d3(position), vd = d3(agent.velocity);
+        body.position[0] = pd.x; body.position[1] = pd.y; body.position[2] = pd.z;
+        body.linearVelocity[0] = vd.x; body.linearVelocity[1] = vd.y; body.linearVelocity[2] = vd.z;
     }
 }
 

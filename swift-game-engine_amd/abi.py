@@ -36,6 +36,7 @@ CAST, CAST_BLOCKING, CAST_GROUND = 0, 1, 2
 STAGE_INTENT, STAGE_GRAVITY, STAGE_MOVE, STAGE_LOCOMOTION = 1, 2, 4, 8
 STAGE_ACTION, STAGE_POSE, STAGE_WRITEBACK, STAGE_SKIN, STAGE_AGENTS = 16, 32, 64, 128, 256
 STAGE_BLAS_REFIT = 512
+STAGE_SEPARATION = 1024
 STAGE_ALL_FIXED, STAGE_ALL = 0x7F, 0xFF
 # options
 OPT_STORE_POSE_DEBUG, OPT_SKIN_LAYOUT, OPT_PROFILE, OPT_OVERLAP_SKIN, OPT_HEAVY_THRESHOLD, OPT_PLACEMENT_PROBES = 1, 2, 3, 4, 5, 6
@@ -283,6 +284,7 @@ PROTOTYPES = {
     "sge_agents_export": (C.c_int, [VP, VP]),
     "sge_agents_import": (C.c_int, [VP, VP, i32, i32]),
     "sge_profile_read": (C.c_int, [VP, P(StageTimes), C.c_int]),
+    "sge_separation_params": (C.c_int, [VP, C.c_int32, C.c_float, C.c_float]),
     "sge_move_stats_read": (C.c_int, [VP, P(MoveStats), C.c_int]),
     "sge_move_cost_read": (C.c_int, [VP, C.c_int32, C.c_int32, VP]),
     "sge_debug_wave_profile": (C.c_int, [VP, VP, C.c_int32]),

@@ -100,7 +100,8 @@ struct sge_context {
            dBlasIndices, dBlasBounds, dBlasInstances, dBlasRays, dBlasHits, dBlasTileStart, dBlasRoundLen, dBlasRoundCluster, dBlasRoundIds, dBlasWorldBoxes, dBlasUVs;
     bool blasHasUVs = false;
     // stats / profiling
-    DevBuf dStats, dWaveProf, dOrderHist;
+    DevBuf dStats, dWaveProf, dOrderHist, dSepAgents, dSepCounts;
+    int separationIterations = 2; float separationMargin = 0.2f, separationHeightMargin = 0.1f; // AgentSeparationSystem.init :2146-2152
     Events evMove, evPose, evSkin, evAgents, evBlas;
 };
 
@@ -407,7 +408,7 @@ void sge_context_destroy(sge_context* c) {
     drainEvents(c->evMove); drainEvents(c->evPose); drainEvents(c->evSkin); drainEvents(c->evAgents); drainEvents(c->evBlas);
     DevBuf* bufs[] = {&c->dParent, &c->dDepth, &c->dLeanChain, &c->dPath, &c->dBindLocal, &c->dInvBind, &c->dRestT, &c->dRawRestT, &c->dPreRot,
                       &c->dCoeffs, &c->dCoeffCount, &c->dBonePresent, &c->dMeshPos, &c->dMeshNrm, &c->dMeshTan, &c->dMeshIdx, &c->dMeshWgt,
-                      &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dSlotOfRank, &c->dCost, &c->dHint, &c->dHeavyFlags, &c->dJobTable, &c->dBlockJob, &c->dLists, &c->dListCounts, &c->dOrderHist, &c->dWaveProf, &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
+                      &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dSlotOfRank, &c->dCost, &c->dHint, &c->dHeavyFlags, &c->dJobTable, &c->dBlockJob, &c->dLists, &c->dListCounts, &c->dOrderHist, &c->dWaveProf, &c->dSepAgents, &c->dSepCounts, &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
                       &c->dPalettes[0], &c->dPalettes[1], &c->dPoseModel, &c->dPoseLocal, &c->dMoveScratch, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
                       &c->dCellCursor, &c->dAgentMinMax, &c->dAgentGrid, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats,
                       &c->dBlasEntryLink, &c->dBlasWideFirst, &c->dBlasWideParent, &c->dBlasWideLevel, &c->dBlasSlotIdx, &c->dBlasSlotTri,
@@ -1080,6 +1081,16 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         Bracket br(c, &c->evMove);
         launch_move(L, c->stream);
     }
+    if (st & SGE_STAGE_SEPARATION) { // AgentSeparationSystem: after the move stage, before the animation stages (DemoScene.swift:66-71)
+        if (first != 0 || count != c->crowd.count) { set_error("SGE_STAGE_SEPARATION works on the whole crowd (first = 0, count = all)"); return SGE_ERR_INVALID; }
+        if (c->crowd.count > SGE_MAX_SEPARATION_AGENTS) { set_error("SGE_STAGE_SEPARATION: more than SGE_MAX_SEPARATION_AGENTS characters in this context"); return SGE_ERR_CAPACITY; }
+        if (c->col.root < 0 && c->col.triCount != 0) { set_error("collision world not built"); return SGE_ERR_STATE; }
+        int rc;
+        if ((rc = c->dSepAgents.alloc((size_t)SGE_MAX_SEPARATION_AGENTS * kSeparationAgentBytes)) != SGE_OK) return rc;
+        if ((rc = c->dSepCounts.alloc(2 * sizeof(int))) != SGE_OK) return rc;
+        launch_separation(c->crowd, c->col, c->separationIterations, c->separationMargin, c->separationHeightMargin, c->dSepAgents.p,
+                          c->dSepCounts.as<int>(), c->stream);
+    }
     if (st & (SGE_STAGE_LOCOMOTION | SGE_STAGE_ACTION | SGE_STAGE_POSE | SGE_STAGE_WRITEBACK)) {
         if ((st & SGE_STAGE_POSE) && (c->boneCount == 0 || c->prof.count == 0)) { set_error("pose stage needs a skeleton and motion profiles"); return SGE_ERR_STATE; }
         if (st & SGE_STAGE_POSE) {
@@ -1338,6 +1349,14 @@ int sge_profile_read(sge_context* c, sge_stage_times* out, int reset) {
     if (reset) {
         for (Events* e : {&c->evMove, &c->evPose, &c->evSkin, &c->evAgents}) { e->ms = 0; e->launches = 0; }
     }
+    return SGE_OK;
+}
+
+int sge_separation_params(sge_context* c, int32_t iterations, float separation_margin, float height_margin) {
+    if (!c) return SGE_ERR_INVALID;
+    c->separationIterations = iterations < 1 ? 1 : iterations; // max(1, iterations) :2146
+    c->separationMargin = separation_margin;
+    c->separationHeightMargin = height_margin;
     return SGE_OK;
 }
 

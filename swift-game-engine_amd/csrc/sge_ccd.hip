@@ -973,11 +973,21 @@ __device__ __forceinline__ D3 approachVecD(D3 current, D3 target, double maxDelt
 }
 
 struct SlideHit { bool isStatic; CastRec s; float aToi; F3 aNormal; };
+// SlideResolver.SlideOptions (Systems.swift:1208-1222): .kinematicMove / .agentSeparation
+struct SlideOpts { bool allowHorizontalGroundPass, adjustVelocity, useGroundSnapSkinForStatic, allowTriangleNormalGroundLike; };
+__device__ constexpr SlideOpts kKinematicMove{false, true, true, true};
+__device__ constexpr SlideOpts kAgentSeparation{true, false, false, false};
 
-// SlideResolver.resolveHit with options .kinematicMove (Systems.swift:1229-1375)
+// SlideResolver.resolveHit (Systems.swift:1229-1375)
 __device__ __forceinline__ bool resolveHit(F3& remaining, float len, const SlideHit& hit, const sge_controller_params& P,
                                            const sge_controller_state& C, bool wasGrounded, bool wasGroundedNear,
-                                           D3& velocity, F3& position, bool hasCachedSide, F3 cachedSide) {
+                                           D3& velocity, F3& position, bool hasCachedSide, F3 cachedSide,
+                                           const SlideOpts options = kKinematicMove) {
+    if (options.allowHorizontalGroundPass && hit.isStatic && fabsf(remaining.y) < 1e-5f && hit.s.normal.y >= P.minGroundDot) { // :1240-1247
+        position = position + remaining;
+        remaining = F3{0, 0, 0};
+        return true;
+    }
     float contactSkin, hitToi;
     F3 slideNormal, hitTriNormal{0, 0, 0};
     bool hitIsStatic = false, hitIsGroundLike = false;
@@ -985,7 +995,7 @@ __device__ __forceinline__ bool resolveHit(F3& remaining, float len, const Slide
         hitToi = hit.s.toi;
         slideNormal = hit.s.normal;
         hitIsGroundLike = hit.s.triNormal.y >= P.minGroundDot;
-        contactSkin = hitIsGroundLike ? P.groundSnapSkin : P.skinWidth;
+        contactSkin = (options.useGroundSnapSkinForStatic && hitIsGroundLike) ? P.groundSnapSkin : P.skinWidth;
         hitTriNormal = hit.s.triNormal;
         hitIsStatic = true;
     } else {
@@ -1009,7 +1019,7 @@ __device__ __forceinline__ bool resolveHit(F3& remaining, float len, const Slide
         }
     }
     if (slideNormal.y < P.minGroundDot) {
-        if (hitIsStatic && hitIsGroundLike) slideNormal = hitTriNormal;
+        if (hitIsStatic && hitIsGroundLike && options.allowTriangleNormalGroundLike) slideNormal = hitTriNormal;
         if (slideNormal.y < P.minGroundDot) {
             slideNormal.y = 0;
             float nLen = length(slideNormal);
@@ -1063,9 +1073,11 @@ __device__ __forceinline__ bool resolveHit(F3& remaining, float len, const Slide
         return true;
     }
     remaining = leftover;
-    D3 snD = toD(slideNormal);
-    double vInto = dot(velocity, snD);
-    if (vInto < 0) velocity = velocity - snD * vInto;
+    if (options.adjustVelocity) {
+        D3 snD = toD(slideNormal);
+        double vInto = dot(velocity, snD);
+        if (vInto < 0) velocity = velocity - snD * vInto;
+    }
     return false;
 }
 
@@ -2177,6 +2189,259 @@ __global__ __launch_bounds__(kWave, SGE_GROUP_WAVES) void move_group_kernel(Move
             if (pr) atomicAdd(&sp[6], (unsigned long long)pr);
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// AgentSeparationSystem (Systems.swift:1906-2210), canonical order = character index
+// ---------------------------------------------------------------------------
+// The pair loop is sequential by definition — pair (i, j) reads the positions and velocities the pairs before it wrote, and agent
+// i's stale copy `a` taken at the head of loop i (:1952) — and in a crowd the chain of dependent pairs runs through every agent, so
+// there is nothing to spread over the chip: ONE wavefront walks the loop in the reference's order (per agent i: the 3 x 3 cells
+// around it, dz outer, dx inner, the cell's agents in ascending index, j > i) with the live positions / velocities in LDS. The
+// grid of :1915-1944 is only a filter, so it is kept as each agent's cell at rebuild time and a neighbour cell's members are found
+// by a 64-wide scan of those; the two capsuleCastBlocking calls of a pair (:2004-2027) run as one two-ray pass (each ray with its
+// own capsule). The post-process (:2047-2140) is independent per agent: one wavefront each.
+struct SepAgentDev { float position[3], velocity[3], start[3]; float radius, halfHeight, invWeight; int entity; int pad; };
+struct SepLaunch {
+    DevCrowd crowd; DevCollision col;
+    int iterations; float separationMargin, heightMargin;
+    SepAgentDev* agents; int* count; // count[0]: listed agents (0: nothing to post-process)
+};
+__shared__ F3 sSepPos[SGE_MAX_SEPARATION_AGENTS], sSepVel[SGE_MAX_SEPARATION_AGENTS];
+__shared__ int sSepCellX[SGE_MAX_SEPARATION_AGENTS], sSepCellZ[SGE_MAX_SEPARATION_AGENTS];
+
+__global__ __launch_bounds__(kWave) void separation_resolve_kernel(SepLaunch K) {
+    const int lane = laneId();
+    const DevCollision& col = K.col;
+    WaveStats st{0, 0, 0, 0, 0, 0, 0};
+    const int N = K.crowd.count;
+    // ---- the agent list (:2166-2187), in character order ----
+    int n = 0;
+    float maxRadius = 0;
+    for (int base = 0; base < N; base += kWave) {
+        const int e = base + lane;
+        bool solid = false;
+        float radius = 0, invWeight = 0;
+        if (e < N) {
+            const sge_controller_params& P = K.crowd.params[e];
+            const bool present = (P.agentFlags & SGE_AGENT_PRESENT) != 0;
+            solid = present ? (P.agentFlags & SGE_AGENT_SOLID) != 0 : true; // aStore[e] ?? AgentCollisionComponent()
+            radius = (present && (P.agentFlags & SGE_AGENT_RADIUS_OVERRIDE)) ? P.agentRadiusOverride : P.radius;
+            const float massWeight = present ? P.agentMassWeight : 1.0f;
+            invWeight = massWeight > 0 ? 1.0f / massWeight : 0.0f;
+        }
+        const unsigned long long m = __ballot(solid);
+        const int idx = n + prefixCount(m);
+        if (solid && idx < SGE_MAX_SEPARATION_AGENTS) {
+            const sge_body_state& b = K.crowd.bodies[e];
+            SepAgentDev a;
+            for (int k = 0; k < 3; ++k) { a.position[k] = (float)b.position[k]; a.velocity[k] = (float)b.linearVelocity[k]; a.start[k] = a.position[k]; }
+            a.radius = radius; a.halfHeight = K.crowd.params[e].halfHeight; a.invWeight = invWeight; a.entity = e; a.pad = 0;
+            K.agents[idx] = a;
+            sSepPos[idx] = F3{a.position[0], a.position[1], a.position[2]};
+            sSepVel[idx] = F3{a.velocity[0], a.velocity[1], a.velocity[2]};
+        }
+        float r = solid ? radius : 0.0f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) r = smax(r, __shfl_xor(r, o, kWave));
+        maxRadius = smax(maxRadius, r);
+        n += __popcll(m);
+    }
+    __syncthreads();
+    if (N <= 1 || n <= 1 || n > SGE_MAX_SEPARATION_AGENTS) { if (lane == 0) K.count[0] = 0; return; } // guards :2153, :2189 (capacity: sge_tick)
+    const float cellSize = smax(maxRadius * 2 + K.separationMargin, 0.001f);
+    const float separationMargin = K.separationMargin, heightMargin = K.heightMargin;
+    for (int it = 0; it < K.iterations; ++it) {
+        // grid.rebuild (:1930-1936): every agent's cell at this moment
+        for (int i = lane; i < n; i += kWave) {
+            const F3 p = sSepPos[i];
+            sSepCellX[i] = (int)floorf(p.x / cellSize);
+            sSepCellZ[i] = (int)floorf(p.z / cellSize);
+        }
+        __syncthreads();
+        for (int i = 0; i < n; ++i) { // AgentSeparationResolver.resolve :1947-2046
+            const F3 aPos = sSepPos[i], aVel = sSepVel[i]; // the stale copy `a`
+            const SepAgentDev A = K.agents[i];
+            const sge_controller_params& Pa = K.crowd.params[A.entity];
+            const float aSkin = Pa.skinWidth, aMinGroundDot = Pa.minGroundDot;
+            const uint32_t aMask = Pa.collisionMask;
+            const int cx = (int)floorf(aPos.x / cellSize), cz = (int)floorf(aPos.z / cellSize);
+            for (int dz = -1; dz <= 1; ++dz) {
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int tx = cx + dx, tz = cz + dz;
+                    for (int base = (i + 1) & ~(kWave - 1); base < n; base += kWave) {
+                        const int jl = base + lane;
+                        unsigned long long members = __ballot(jl > i && jl < n && sSepCellX[jl] == tx && sSepCellZ[jl] == tz);
+                        while (members) {
+                            const int j = base + __ffsll((long long)members) - 1;
+                            members &= members - 1;
+                            const F3 bPos = sSepPos[j], bVel = sSepVel[j];
+                            const SepAgentDev B = K.agents[j];
+                            const sge_controller_params& Pb = K.crowd.params[B.entity];
+                            const float aMin = aPos.y - A.halfHeight, aMax = aPos.y + A.halfHeight;
+                            const float bMin = bPos.y - B.halfHeight, bMax = bPos.y + B.halfHeight;
+                            const float ddx = aPos.x - bPos.x, ddz = aPos.z - bPos.z;
+                            const float distSq = ddx * ddx + ddz * ddz;
+                            const float skinAllowance = smin(aSkin, Pb.skinWidth);
+                            const float margin = smin(separationMargin, skinAllowance);
+                            const float minDist = A.radius + B.radius + margin;
+                            const bool heightSeparated = aMax < bMin - heightMargin || aMin > bMax + heightMargin;
+                            if (heightSeparated) continue;
+                            if (distSq >= minDist * minDist) continue;
+                            const float dist = sqrtf(smax(distSq, 1e-8f));
+                            const float nx = ddx / dist, nz = ddz / dist;
+                            const float penetration = minDist - dist;
+                            const float wSum = A.invWeight + B.invWeight;
+                            if (wSum <= 0) continue;
+                            const float corr = penetration / wSum;
+                            F3 moveA{nx * corr * A.invWeight, 0, nz * corr * A.invWeight};
+                            F3 moveB{-nx * corr * B.invWeight, 0, -nz * corr * B.invWeight};
+                            const F3 relV = aVel - bVel;
+                            const float vn = relV.x * nx + relV.z * nz;
+                            F3 velI = sSepVel[i], velJ = bVel;
+                            if (vn < 0) {
+                                const float impulse = -vn;
+                                const float scaleA = A.invWeight / wSum, scaleB = B.invWeight / wSum;
+                                velI.x += nx * impulse * scaleA; velI.z += nz * impulse * scaleA;
+                                velJ.x -= nx * impulse * scaleB; velJ.z -= nz * impulse * scaleB;
+                            }
+                            const F3 posI = sSepPos[i]; // the live position of agent i (:2008)
+                            __syncthreads();
+                            sSepVel[i] = velI; sSepVel[j] = velJ;
+                            // the two blocking casts of :2004-2027 as one pass: ray 0 = agent i along moveA, ray 1 = agent j along moveB
+                            const float eps = 1e-6f;
+                            const bool castA = length(moveA) > eps, castB = length(moveB) > eps;
+                            bool blockedA = false, blockedB = false;
+                            if (castA || castB) {
+                                sh.rayFrom[0] = posI; sh.rayDelta[0] = castA ? moveA : F3{0, 0, 0};
+                                sh.rayFrom[1] = bPos; sh.rayDelta[1] = castB ? moveB : F3{0, 0, 0};
+                                __syncthreads();
+                                int itemCount = 0;
+                                F3 minP, maxP;
+                                if (groupSetupRays(col, 0, 1, A.radius, A.halfHeight, true, false, 0.0f, minP, maxP) > 0)
+                                    groupGather(col, 0, 1, minP, maxP, A.radius, false, 0.0f, aMask, itemCount, st);
+                                if (groupSetupRays(col, 1, 1, B.radius, B.halfHeight, true, false, 0.0f, minP, maxP) > 0)
+                                    groupGather(col, 1, 1, minP, maxP, B.radius, false, 0.0f, Pb.collisionMask, itemCount, st);
+                                groupSweep(col, itemCount, st);
+                                blockedA = castA && rayHit(0) && sh.rayRec[0].toi <= aSkin && sh.rayRec[0].normal.y < aMinGroundDot;
+                                blockedB = castB && rayHit(1) && sh.rayRec[1].toi <= Pb.skinWidth && sh.rayRec[1].normal.y < Pb.minGroundDot;
+                            }
+                            if (blockedA && !blockedB) {
+                                moveA = F3{0, 0, 0};
+                                moveB = F3{-nx * penetration, 0, -nz * penetration};
+                            } else if (blockedB && !blockedA) {
+                                moveB = F3{0, 0, 0};
+                                moveA = F3{nx * penetration, 0, nz * penetration};
+                            } else if (blockedA && blockedB) {
+                                continue;
+                            }
+                            __syncthreads();
+                            sSepPos[i] = posI + moveA;
+                            sSepPos[j] = bPos + moveB;
+                            __syncthreads();
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += kWave) {
+        const F3 p = sSepPos[i], v = sSepVel[i];
+        K.agents[i].position[0] = p.x; K.agents[i].position[1] = p.y; K.agents[i].position[2] = p.z;
+        K.agents[i].velocity[0] = v.x; K.agents[i].velocity[1] = v.y; K.agents[i].velocity[2] = v.z;
+    }
+    if (lane == 0) K.count[0] = n;
+}
+
+// AgentSeparationPostProcessor.apply + the write-back of :2201-2215, one wavefront per listed agent
+__global__ __launch_bounds__(kWave, 3) void separation_post_kernel(SepLaunch K) {
+    const int idx = blockIdx.x;
+    if (idx >= K.count[0]) return;
+    const int lane = laneId();
+    const DevCollision& col = K.col;
+    WaveStats st{0, 0, 0, 0, 0, 0, 0};
+    const SepAgentDev A = K.agents[idx];
+    const int e = A.entity;
+    {
+        const uint32_t* gb = reinterpret_cast<const uint32_t*>(K.crowd.bodies + e);
+        const uint32_t* gp = reinterpret_cast<const uint32_t*>(K.crowd.params + e);
+        const uint32_t* gc = reinterpret_cast<const uint32_t*>(K.crowd.controllers + e);
+        if (lane < 24) reinterpret_cast<uint32_t*>(&sBodyA[0])[lane] = gb[lane];
+        if (lane < 16) reinterpret_cast<uint32_t*>(&sParamsA[0])[lane] = gp[lane];
+        if (lane < 32) reinterpret_cast<uint32_t*>(&sCtrlA[0])[lane] = gc[lane];
+        __syncthreads();
+    }
+    sge_body_state& body = sBodyA[0];
+    const sge_controller_params& P = sParamsA[0];
+    sge_controller_state& C = sCtrlA[0];
+    const F3 start{A.start[0], A.start[1], A.start[2]};
+    F3 position{A.position[0], A.position[1], A.position[2]};
+    D3 bodyVelocity{body.linearVelocity[0], body.linearVelocity[1], body.linearVelocity[2]};
+    const F3 delta = position - start;
+    const float len = length(delta);
+    bool moved = false;
+    if (len > 1e-6f) {
+        moved = true;
+        F3 remaining = delta;
+        position = start;
+        for (int s = 0; s < 2; ++s) { // slideIterations :2063
+            const float segLen = length(remaining);
+            if (segLen < 1e-6f) break;
+            __syncthreads();
+            sh.rayCount = 1; sh.rayFrom[0] = position; sh.rayDelta[0] = remaining;
+            __syncthreads();
+            waveCastRays(col, A.radius, A.halfHeight, true, false, 0.0f, P.collisionMask, st);
+            if (rayHit(0)) {
+                SlideHit hit;
+                hit.isStatic = true; hit.s = sh.rayRec[0]; hit.aToi = 0; hit.aNormal = F3{0, 0, 0};
+                const bool done = resolveHit(remaining, segLen, hit, P, C, false, false, bodyVelocity, position, false, F3{0, 0, 0}, kAgentSeparation);
+                if (done) break;
+            } else {
+                position = position + remaining;
+                remaining = F3{0, 0, 0};
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (moved && bodyVelocity.y <= 0 && P.snapDistance > 0) { // :2108-2136
+        const F3 down{0, -1, 0};
+        sh.rayCount = 1; sh.rayFrom[0] = position; sh.rayDelta[0] = down * P.snapDistance;
+        __syncthreads();
+        waveCastRays(col, A.radius, A.halfHeight, false, true, P.minGroundDot, P.collisionMask, st);
+        if (rayHit(0) && sh.rayRec[0].toi <= P.snapDistance) {
+            const CastRec hit = sh.rayRec[0];
+            const float rawMove = smax(hit.toi - P.groundSnapSkin, 0.0f);
+            const float moveDist = smin(rawMove, P.groundSnapMaxStep);
+            position = position + down * moveDist;
+            __syncthreads();
+            uint32_t flags = C.flags | SGE_CTRL_GROUNDED;
+            if (hit.toi <= smax(P.groundSnapSkin, P.skinWidth)) flags |= SGE_CTRL_GROUNDED_NEAR; else flags &= ~(uint32_t)SGE_CTRL_GROUNDED_NEAR;
+            C.flags = flags;
+            const F3 gn = col.materials[hit.triIndex].flatten ? F3{0, 1, 0} : hit.triNormal;
+            st3(C.groundNormal, gn);
+            C.groundTriangleIndex = hit.triIndex;
+        }
+    }
+    __syncthreads();
+    const D3 pd = toD(position), vd = toD(F3{A.velocity[0], A.velocity[1], A.velocity[2]});
+    body.position[0] = pd.x; body.position[1] = pd.y; body.position[2] = pd.z;
+    body.linearVelocity[0] = vd.x; body.linearVelocity[1] = vd.y; body.linearVelocity[2] = vd.z;
+    __syncthreads();
+    uint32_t* gb = reinterpret_cast<uint32_t*>(K.crowd.bodies + e);
+    uint32_t* gc = reinterpret_cast<uint32_t*>(K.crowd.controllers + e);
+    if (lane < 24) gb[lane] = reinterpret_cast<const uint32_t*>(&sBodyA[0])[lane];
+    if (lane < 32) gc[lane] = reinterpret_cast<const uint32_t*>(&sCtrlA[0])[lane];
+}
+
+void launch_separation(const DevCrowd& crowd, const DevCollision& col, int iterations, float separationMargin, float heightMargin,
+                       void* agentScratch, int* counts, hipStream_t s) {
+    if (crowd.count <= 1) return;
+    SepLaunch K{crowd, col, iterations < 1 ? 1 : iterations, separationMargin, heightMargin, reinterpret_cast<SepAgentDev*>(agentScratch), counts};
+    hipLaunchKernelGGL(separation_resolve_kernel, dim3(1), dim3(kWave), 0, s, K);
+    const int grid = crowd.count < SGE_MAX_SEPARATION_AGENTS ? crowd.count : SGE_MAX_SEPARATION_AGENTS;
+    hipLaunchKernelGGL(separation_post_kernel, dim3(grid), dim3(kWave), 0, s, K);
 }
 
 // Picks this step's heavy characters by last step's sweep cost: flags[e] = 1 and an entry in the heavy list (at most

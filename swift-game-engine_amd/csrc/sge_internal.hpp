@@ -229,6 +229,9 @@ constexpr int kMoveScratchBytes = 256;
 constexpr int kTraversalStackCap = 256; // LDS stack of pending wide nodes per query (sge_ccd.hip)
 constexpr int kStatShards = 256; // device counters: kStatShards lines of 8 x u64
 void launch_move(const MoveLaunch& L, hipStream_t s);
+constexpr size_t kSeparationAgentBytes = 56; // SepAgentDev (sge_ccd.hip)
+void launch_separation(const DevCrowd& crowd, const DevCollision& col, int iterations, float separationMargin, float heightMargin,
+                       void* agentScratch, int* counts, hipStream_t s);
 void launch_cast_queries(const DevCollision& col, const sge_capsule_query* d_q, int n, sge_capsule_cast_hit* d_out,
                          unsigned long long* stats, hipStream_t s);
 void launch_overlap_queries(const DevCollision& col, const sge_capsule_query* d_q, int n, int maxHits,

@@ -405,6 +405,11 @@ class CharacterEngine:
         self._call("blas_profile_read", C.byref(ms), C.byref(n), int(reset))
         return ms.value, n.value
 
+    # -- AgentSeparationSystem (Systems.swift:1906-2210) ---------------------- #
+    def separation_params(self, iterations=2, separation_margin=0.2, height_margin=0.1):
+        """AgentSeparationSystem.init(iterations:separationMargin:heightMargin:); the stage itself is abi.STAGE_SEPARATION of tick()."""
+        self._call("separation_params", int(iterations), C.c_float(separation_margin), C.c_float(height_margin))
+
     # -- agents (config 5) -------------------------------------------------- #
     def agents_export(self, out_ptr):
         """Packs this engine's characters as AgentSweepState[count] at `out_ptr`

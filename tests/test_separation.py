@@ -1,0 +1,132 @@
+"""AgentSeparationSystem (Systems.swift:1906-2210), row f3: known answers of the oracle's restatement (CPU), the canonical
+character-index order, and — on the GPU — bit-exact parity of the HIP stage with the oracle on a crowded real scene."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from scenes import build_scene, compare_states
+
+
+def _pair_world(sge, eng, positions, velocities=None, mass=None, solid=None, present=True):
+    ybot, _, _ = build_scene(sge, eng, 1, terrain_cells=None, rings=3, segments=3)
+    n = len(positions)
+    eng.resize(n)
+    params = sge.assets.default_controller_params(n)
+    if present:
+        solid = solid if solid is not None else (True,) * n
+        params["agentFlags"] = [sge.abi.AGENT_PRESENT | (sge.abi.AGENT_SOLID if s else 0) for s in solid]
+        params["agentMassWeight"] = mass if mass is not None else 1.0
+    ctrl = sge.assets.default_controller_state(n)
+    ctrl["flags"] = sge.abi.CTRL_GROUNDED | sge.abi.CTRL_GROUNDED_NEAR
+    bodies = sge.assets.default_bodies(n, np.asarray(positions, np.float64))
+    if velocities is not None:
+        bodies["linearVelocity"] = velocities
+    eng.upload(bodies=bodies, params=params, controllers=ctrl, intents=sge.assets.default_intents(n),
+               locomotion=sge.assets.default_locomotion(n, ybot), actions=sge.assets.default_actions(n, ybot, present=True))
+    return ybot
+
+
+REST_Y = -3.0 + 2.5 + 0.05   # capsule (r 1.5, hh 1.0) resting groundSnapSkin above the quad at y = -3
+
+
+def test_two_overlapping_agents_are_pushed_apart_symmetrically(sge):
+    cpu = ob.oracle_engine()
+    _pair_world(sge, cpu, [(0.0, REST_Y, 0.0), (2.0, REST_Y, 0.0)], velocities=[(1.0, 0, 0), (-1.0, 0, 0)])
+    cpu.tick(dt=1 / 60, stages=sge.abi.STAGE_SEPARATION)
+    d = cpu.download(what=("bodies", "controllers"))
+    x = d["bodies"]["position"][:, 0]
+    # minDist = r + r + min(separationMargin 0.2, skinWidth 0.3) = 3.2 (:1971-1973); equal weights share the correction
+    assert abs((x[1] - x[0]) - 3.2) < 2e-6 and abs(x[0] + 0.6) < 2e-6 and abs(x[1] - 2.6) < 2e-6
+    assert np.allclose(d["bodies"]["position"][:, 1], REST_Y, atol=1e-6) and np.allclose(d["bodies"]["position"][:, 2], 0, atol=1e-7)
+    # approaching along the normal: the relative normal velocity is cancelled, half each (:1991-2000)
+    assert np.allclose(d["bodies"]["linearVelocity"][:, 0], [0.0, 0.0], atol=1e-6)
+    # moved + not rising: the post-process snap marks the agent grounded (:2108-2133)
+    assert ((d["controllers"]["flags"] & sge.abi.CTRL_GROUNDED) != 0).all()
+    cpu.close()
+
+
+def test_weights_height_separation_and_non_solid(sge):
+    cpu = ob.oracle_engine()
+    # massWeight 0 -> invWeight 0: the other agent takes the whole correction (:2172-2177, :1986-1990)
+    _pair_world(sge, cpu, [(0.0, REST_Y, 0.0), (2.0, REST_Y, 0.0)], mass=(0.0, 1.0))
+    cpu.tick(stages=sge.abi.STAGE_SEPARATION)
+    x = cpu.download(what=("bodies",))["bodies"]["position"][:, 0]
+    assert abs(x[0]) < 1e-7 and abs(x[1] - 3.2) < 2e-6
+    # height separated (:1974-1975): nothing happens; positions still go through Float (:2210)
+    _pair_world(sge, cpu, [(0.0, REST_Y, 0.0), (1.0, REST_Y + 2.0 + 2.0 + 0.2, 0.0)])
+    cpu.tick(stages=sge.abi.STAGE_SEPARATION)
+    p = cpu.download(what=("bodies",))["bodies"]["position"]
+    assert np.array_equal(p[:, 0], [0.0, 1.0])
+    # a non-solid agent is not part of the list; an entity WITHOUT the component counts as a default solid agent (:2171)
+    _pair_world(sge, cpu, [(0.0, REST_Y, 0.0), (2.0, REST_Y, 0.0), (0.0, REST_Y, 2.0)], solid=(True, False, True))
+    cpu.tick(stages=sge.abi.STAGE_SEPARATION)
+    p = cpu.download(what=("bodies",))["bodies"]["position"]
+    assert p[1, 0] == 2.0 and abs(p[2, 2] - p[0, 2] - 3.2) < 2e-6
+    _pair_world(sge, cpu, [(0.0, REST_Y, 0.0), (2.0, REST_Y, 0.0)], present=False)
+    cpu.tick(stages=sge.abi.STAGE_SEPARATION)
+    x = cpu.download(what=("bodies",))["bodies"]["position"][:, 0]
+    assert abs((x[1] - x[0]) - 3.2) < 2e-6
+    cpu.close()
+
+
+def test_order_is_the_character_index(sge):
+    """Three agents in a row: pair (0,1) is resolved before (1,2) and (0,2) sees the stale copy of agent 0 (:1952) — the result
+    differs from the mirrored order, so the canonical order is observable."""
+    cpu = ob.oracle_engine()
+    pts = [(0.0, REST_Y, 0.0), (2.0, REST_Y, 0.0), (4.0, REST_Y, 0.0)]
+    _pair_world(sge, cpu, pts, mass=(1, 1, 1), solid=(True, True, True))
+    cpu.separation_params(iterations=1)
+    cpu.tick(stages=sge.abi.STAGE_SEPARATION)
+    a = cpu.download(what=("bodies",))["bodies"]["position"][:, 0].copy()
+    _pair_world(sge, cpu, pts[::-1], mass=(1, 1, 1), solid=(True, True, True))
+    cpu.tick(stages=sge.abi.STAGE_SEPARATION)
+    b = cpu.download(what=("bodies",))["bodies"]["position"][::-1, 0].copy()
+    # pair (0,1): -0.6 / +0.6 -> x = (-0.6, 2.6, 4); then (1,2): dist 1.4, penetration 1.8 -> (-0.6, 1.7, 4.9)
+    assert np.allclose(a, [-0.6, 1.7, 4.9], atol=3e-6)
+    assert np.allclose(b, [-0.9, 2.3, 4.6], atol=3e-6)
+    cpu.separation_params()   # defaults again
+    cpu.close()
+
+
+@pytest.mark.gpu
+def test_separation_stage_gpu_parity(sge):
+    """f3 on the GPU: 192 solid agents crowded onto the real cheese + mirror scene, move-and-slide + character-vs-character sweeps +
+    AgentSeparationSystem every step: positions, velocities and controller state bit-exact with the oracle."""
+    import torch
+
+    gpu = sge.CharacterEngine(0)
+    cpu = ob.oracle_engine()
+    n = 192
+    for e in (gpu, cpu):
+        _, _, st0 = build_scene(sge, e, n, seed=41, mixed=True, agents=True, rings=3, segments=3, asset_scene=("cheese", "mirror"), footprint=60.0)
+        p = st0["params"].copy()
+        p["agentFlags"][::9] = 0                                   # no AgentCollisionComponent: default solid agent
+        p["agentFlags"][4::13] = sge.abi.AGENT_PRESENT               # present, not solid
+        p["agentMassWeight"][::5] = 2.5
+        p["agentMassWeight"][7::31] = 0.0
+        p["agentFlags"][3::17] |= sge.abi.AGENT_RADIUS_OVERRIDE
+        p["agentRadiusOverride"][:] = 1.2
+        e.upload(params=p)
+    ex = sge.parallel.AgentExchange(gpu, n, 0, 1, torch.device("cuda", 0), None)
+    st = (sge.abi.STAGE_ALL & ~sge.abi.STAGE_SKIN) | sge.abi.STAGE_SEPARATION
+    moved = 0
+    for s in range(90):
+        before = gpu.download(what=("bodies",))["bodies"]["position"].copy()
+        ex.step(stages=st)
+        ob.tick_mt(cpu, 8, stages=st | sge.abi.STAGE_AGENTS)
+        if s % 6 == 0 or s == 89:
+            gpu.synchronize()
+            compare_states(sge, gpu, cpu, n)
+    # the stage does something in this scene: compare with a run without it
+    free = ob.oracle_engine()
+    build_scene(sge, free, n, seed=41, mixed=True, agents=True, rings=3, segments=3, asset_scene=("cheese", "mirror"), footprint=60.0)
+    for s in range(90):
+        ob.tick_mt(free, 8, stages=(st & ~sge.abi.STAGE_SEPARATION) | sge.abi.STAGE_AGENTS)
+    a = free.download(what=("bodies",))["bodies"]["position"]
+    b = cpu.download(what=("bodies",))["bodies"]["position"]
+    assert np.abs(a - b).max() > 1e-2, "the scene must exercise agent separation"
+    # capacity and range errors
+    with pytest.raises(sge.SgeError):
+        gpu.tick(stages=sge.abi.STAGE_SEPARATION, first=1, count=5)
+    for e in (gpu, cpu, free):
+        e.close()
