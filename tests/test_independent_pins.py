@@ -1,0 +1,221 @@
+"""Independent pins for the parts of the path the reference holds no vectors for (skinning and all of CCD).
+
+HIP-vs-oracle bit-exactness cannot detect a misreading shared by both sides, so the oracle is checked here against restatements
+that share NO code, precision or algorithm with it:
+  (a) the Metal skinningKernel (RayTracing.metalinc:737-776) as a float64 numpy expression written from the Metal text, on the real
+      Y-Bot mesh;
+  (b) capsule-vs-triangle time of impact by a different numerical route: float64, the distance from a point to a triangle by
+      constrained minimisation over barycentrics (plane projection, else the three edges), the segment-triangle distance by
+      golden-section search along the segment (the distance of a moving point to a convex set is convex), the first contact by pure
+      conservative advancement run to convergence — no Moeller-Trumbore, no Ericson region tests, no minAdvance, no bisection;
+  (c) step-level invariants of the move-and-slide on the engine's own scene (no deep penetration left behind, grounded characters
+      have ground under them).
+All CPU, a few seconds each."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from scenes import build_scene
+
+
+# ---- (a) skinning -------------------------------------------------------------------------------------------------------
+def _metal_skinning_f64(pos, nrm, tan, idx, w, palette):
+    """skinningKernel, RayTracing.metalinc:758-775. palette: [B][16] column-major float4x4 (palette[b] * float4 = sum_c col_c * v_c)."""
+    M = palette.astype(np.float64).reshape(-1, 4, 4).transpose(0, 2, 1)  # [b][row][col]
+    p4 = np.concatenate([pos, np.ones((len(pos), 1))], 1).astype(np.float64)
+    n4 = np.concatenate([nrm, np.zeros((len(pos), 1))], 1).astype(np.float64)
+    t4 = np.concatenate([tan[:, :3], np.zeros((len(pos), 1))], 1).astype(np.float64)
+    acc, nacc, tacc = (np.zeros((len(pos), 3)) for _ in range(3))
+    for j in range(4):
+        wj = w[:, j].astype(np.float64)
+        use = (wj > 0.0)[:, None]                                        # `if (w.x > 0.0)`
+        Mj = M[idx[:, j]]
+        acc += np.where(use, np.einsum("vrc,vc->vr", Mj, p4)[:, :3] * wj[:, None], 0.0)
+        nacc += np.where(use, np.einsum("vrc,vc->vr", Mj, n4)[:, :3] * wj[:, None], 0.0)
+        tacc += np.where(use, np.einsum("vrc,vc->vr", Mj, t4)[:, :3] * wj[:, None], 0.0)
+    nn = nacc / np.linalg.norm(nacc, axis=1, keepdims=True)
+    tt = tacc / np.linalg.norm(tacc, axis=1, keepdims=True)
+    return acc, nn, np.concatenate([tt, tan[:, 3:4].astype(np.float64)], 1)
+
+
+def test_oracle_skinning_matches_float64_literal_of_the_metal_kernel(sge, ybot):
+    cpu = ob.oracle_engine()
+    built, asset = sge.crowd.upload_ybot_mesh(cpu, ybot)
+    mesh = cpu.mesh
+    V, B = mesh["positions"].shape[0], ybot.bone_count
+    assert V == 35440
+    rng = np.random.default_rng(3)
+    # a palette of rigid + slightly sheared matrices (what model * invBind looks like mid-animation)
+    pal = np.zeros((B, 4, 4), np.float64)
+    for b in range(B):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        x, y, z, s = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * s), 2 * (x * z + y * s)],
+                      [2 * (x * y + z * s), 1 - 2 * (x * x + z * z), 2 * (y * z - x * s)],
+                      [2 * (x * z - y * s), 2 * (y * z + x * s), 1 - 2 * (x * x + y * y)]])
+        pal[b, :3, :3] = R + rng.normal(0, 0.02, (3, 3))
+        pal[b, :3, 3] = rng.normal(0, 0.5, 3)
+        pal[b, 3, 3] = 1.0
+    palette = np.ascontiguousarray(pal.transpose(0, 2, 1).reshape(B, 16), np.float32)   # column-major
+    out = [np.zeros((V, 3), np.float32), np.zeros((V, 3), np.float32), np.zeros((V, 4), np.float32)]
+    keep = {k: np.ascontiguousarray(mesh[k]) for k in ("positions", "normals", "tangents", "boneIndices", "boneWeights")}
+    job = dict(sourcePositions=keep["positions"].ctypes.data, sourceNormals=keep["normals"].ctypes.data, sourceTangents=keep["tangents"].ctypes.data,
+               sourceBoneIndices=keep["boneIndices"].ctypes.data, sourceBoneWeights=keep["boneWeights"].ctypes.data, palette=palette.ctypes.data,
+               paletteCount=B, vertexCount=V, dstBaseVertex=0)
+    cpu.skinning_encode(out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, sge.abi.LAYOUT_PACKED, [job])
+    ref = _metal_skinning_f64(keep["positions"], keep["normals"], keep["tangents"], keep["boneIndices"], keep["boneWeights"], palette)
+    assert (keep["boneWeights"] > 0).sum(1).min() >= 1 and (keep["boneWeights"] > 0).sum(1).max() >= 3
+    assert np.abs(out[0] - ref[0]).max() <= 2e-6 * np.abs(ref[0]).max()
+    assert np.abs(out[1] - ref[1]).max() <= 5e-6 and np.abs(out[2] - ref[2]).max() <= 5e-6
+    cpu.close()
+
+
+# ---- (b) capsule-vs-triangle time of impact -------------------------------------------------------------------------------
+def _point_triangle_distance(P, A, B, C):
+    """Distance from points P [n,3] to triangles (A,B,C) [n,3]: the unconstrained minimiser over barycentrics is the plane projection;
+    when it leaves the triangle the constrained minimum lies on an edge."""
+    ab, ac, ap = B - A, C - A, P - A
+    d00, d01, d11 = (ab * ab).sum(1), (ab * ac).sum(1), (ac * ac).sum(1)
+    d20, d21 = (ap * ab).sum(1), (ap * ac).sum(1)
+    den = d00 * d11 - d01 * d01
+    v = (d11 * d20 - d01 * d21) / den
+    w = (d00 * d21 - d01 * d20) / den
+    inside = (v >= 0) & (w >= 0) & (v + w <= 1)
+    proj = A + ab * v[:, None] + ac * w[:, None]
+    best = np.where(inside, np.linalg.norm(P - proj, axis=1), np.inf)
+    for S, E in ((A, B), (B, C), (C, A)):
+        e = E - S
+        t = np.clip(((P - S) * e).sum(1) / (e * e).sum(1), 0, 1)
+        best = np.minimum(best, np.linalg.norm(P - (S + e * t[:, None]), axis=1))
+    return best
+
+
+def _segment_triangle_distance(c, hh, A, B, C, iters=38):
+    """min over the capsule axis {c + (0, s, 0), |s| <= hh} of the point-triangle distance: golden-section search (the distance of a
+    point moving along a line to a convex set is convex in the line parameter)."""
+    g = (np.sqrt(5.0) - 1) / 2
+    lo, hi = -np.full(len(c), hh), np.full(len(c), hh)
+    up = np.array([0.0, 1.0, 0.0])
+    x1, x2 = hi - g * (hi - lo), lo + g * (hi - lo)
+    f1 = _point_triangle_distance(c + up * x1[:, None], A, B, C)
+    f2 = _point_triangle_distance(c + up * x2[:, None], A, B, C)
+    for _ in range(iters):
+        left = f1 < f2
+        hi = np.where(left, x2, hi); lo = np.where(left, lo, x1)
+        x1, x2 = hi - g * (hi - lo), lo + g * (hi - lo)
+        f1 = _point_triangle_distance(c + up * x1[:, None], A, B, C)
+        f2 = _point_triangle_distance(c + up * x2[:, None], A, B, C)
+    return np.minimum(f1, f2)
+
+
+def _first_contact_f64(origin, direction, length, r, hh, A, B, C, tol=2e-6):
+    """Pure conservative advancement: t += dist - r never passes the first contact (the distance is 1-Lipschitz in t).
+    Returns (t, gap): gap = dist - r at the returned t (<= tol: contact, t is within tol / cos(incidence) of it; else the sweep ended)."""
+    n = len(origin)
+    t, gap = np.zeros(n), np.full(n, np.inf)
+    live = np.arange(n)
+    for _ in range(300):
+        d = _segment_triangle_distance(origin[live] + direction[live] * t[live, None], hh, A[live], B[live], C[live])
+        gap[live] = d - r
+        go = (gap[live] > tol) & (t[live] < length[live])
+        live = live[go]
+        if not len(live):
+            break
+        t[live] = np.minimum(t[live] + gap[live], length[live] + 1e-9)
+    return t, gap
+
+
+def test_capsule_triangle_toi_matches_an_independent_float64_method(sge):
+    cpu = ob.oracle_engine()
+    rng = np.random.default_rng(17)
+    n = 10000
+    r, hh = 0.6, 0.45
+    # one well-separated triangle per case (a 22^3 lattice of cells 25 units apart around the origin: float32 keeps ~3e-5 there), one
+    # cast per case, reaching its own triangle only
+    k = np.arange(n)
+    centre = (np.stack([k % 22, (k // 22) % 22, k // 484], -1) - 10.5) * 25.0
+    kind = rng.integers(0, 4, n)
+    shape = np.where((kind == 1)[:, None], [1.0, 0.05, 1.0], np.where((kind == 2)[:, None], [0.05, 1.0, 1.0], [1.0, 1.0, 1.0]))  # floors, walls, any
+    tri = (centre[:, None, :] + rng.normal(0, 1.2, (n, 3, 3)) * shape[:, None, :]).astype(np.float32)
+    T = [tri[:, k].astype(np.float64) for k in range(3)]
+    area = np.linalg.norm(np.cross(T[1] - T[0], T[2] - T[0]), axis=1)
+    # aim from 2.5..6 units away at a point of the triangle (face, edge and vertex regions) with some scatter; overshoot or stop short
+    bary = rng.dirichlet([0.5, 0.5, 0.5], n)
+    target = sum(T[k] * bary[:, k:k + 1] for k in range(3)) + rng.normal(0, 0.25, (n, 3))
+    away = rng.normal(size=(n, 3)); away /= np.linalg.norm(away, axis=1, keepdims=True)
+    away[kind == 3] = [0.0, 1.0, 0.0]                                           # vertical drops, as the ground probe casts them
+    start = (target + away * rng.uniform(2.5, 6.0, (n, 1))).astype(np.float32)
+    delta = ((target - start) * rng.uniform(0.5, 1.5, (n, 1))).astype(np.float32)
+    cpu.rebuild_static([{"positions": tri.reshape(-1, 3), "indices": np.arange(3 * n, dtype=np.uint32)}])
+    kept = cpu.collision_counts()[1]
+    assert kept == (area.astype(np.float32) ** 2 > 1e-10).sum() and kept > n - 50  # the set drops triangles with |e1 x e2|^2 <= 1e-10 (:360)
+    hits = cpu.capsule_cast(sge.make_queries(start, delta, radius=r, half_height=hh, mode=sge.abi.CAST))
+    s64, d64 = start.astype(np.float64), delta.astype(np.float64)
+    length = np.linalg.norm(d64, axis=1)
+    direction = d64 / length[:, None]
+    t64, gap = _first_contact_f64(s64, direction, length, r, hh, *T)
+    d0 = _segment_triangle_distance(s64, hh, *T)
+    # clear cases only: away from the thresholds the two methods treat differently — a start inside the contact band, slivers, and a
+    # contact within a couple of minAdvance steps (max(0.02 r, 1e-4), :1295) of the end of the sweep: the reference's march may step
+    # past maxDistance there and return nil (`t += max(dist - r, minAdvance)`, then `if t > maxDistance { return nil }`, :1303-1321)
+    min_advance = max(0.02 * r, 1e-4)
+    clear_hit = (gap <= 2e-6) & (t64 < length - 2.5 * min_advance) & (d0 > r + 1e-3) & (area > 1e-2)
+    ends_clear = (gap > 5e-3) & (t64 >= length)      # conservative advancement reached the end with 5e-3 to spare: no contact anywhere
+    assert clear_hit.sum() > 4000 and ends_clear.sum() > 500, (clear_hit.sum(), ends_clear.sum())
+    assert (hits["hit"][clear_hit] == 1).all(), "the oracle misses contacts the float64 method finds"
+    assert (hits["hit"][ends_clear] == 0).all(), "the oracle reports contacts where the capsule stays clear by 5e-3"
+    err = hits["toi"][clear_hit].astype(np.float64) - t64[clear_hit]
+    # sweepCapsuleTriangle declares contact at dist <= r + 1e-5 and bisects 10 times on dist <= r (:1308-1322, :1361-1394); the float64
+    # march stops at dist <= r + 2e-6. Both thresholds translate into time through the approach rate -d(dist)/dt at the contact (1 for
+    # a head-on hit, -> 0 for a grazing one), so the two answers may differ by about 1.2e-5 / rate, plus the last bisection bracket / 1024
+    # and float32 rounding at coordinates of a few hundred units
+    h = 1e-3
+    before = _segment_triangle_distance(s64[clear_hit] + direction[clear_hit] * (t64[clear_hit] - h)[:, None], hh, *(t[clear_hit] for t in T))
+    rate = np.maximum((before - (r + gap[clear_hit])) / h, 0.02)
+    bound = 2e-5 / rate + 1.5e-4
+    assert (np.abs(err) <= bound).all(), (np.abs(err) / bound).max()
+    assert np.median(np.abs(err)) < 2e-5 and np.percentile(np.abs(err), 90) < 2e-4, (np.median(np.abs(err)), np.percentile(np.abs(err), 90))
+    # the reported contact: unit normal, and the capsule at the reported toi touches the triangle
+    nrm = hits["normal"][clear_hit].astype(np.float64)
+    assert np.abs(np.linalg.norm(nrm, axis=1) - 1).max() < 1e-5
+    at = s64[clear_hit] + direction[clear_hit] * hits["toi"][clear_hit].astype(np.float64)[:, None]
+    dist_at = _segment_triangle_distance(at, hh, *(t[clear_hit] for t in T))
+    assert np.abs(dist_at - r).max() < 5e-3 and np.percentile(np.abs(dist_at - r), 99) < 2e-4
+    # position = the triangle's closest point (:1340): it lies on the triangle and r away from the axis, along the normal
+    pos = hits["position"][clear_hit].astype(np.float64)
+    assert np.percentile(_point_triangle_distance(pos, *(t[clear_hit] for t in T)), 99) < 1e-4
+    cpu.close()
+
+
+# ---- (c) step invariants on the engine's own scene -----------------------------------------------------------------------
+def test_move_and_slide_invariants_on_the_real_scene(sge):
+    cpu = ob.oracle_engine()
+    n = 96
+    build_scene(sge, cpu, n, seed=23, mixed=True, rings=3, segments=3, asset_scene=("cheese", "semla"), footprint=120.0)
+    st = sge.abi.STAGE_INTENT | sge.abi.STAGE_GRAVITY | sge.abi.STAGE_MOVE
+    P = sge.assets.default_controller_params(1)[0]
+    worst = 0.0
+    for s in range(260):
+        ob.tick_mt(cpu, 8, stages=st)
+        if s < 60 or s % 20:
+            continue
+        d = cpu.download(what=("bodies", "controllers"))
+        pos = d["bodies"]["position"].astype(np.float32)
+        assert np.isfinite(pos).all()
+        # no deep penetration is left behind: DepenetrationResolver pushes out by depth + slop (ground) or up to skinWidth per
+        # iteration, 4 iterations, side contacts (:734-808): what remains is bounded by the capsule radius minus what four side pushes take
+        hit, found = cpu.capsule_overlap(sge.make_queries(pos))
+        depth = np.where(found != 0, hit["depth"], 0.0)
+        worst = max(worst, float(depth.max()))
+        assert depth.max() < 0.5 * P["radius"], depth.max()
+        assert np.percentile(depth, 95) <= P["skinWidth"] + 1e-3
+        # grounded => a walkable triangle within the snap distance below (GroundProbe.resolve :844-853, :868-894)
+        g = (d["controllers"]["flags"] & sge.abi.CTRL_GROUNDED) != 0
+        probes = cpu.capsule_cast(sge.make_queries(pos[g], np.tile([0, -(P["snapDistance"] + 0.2), 0], (g.sum(), 1)), mode=sge.abi.CAST_GROUND))
+        assert g.sum() > n // 3 and (probes["hit"] == 1).all()
+        assert (probes["triangleNormal"][:, 1] >= P["minGroundDot"] - 1e-6).all()
+        # the ground distance the controller reports is what a fresh probe measures from the written-back position, up to the snap move
+        near = (d["controllers"]["flags"] & sge.abi.CTRL_GROUNDED_NEAR) != 0
+        assert (d["controllers"]["groundDistance"][near] <= max(P["groundSnapSkin"], P["skinWidth"]) + 1e-6).all()
+    assert worst > 0.0    # the scene does produce contacts
+    cpu.close()
