@@ -222,6 +222,9 @@ int sge_abi_version(void);
 /* Use the caller's hipStream_t (e.g. torch's current stream) instead of the
  * context-owned one. NULL restores the owned stream. */
 int sge_context_set_stream(sge_context* ctx, void* hip_stream);
+/* The hipStream_t the context currently enqueues on (its own, or the caller's), so that a host can order its own work — an RCCL
+ * collective, a renderer's pass — behind sge_* calls without a host synchronisation. */
+int sge_context_get_stream(sge_context* ctx, void** hip_stream);
 /* Blocks until everything enqueued on the context's stream has completed. */
 int sge_synchronize(sge_context* ctx);
 
@@ -558,6 +561,14 @@ int sge_agents_export(sge_context* ctx, void* d_out);
  * index of this GPU's first character inside it; binned on device into an XZ
  * grid each step when SGE_STAGE_AGENTS is set. */
 int sge_agents_import(sge_context* ctx, const void* d_all, int32_t total, int32_t self_offset);
+/* The whole exchange of the character-vs-character config (collectAgentStates Systems.swift:1592-1611 taken on every GPU)
+ * in one call, stream-ordered on the context's stream, no host synchronisation:
+ *     sge_agents_export into the context's own buffer -> ncclAllGather(comm) -> sge_agents_import of the gathered set.
+ * `nccl_comm` is the caller's ncclComm_t (one rank per GPU; RCCL is resolved at run time from librccl.so, this library does not link
+ * it); rank / world_size are that communicator's; slot = max over ranks of their character counts (every rank contributes `slot`
+ * 32-byte records, padded with radius < 0). Call between the tick with SGE_STAGE_INTENT|GRAVITY and the tick with the remaining stages
+ * + SGE_STAGE_AGENTS, as the snapshot is taken after gravity (Systems.swift:1837-1841). world_size 1 needs no communicator (NULL). */
+int sge_agents_allgather(sge_context* ctx, void* nccl_comm, int32_t rank, int32_t world_size, int32_t slot);
 
 /* Accumulated HIP-event kernel time since the last reset (SGE_OPT_PROFILE). */
 typedef struct sge_stage_times {

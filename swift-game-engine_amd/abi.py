@@ -286,6 +286,8 @@ PROTOTYPES = {
     "sge_profile_read": (C.c_int, [VP, P(StageTimes), C.c_int]),
     "sge_separation_params": (C.c_int, [VP, C.c_int32, C.c_float, C.c_float]),
     "sge_move_stats_read": (C.c_int, [VP, P(MoveStats), C.c_int]),
+    "sge_context_get_stream": (C.c_int, [VP, P(VP)]),
+    "sge_agents_allgather": (C.c_int, [VP, VP, C.c_int32, C.c_int32, C.c_int32]),
     "sge_move_cost_read": (C.c_int, [VP, C.c_int32, C.c_int32, VP]),
     "sge_debug_wave_profile": (C.c_int, [VP, VP, C.c_int32]),
     "sge_debug_move_lists": (C.c_int, [VP, VP, VP]),

@@ -9,6 +9,7 @@
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
+#include <dlfcn.h>
 #include "sge_internal.hpp"
 
 namespace sge {
@@ -87,7 +88,7 @@ struct sge_context {
     int outLayoutAllocated = -1;
     // agents
     DevAgents agents{};
-    DevBuf dCellStart, dCellItems, dCellCursor, dAgentMinMax, dAgentGrid;
+    DevBuf dCellStart, dCellItems, dCellCursor, dAgentMinMax, dAgentGrid, dAgentsAll;
     // scratch for batched queries
     DevBuf dQueries, dCastOut, dOverlapOut, dCounts;
     // skinned-geometry acceleration structure (RTAccelerationBuilder.swift:75-145)
@@ -410,7 +411,7 @@ void sge_context_destroy(sge_context* c) {
                       &c->dCoeffs, &c->dCoeffCount, &c->dBonePresent, &c->dMeshPos, &c->dMeshNrm, &c->dMeshTan, &c->dMeshIdx, &c->dMeshWgt,
                       &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dSlotOfRank, &c->dCost, &c->dHint, &c->dHeavyFlags, &c->dJobTable, &c->dBlockJob, &c->dLists, &c->dListCounts, &c->dOrderHist, &c->dWaveProf, &c->dSepAgents, &c->dSepCounts, &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
                       &c->dPalettes[0], &c->dPalettes[1], &c->dPoseModel, &c->dPoseLocal, &c->dMoveScratch, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
-                      &c->dCellCursor, &c->dAgentMinMax, &c->dAgentGrid, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats,
+                      &c->dCellCursor, &c->dAgentMinMax, &c->dAgentGrid, &c->dAgentsAll, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats,
                       &c->dBlasEntryLink, &c->dBlasWideFirst, &c->dBlasWideParent, &c->dBlasWideLevel, &c->dBlasSlotIdx, &c->dBlasSlotTri,
                       &c->dBlasIndices, &c->dBlasBounds, &c->dBlasInstances, &c->dBlasRays, &c->dBlasHits, &c->dBlasTileStart,
                       &c->dBlasRoundLen, &c->dBlasRoundCluster, &c->dBlasRoundIds, &c->dBlasWorldBoxes, &c->dBlasUVs};
@@ -432,6 +433,12 @@ int sge_context_set_stream(sge_context* c, void* hip_stream) {
     if (rc != SGE_OK) return rc;
     c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->ownStream;
     c->customStream = hip_stream != nullptr; // on a caller's stream everything stays in that stream's order
+    return SGE_OK;
+}
+
+int sge_context_get_stream(sge_context* c, void** hip_stream) {
+    if (!c || !hip_stream) return SGE_ERR_INVALID;
+    *hip_stream = reinterpret_cast<void*>(c->stream);
     return SGE_OK;
 }
 
@@ -1335,6 +1342,49 @@ int sge_agents_import(sge_context* c, const void* d_all, int32_t total, int32_t 
     c->agents.total = total;
     c->agents.selfOffset = self_offset;
     return SGE_OK;
+}
+
+// RCCL is an optional run-time dependency of exactly one entry point: resolved with dlopen so that single-GPU users of the library
+// need no librccl.so.
+namespace {
+typedef int (*NcclAllGatherFn)(const void*, void*, size_t, int /*ncclDataType_t*/, void* /*ncclComm_t*/, hipStream_t);
+NcclAllGatherFn resolveAllGather() {
+    static NcclAllGatherFn fn = nullptr;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h) fn = reinterpret_cast<NcclAllGatherFn>(dlsym(h, "ncclAllGather"));
+    }
+    return fn;
+}
+} // namespace
+
+int sge_agents_allgather(sge_context* c, void* nccl_comm, int32_t rank, int32_t world_size, int32_t slot) {
+    if (!c || world_size < 1 || rank < 0 || rank >= world_size || slot < c->crowd.count || (world_size > 1 && !nccl_comm)) {
+        set_error("sge_agents_allgather: bad argument (slot must be >= this context's character count)");
+        return SGE_ERR_INVALID;
+    }
+    (void)hipSetDevice(c->device);
+    const size_t slotBytes = (size_t)slot * sizeof(sge_agent_state);
+    int rc;
+    if ((rc = c->dAgentsAll.alloc(slotBytes * world_size)) != SGE_OK) return rc;
+    sge_agent_state* all = c->dAgentsAll.as<sge_agent_state>();
+    sge_agent_state* mine = all + (size_t)rank * slot; // in place: this rank's records sit where the gather puts them
+    // padding entries: radius < 0 (every float of the record = -1 does it)
+    if (slot > c->crowd.count) launch_agents_pad(mine + c->crowd.count, slot - c->crowd.count, c->stream);
+    launch_agents_export(c->crowd, mine, c->stream);
+    if (world_size > 1) {
+        NcclAllGatherFn allGather = resolveAllGather();
+        if (!allGather) { set_error("sge_agents_allgather: librccl.so not found (ncclAllGather)"); return SGE_ERR_STATE; }
+        const int ncclChar = 0; // ncclInt8 / ncclChar
+        const int nr = allGather(mine, all, slotBytes, ncclChar, nccl_comm, c->stream);
+        if (nr != 0) { set_error("ncclAllGather failed with code " + std::to_string(nr)); return SGE_ERR_DEVICE; }
+    }
+    SGE_HIP(hipGetLastError());
+    return sge_agents_import(c, all, slot * world_size, rank * slot);
 }
 
 // ---- diagnostics ------------------------------------------------------------------------------

@@ -2804,6 +2804,16 @@ __global__ void agents_export_kernel(DevCrowd crowd, sge_agent_state* out) {
     a.halfHeight = P.halfHeight;
     out[e] = a;
 }
+__global__ void agents_pad_kernel(sge_agent_state* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    sge_agent_state a{};
+    a.radius = -1.0f; // not an agent
+    out[i] = a;
+}
+void launch_agents_pad(sge_agent_state* d_out, int n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(agents_pad_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_out, n);
+}
 void launch_agents_export(const DevCrowd& crowd, sge_agent_state* d_out, hipStream_t s) {
     if (crowd.count <= 0) return;
     hipLaunchKernelGGL(agents_export_kernel, dim3((crowd.count + 255) / 256), dim3(256), 0, s, crowd, d_out);

@@ -268,6 +268,7 @@ void launch_skin_jobs(const SkinJobDev* d_jobs, const int2* d_blockJob, int bloc
 void launch_store_probe(void* outPos, void* outNrm, void* outTan, int chars, int vertexCount, int dstLayout, hipStream_t s);
 
 void launch_agents_export(const DevCrowd& crowd, sge_agent_state* d_out, hipStream_t s);
+void launch_agents_pad(sge_agent_state* d_out, int n, hipStream_t s);
 
 // boxes of `chars` characters: character k reads vertices [firstVertex + k * vertexCount, +vertexCount) of `positions`
 // (layout SGE_LAYOUT_*) and writes bounds[k][entryCount + 1][6]

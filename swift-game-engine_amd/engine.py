@@ -419,6 +419,17 @@ class CharacterEngine:
     def agents_import(self, all_ptr, total, self_offset):
         self._call("agents_import", C.c_void_p(all_ptr), int(total), int(self_offset))
 
+    def agents_allgather(self, nccl_comm=None, rank=0, world_size=1, slot=None):
+        """export -> ncclAllGather on the context's stream -> import, in one stream-ordered call (product only);
+        nccl_comm: the caller's ncclComm_t as an integer / c_void_p (None with world_size 1)."""
+        self._call("agents_allgather", C.c_void_p(nccl_comm), int(rank), int(world_size), int(self.count if slot is None else slot))
+
+    def stream_handle(self):
+        """The hipStream_t the context enqueues on, as an integer (product only)."""
+        p = C.c_void_p()
+        self._call("context_get_stream", C.byref(p))
+        return p.value or 0
+
     # -- diagnostics ------------------------------------------------------- #
     def profile_read(self, reset=True):
         st = abi.StageTimes()

@@ -26,7 +26,12 @@ def max_shard(n_total, world):
 
 class AgentExchange:
     """The config-5 exchange. Works on any engine exposing agents_export/agents_import with raw
-    pointers: the HIP product (cuda tensors, RCCL) and, in the CPU tests, the oracle (cpu tensors, gloo)."""
+    pointers: the HIP product (cuda tensors, RCCL) and, in the CPU tests, the oracle (cpu tensors, gloo).
+
+    On the product nothing here synchronises with the host: the export kernel, the collective and the import are ordered on the
+    engine's own stream — torch sees that stream as an ExternalStream, and ProcessGroupNCCL orders its collective behind / ahead
+    of the current stream with events. With one rank the whole exchange is the library's own C entry point
+    (sge_agents_allgather, which a Swift / C++ host calls with its ncclComm_t)."""
 
     def __init__(self, engine, n_total, rank, world, device, dist=None):
         import torch
@@ -37,10 +42,20 @@ class AgentExchange:
         self.rank, self.world = rank, world
         self.first, self.count = shard_range(n_total, rank, world)
         self.slot = max_shard(n_total, world)  # all_gather needs equal contributions: pad with radius < 0
-        self.local = torch.zeros((self.slot, 8), dtype=torch.float32, device=device)
-        self.local[:, 3] = -1.0
-        self.all = torch.zeros((world * self.slot, 8), dtype=torch.float32, device=device)
         self.self_offset = rank * self.slot
+        self.product = bool(getattr(engine.t, "is_product", False))
+        self.stream = None
+        self.staged = False
+        if self.product and world == 1:
+            return  # sge_agents_allgather keeps its own buffers
+        self.staged = self.product and dist is not None and dist.get_backend() != "nccl"  # rehearsal: gloo moves host memory
+        if self.product:
+            self.stream = torch.cuda.ExternalStream(engine.stream_handle(), device=device)
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else _Null()
+        with ctx:  # allocation and fill on the stream that will use the buffers
+            self.local = torch.zeros((self.slot, 8), dtype=torch.float32, device=device)
+            self.local[:, 3] = -1.0
+            self.all = torch.zeros((world * self.slot, 8), dtype=torch.float32, device=device)
 
     def step(self, dt=1.0 / 60.0, stages=abi.STAGE_ALL, gravity=(0.0, -98.0, 0.0)):
         """One fixed step with character-vs-character sweeps. The snapshot is taken inside
@@ -49,15 +64,32 @@ class AgentExchange:
         pre = stages & (abi.STAGE_INTENT | abi.STAGE_GRAVITY)
         if pre:
             eng.tick(dt=dt, stages=pre, gravity=gravity)
-        eng.agents_export(self.local.data_ptr())
-        eng.synchronize()  # the engine's stream -> torch's stream
-        if self.world > 1:
-            self.dist.all_gather_into_tensor(self.all, self.local)
-            if self.all.is_cuda:
-                self.torch.cuda.current_stream().synchronize()
+        if self.product and self.world == 1:
+            eng.agents_allgather(None, 0, 1, self.slot)
+        elif self.product and not self.staged:
+            with self.torch.cuda.stream(self.stream):
+                eng.agents_export(self.local.data_ptr())
+                self.dist.all_gather_into_tensor(self.all, self.local)
+            eng.agents_import(self.all.data_ptr(), self.all.shape[0], self.self_offset)
         else:
-            self.all.copy_(self.local)
-            if self.all.is_cuda:
-                self.torch.cuda.current_stream().synchronize()
-        eng.agents_import(self.all.data_ptr(), self.all.shape[0], self.self_offset)
+            eng.agents_export(self.local.data_ptr())
+            if self.staged:  # one-GPU rehearsal of N ranks over gloo: through host memory, synchronising
+                eng.synchronize()
+                host_all = self.torch.zeros(self.all.shape, dtype=self.torch.float32)
+                self.dist.all_gather_into_tensor(host_all, self.local.cpu())
+                self.all.copy_(host_all)
+                self.torch.cuda.synchronize()
+            elif self.world > 1:
+                self.dist.all_gather_into_tensor(self.all, self.local)
+            else:
+                self.all.copy_(self.local)
+            eng.agents_import(self.all.data_ptr(), self.all.shape[0], self.self_offset)
         eng.tick(dt=dt, stages=(stages & ~(abi.STAGE_INTENT | abi.STAGE_GRAVITY)) | abi.STAGE_AGENTS, gravity=gravity)
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -27,3 +27,26 @@ def test_host_mirror_on_gpu(tmp_path, sge):
     out = subprocess.run([build(tmp_path, sge)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "host mirror smoke ok" in out.stdout
+
+
+ALLGATHER_SRC = os.path.join(ROOT, "tests", "cpp", "allgather_smoke.cpp")
+
+
+def build_allgather(tmp_path):
+    exe = str(tmp_path / "allgather_smoke")
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
+    subprocess.check_call([hipcc, "-std=c++17", ALLGATHER_SRC, "-I" + os.path.join(ROOT, "include"), "-L" + PKG, "-lsge_amd", "-lrccl",
+                           "-Wl,-rpath," + PKG, "-o", exe])
+    return exe
+
+
+def test_allgather_host_sample_compiles_and_links(tmp_path, sge):
+    """The C host sequence of the character-vs-character exchange (sge_agents_allgather with the caller's ncclComm_t)."""
+    assert os.path.exists(build_allgather(tmp_path))
+
+
+@pytest.mark.gpu
+def test_allgather_host_sample_on_gpu(tmp_path, sge):
+    out = subprocess.run([build_allgather(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "allgather smoke ok" in out.stdout
