@@ -33,9 +33,9 @@ namespace sge {
 
 constexpr int kWave = 64;
 constexpr int kStackCap = kTraversalStackCap; // wide nodes pending (each pop adds <= 64; sge_api checks the tree depth against it)
-constexpr int kCandCap = 512;
+constexpr int kCandCap = 128;  // every traversal loop stops expanding at 64 pending candidates: 63 + 64 is the most there can be
 constexpr int kRangeCap = 128;
-constexpr int kItemCap = 1024;
+constexpr int kItemCap = 512;   // the queue is topped up / swept before it exceeds 64 + 64 * kMaxRays
 constexpr int kMaxRays = 6;
 #ifndef SGE_GROUP
 #define SGE_GROUP 4
@@ -1696,6 +1696,12 @@ __shared__ int sGroupE[kGroup];    // character index of every member (-1: none)
 // through every wall triangle below a ledge. Exact: a triangle entirely below the capsule's lowest point at t = bestToi (+ margin)
 // cannot be touched before bestToi, and a later or equal hit with a higher visit rank never wins.
 __shared__ F3 sNearMin[kGroup], sNearMax[kGroup];
+// speculative bisection (groupSweep): lane of the refining item a helper works for, and the helpers' answers per item
+#ifndef SGE_BISECT_SPEC
+#define SGE_BISECT_SPEC 1
+#endif
+__shared__ int sSpecOwner[kWave];
+__shared__ unsigned sSpecBits[kWave];
 
 // One cast pass of character g, rays rb .. rb + R - 1 already in sh.rayFrom / sh.rayDelta: the per-ray setup of waveCastRays
 // (CollisionQuery.swift:1021-1035). Returns the number of valid rays and their union box.
@@ -1819,6 +1825,57 @@ __device__ __forceinline__ void groupSweep(const DevCollision& col, int& itemCou
             // loop head of :1303-1307 for the helper's evaluation: the owner's count already includes its own evaluation of this trip
             if (helper) cEval = (bIter + h < bMaxIter) && !(cT > bLen);
         }
+        // ---- speculative bisection -------------------------------------------------------------------------------------
+        // refineTOI (:1361-1377) is ten DEPENDENT evaluations, and every contact goes through it — the longest chain of an ordinary
+        // cast pass (two march steps, ten bisection steps, the final evaluation). The points of the next steps are functions of the
+        // interval only: mid = 0.5 (lo + hi), then 0.5 (lo + mid) or 0.5 (mid + hi), ... Idle lanes evaluate the two (six, fourteen)
+        // descendants of a refining item's midpoint in the trip in which its owner evaluates the midpoint itself — the same float
+        // operations on the same operands — and the owner then walks two (three, four) steps of the bisection at once.
+        // Node numbering: root 1 = the owner's midpoint; 2n = the midpoint after "contact at n" (hi = mid), 2n + 1 after "clear" (lo = mid).
+        const unsigned long long refMask = __ballot(phase == PH_REFINE);
+        const int nOwn = __popcll(refMask);
+        int per = 0, levels = 1;
+        if (SGE_BISECT_SPEC && !spec && nOwn > 0 && nHelp >= 2) {
+            per = nOwn * 14 <= nHelp ? 14 : (nOwn * 6 <= nHelp ? 6 : 2);
+            levels = per == 14 ? 4 : (per == 6 ? 3 : 2);
+        }
+        const bool bspec = per != 0;
+        const int nServe = bspec ? (nOwn < nHelp / per ? nOwn : nHelp / per) : 0;
+        const int oRank = prefixCount(refMask);
+        const bool served = bspec && phase == PH_REFINE && oRank < nServe;
+        const bool bHelper = bspec && ((helpMask >> lane) & 1) && h < nServe * per;
+        int node = 0, bOwnerRank = 0;
+        float bRad = 0;
+        bool ownContact = false;
+        if (bspec) {
+            if (served) { sSpecOwner[oRank] = lane; sSpecBits[oRank] = 0; }
+            __syncthreads();
+            bOwnerRank = bHelper ? h / per : 0;
+            node = bHelper ? h - bOwnerRank * per + 2 : 0;
+            const int src = bHelper ? sSpecOwner[bOwnerRank] : lane;
+            const int oRay = __shfl(myRay, src, kWave);
+            float oLo = __shfl(lo, src, kWave), oHi = __shfl(hi, src, kWave);
+            const float oHalf = __shfl(halfHeight, src, kWave);
+            bRad = __shfl(radius, src, kWave);
+            const F3 o0{__shfl(tri.v0.x, src, kWave), __shfl(tri.v0.y, src, kWave), __shfl(tri.v0.z, src, kWave)};
+            const F3 o1{__shfl(tri.v1.x, src, kWave), __shfl(tri.v1.y, src, kWave), __shfl(tri.v1.z, src, kWave)};
+            const F3 o2{__shfl(tri.v2.x, src, kWave), __shfl(tri.v2.y, src, kWave), __shfl(tri.v2.z, src, kWave)};
+            if (bHelper) {
+                // walk from the root to this node: the bits of `node` below its leading one, most significant first
+                const int depth = 31 - __clz(node); // 1 .. 3
+#pragma unroll
+                for (int i = 2; i >= 0; --i) {
+                    if (i < depth) {
+                        const float mid = 0.5f * (oLo + oHi);
+                        if ((node >> i) & 1) oLo = mid; else oHi = mid;
+                    }
+                }
+                cT = 0.5f * (oLo + oHi);
+                cHalf = oHalf; c0 = o0; c1 = o1; c2 = o2;
+                cFrom = sh.rayFrom[oRay]; cDir = sh.rayDir[oRay];
+                cEval = true;
+            }
+        }
         bool finished = false;
         unsigned long long myKey = ~0ull;
         CastRec rec;
@@ -1846,7 +1903,8 @@ __device__ __forceinline__ void groupSweep(const DevCollision& col, int& itemCou
                     if (advance <= 0) t += minAdvance; else t += advance;
                 }
             } else if (phase == PH_REFINE) {
-                if (dist <= radius) hi = tEval; else lo = tEval;
+                ownContact = dist <= radius;
+                if (ownContact) hi = tEval; else lo = tEval;
                 refineK += 1;
                 if (refineK == 10) { phase = PH_FINAL; tEval = hi; }
             } else { // PH_FINAL :1325-1346
@@ -1869,6 +1927,22 @@ __device__ __forceinline__ void groupSweep(const DevCollision& col, int& itemCou
                     myKey = ((unsigned long long)__float_as_uint(tHit) << 32) | (unsigned)tri.rank;
                     atomicMin(&sh.rayKey[myRay], myKey);
                     finished = true;
+                }
+            }
+        }
+        if (bspec) {
+            if (bHelper && dist <= bRad) atomicOr(&sSpecBits[bOwnerRank], 1u << node);
+            __syncthreads();
+            if (served && phase == PH_REFINE) { // (its own step did not finish the bisection)
+                const unsigned bits = sSpecBits[oRank];
+                int n = ownContact ? 2 : 3;
+                for (int k = 1; k < levels; ++k) {
+                    const float mid = 0.5f * (lo + hi);
+                    const bool c = (bits >> n) & 1;
+                    if (c) hi = mid; else lo = mid;
+                    refineK += 1; evals += 1;
+                    n = 2 * n + (c ? 0 : 1);
+                    if (refineK == 10) { phase = PH_FINAL; tEval = hi; break; }
                 }
             }
         }

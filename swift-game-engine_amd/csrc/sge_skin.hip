@@ -68,6 +68,9 @@ __device__ __forceinline__ VertexIn loadVertex(const SkinLaunch& L, int gid) {
     return v;
 }
 
+#ifndef SGE_SKIN_MIN_BLOCKS
+#define SGE_SKIN_MIN_BLOCKS 1
+#endif
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // One workgroup = one character (or 1/splits of its vertices): the palette is staged once,
@@ -192,8 +195,12 @@ __device__ __forceinline__ void skinRange(const SkinLaunch& L, const int c, cons
 }
 
 template <int SRC_STRIDE, int DST_STRIDE>
-__global__ __launch_bounds__(kSkinBlock) void skin_kernel(SkinLaunch L, int splits, int vertsPerSplit) {
+__global__ __launch_bounds__(kSkinBlock, SGE_SKIN_MIN_BLOCKS) void skin_kernel(SkinLaunch L, int splits, int vertsPerSplit, int wavePriority) {
     __shared__ float4 pal[SGE_MAX_BONES * 3];
+    // issue priority over the waves of other kernels on the same SIMD (s_setprio takes an immediate)
+    if (wavePriority == 1) __builtin_amdgcn_s_setprio(1);
+    else if (wavePriority == 2) __builtin_amdgcn_s_setprio(2);
+    else if (wavePriority == 3) __builtin_amdgcn_s_setprio(3);
     // persistent form (gridDim.x < chars * splits): a workgroup keeps its place on the CU and walks over the work units
     for (int u = blockIdx.x; u < L.chars * splits; u += gridDim.x) {
         const int c = u / splits;
@@ -266,13 +273,16 @@ void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU) {
     int ss = L.srcLayout == SGE_LAYOUT_PADDED16 ? 4 : 3, ds = L.dstLayout == SGE_LAYOUT_PADDED16 ? 4 : 3;
     int ldsPad = 0;
     if (maxWorkgroupsPerCU > 0) {
-        const int perWorkgroup = 160 * 1024 / maxWorkgroupsPerCU, own = (int)sizeof(float4) * SGE_MAX_BONES * 3;
+        static const int totalOverride = getenv("SGE_SKIN_LDS_TOTAL") ? atoi(getenv("SGE_SKIN_LDS_TOTAL")) : 0; // experiments
+        const int perWorkgroup = totalOverride > 0 ? totalOverride : 160 * 1024 / maxWorkgroupsPerCU, own = (int)sizeof(float4) * SGE_MAX_BONES * 3;
         ldsPad = perWorkgroup > own + 256 ? (perWorkgroup - own - 256) & ~255 : 0;
     }
-    if (ss == 3 && ds == 3) hipLaunchKernelGGL((skin_kernel<3, 3>), grid, dim3(kSkinBlock), ldsPad, s, L, splits, vertsPerSplit);
-    else if (ss == 3 && ds == 4) hipLaunchKernelGGL((skin_kernel<3, 4>), grid, dim3(kSkinBlock), ldsPad, s, L, splits, vertsPerSplit);
-    else if (ss == 4 && ds == 3) hipLaunchKernelGGL((skin_kernel<4, 3>), grid, dim3(kSkinBlock), ldsPad, s, L, splits, vertsPerSplit);
-    else hipLaunchKernelGGL((skin_kernel<4, 4>), grid, dim3(kSkinBlock), ldsPad, s, L, splits, vertsPerSplit);
+    static const int prio = getenv("SGE_SKIN_SETPRIO") ? atoi(getenv("SGE_SKIN_SETPRIO")) : 0;
+    const int wp = maxWorkgroupsPerCU > 0 ? prio : 0;
+    if (ss == 3 && ds == 3) hipLaunchKernelGGL((skin_kernel<3, 3>), grid, dim3(kSkinBlock), ldsPad, s, L, splits, vertsPerSplit, wp);
+    else if (ss == 3 && ds == 4) hipLaunchKernelGGL((skin_kernel<3, 4>), grid, dim3(kSkinBlock), ldsPad, s, L, splits, vertsPerSplit, wp);
+    else if (ss == 4 && ds == 3) hipLaunchKernelGGL((skin_kernel<4, 3>), grid, dim3(kSkinBlock), ldsPad, s, L, splits, vertsPerSplit, wp);
+    else hipLaunchKernelGGL((skin_kernel<4, 4>), grid, dim3(kSkinBlock), ldsPad, s, L, splits, vertsPerSplit, wp);
 }
 
 // ---------------------------------------------------------------------------
