@@ -68,8 +68,6 @@ struct WaveShared {
     int rayFilter[kRaySlots];    // bit 0: blockingOnly, bit 1: minNormalY set
     unsigned long long rayKey[kRaySlots]; // (toi bits << 32) | visit rank of the best accepted hit so far
     CastRec rayRec[kRaySlots];
-    OverlapRec ovl[SGE_MAX_OVERLAP_HITS];
-    OverlapRec ovlTmp[SGE_MAX_OVERLAP_HITS];
 };
 
 struct WaveStats { unsigned int queries, candidates, evals, overflow, steps, trips, pruned; };
@@ -90,6 +88,8 @@ __device__ unsigned long long g_cycTraverse, g_cycSweep, g_cycTotal;
 
 // One instance per 64-thread workgroup (= per character / per query).
 __shared__ WaveShared sh;
+// results of capsuleOverlapAll (their own variables, so that kernels without an overlap query do not pay for them in LDS)
+__shared__ OverlapRec sOvl[SGE_MAX_OVERLAP_HITS], sOvlTmp[SGE_MAX_OVERLAP_HITS];
 // The wave-uniform per-character state lives in LDS, not in registers: it is touched only
 // between queries, and every lane reads/writes the same value in lockstep.
 // (indexed by the character's place g in its wavefront: always 0 in the one-character kernels)
@@ -628,7 +628,7 @@ __device__ __forceinline__ int waveCapsuleOverlapAll(const DevCollision& col, F3
     F3 minP = vmin(a0, b0), maxP = vmax(a0, b0);
     F3 ext{radius, radius, radius};
     minP = minP - ext; maxP = maxP + ext;
-    int count = 0; // entries in sh.ovl, sorted by rank
+    int count = 0; // entries in sOvl, sorted by rank
     int stackSize = initTraversal(col), rangeCount = 0, candCount = 0;
     __syncthreads();
     while (true) {
@@ -656,22 +656,22 @@ __device__ __forceinline__ int waveCapsuleOverlapAll(const DevCollision& col, F3
             }
         }
         if (__any(pending)) {
-            // merge: existing sorted list (sh.ovl[0..count)) with this batch's hits extracted in rank order
+            // merge: existing sorted list (sOvl[0..count)) with this batch's hits extracted in rank order
             int ie = 0, k = 0;
             for (; k < maxHits; ++k) {
                 unsigned pr = pending ? (unsigned)rec.rank : 0xffffffffu;
                 unsigned long long pmin = waveMinU64((unsigned long long)pr);
-                unsigned er = ie < count ? (unsigned)sh.ovl[ie].rank : 0xffffffffu;
+                unsigned er = ie < count ? (unsigned)sOvl[ie].rank : 0xffffffffu;
                 if (pmin == 0xffffffffull && er == 0xffffffffu) break;
                 if ((unsigned)pmin < er) {
-                    if (pending && (unsigned)rec.rank == (unsigned)pmin) { sh.ovlTmp[k] = rec; pending = false; }
+                    if (pending && (unsigned)rec.rank == (unsigned)pmin) { sOvlTmp[k] = rec; pending = false; }
                 } else {
-                    if (lane == 0) sh.ovlTmp[k] = sh.ovl[ie];
+                    if (lane == 0) sOvlTmp[k] = sOvl[ie];
                     ie += 1;
                 }
             }
             __syncthreads();
-            if (lane < k) sh.ovl[lane] = sh.ovlTmp[lane];
+            if (lane < k) sOvl[lane] = sOvlTmp[lane];
             count = k;
             __syncthreads();
         }
@@ -1119,14 +1119,14 @@ __device__ __noinline__ void consumeDepen(int g, int nOverlap) { // Depenetratio
         const int n = nOverlap;
         // stable sort by depth descending: deepest and second deepest (first occurrence wins ties)
         int i0 = 0;
-        for (int k = 1; k < n; ++k) if (sh.ovl[k].depth > sh.ovl[i0].depth) i0 = k;
+        for (int k = 1; k < n; ++k) if (sOvl[k].depth > sOvl[i0].depth) i0 = k;
         int i1 = -1;
         for (int k = 0; k < n; ++k) {
             if (k == i0) continue;
-            if (i1 < 0 || sh.ovl[k].depth > sh.ovl[i1].depth) i1 = k;
+            if (i1 < 0 || sOvl[k].depth > sOvl[i1].depth) i1 = k;
         }
-        OverlapRec deepest = sh.ovl[i0];
-        OverlapRec second = i1 >= 0 ? sh.ovl[i1] : deepest;
+        OverlapRec deepest = sOvl[i0];
+        OverlapRec second = i1 >= 0 ? sOvl[i1] : deepest;
         __syncthreads();
         const float slop = smax(P.skinWidth * 0.5f, 0.001f);
         bool sideContact = deepest.normal.y < P.minGroundDot;
@@ -1700,8 +1700,9 @@ __shared__ F3 sNearMin[kGroup], sNearMax[kGroup];
 #ifndef SGE_BISECT_SPEC
 #define SGE_BISECT_SPEC 1
 #endif
-__shared__ int sSpecOwner[kWave];
-__shared__ unsigned sSpecBits[kWave];
+// (at most 31 items are served per trip: every served item has at least two of the <= 63 idle lanes)
+__shared__ unsigned char sSpecOwner[kWave / 2];
+__shared__ unsigned sSpecBits[kWave / 2];
 
 // One cast pass of character g, rays rb .. rb + R - 1 already in sh.rayFrom / sh.rayDelta: the per-ray setup of waveCastRays
 // (CollisionQuery.swift:1021-1035). Returns the number of valid rays and their union box.
@@ -1848,11 +1849,11 @@ __device__ __forceinline__ void groupSweep(const DevCollision& col, int& itemCou
         float bRad = 0;
         bool ownContact = false;
         if (bspec) {
-            if (served) { sSpecOwner[oRank] = lane; sSpecBits[oRank] = 0; }
+            if (served) { sSpecOwner[oRank] = (unsigned char)lane; sSpecBits[oRank] = 0; }
             __syncthreads();
             bOwnerRank = bHelper ? h / per : 0;
             node = bHelper ? h - bOwnerRank * per + 2 : 0;
-            const int src = bHelper ? sSpecOwner[bOwnerRank] : lane;
+            const int src = bHelper ? (int)sSpecOwner[bOwnerRank] : lane;
             const int oRay = __shfl(myRay, src, kWave);
             float oLo = __shfl(lo, src, kWave), oHi = __shfl(hi, src, kWave);
             const float oHalf = __shfl(halfHeight, src, kWave);
@@ -2663,7 +2664,7 @@ __global__ __launch_bounds__(kWave, 3) void overlap_query_kernel(DevCollision co
     if (lane < maxHits) {
         sge_capsule_overlap_hit h;
         if (lane < cnt) {
-            OverlapRec r = sh.ovl[lane];
+            OverlapRec r = sOvl[lane];
             h.depth = r.depth;
             h.position[0] = r.position.x; h.position[1] = r.position.y; h.position[2] = r.position.z;
             h.normal[0] = r.normal.x; h.normal[1] = r.normal.y; h.normal[2] = r.normal.z;
@@ -2727,7 +2728,7 @@ __global__ __launch_bounds__(kWave, 3) void overlap_deepest_kernel(DevCollision 
             unsigned long long k = waveMinU64(key);
             if (k < bestKey) {
                 bestKey = k;
-                if (key == k) sh.ovl[0] = rec;
+                if (key == k) sOvl[0] = rec;
             }
             __syncthreads();
         }
@@ -2736,7 +2737,7 @@ __global__ __launch_bounds__(kWave, 3) void overlap_deepest_kernel(DevCollision 
         sge_capsule_overlap_hit h;
         const bool got = bestKey != ~0ull;
         found[i] = got ? 1 : 0;
-        OverlapRec r = sh.ovl[0];
+        OverlapRec r = sOvl[0];
         F3 z{0, 0, 0};
         F3 p = got ? r.position : z, nn = got ? r.normal : z, tn = got ? r.triNormal : z;
         h.depth = got ? r.depth : 0;

@@ -18,6 +18,6 @@ for lib in libs:
     try:
         d = json.loads(p.stdout.strip().splitlines()[-1])
         k = d["kernels_ms_per_step"]
-        print("%-40s step %.3f ms frac %.3f | lbs %.3f move %.3f pose %.3f | trips/q %.2f" % (name, d["ms_per_step"], d["whole_path_hbm_frac"], k["lbs"], k["move_ccd"], k["pose"], d["ccd"]["sweep_trips_per_query"]), flush=True)
+        print("%-40s step %.3f ms frac %.3f | lbs %.3f (alone %.3f) move %.3f pose %.3f | trips/q %.2f" % (name, d["ms_per_step"], d["whole_path_hbm_frac"], k["lbs"], d.get("lbs_alone", {}).get("ms_per_launch", 0.0), k["move_ccd"], k["pose"], d["ccd"]["sweep_trips_per_query"]), flush=True)
     except Exception as ex:
         print(name, "FAILED", ex, p.stderr[-300:], flush=True)
