@@ -115,6 +115,7 @@ int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t s) {
     return SGE_OK;
 }
 
+constexpr size_t kMaxPendingEvents = 2048;
 int drainEvents(Events& ev) {
     for (auto& pr : ev.pending) {
         SGE_HIP(hipEventSynchronize(pr.second));
@@ -135,7 +136,11 @@ struct Bracket {
         if (c->profile) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
     }
     ~Bracket() {
-        if (c->profile) { (void)hipEventRecord(b, s); ev->pending.emplace_back(a, b); }
+        if (!c->profile) return;
+        (void)hipEventRecord(b, s);
+        ev->pending.emplace_back(a, b);
+        // a host that never calls sge_profile_read must not accumulate events without bound: fold the finished ones in
+        if (ev->pending.size() >= kMaxPendingEvents) (void)drainEvents(*ev);
     }
 };
 
@@ -792,6 +797,20 @@ int checkEntities(const sge_static_mesh_entity* ents, int32_t count) {
     return SGE_OK;
 }
 
+// Builds the new set beside the old one and swaps it in only when the merged world passes uploadCollisionAll's capacity checks:
+// after a rejected rebuild the host arrays and the device world still describe the same (old) triangles.
+int rebuildSet(sge_context* c, HostCollision& slot, const sge_static_mesh_entity* ents, int32_t count) {
+    HostCollision fresh;
+    fresh.rebuild(ents, count);
+    std::swap(slot, fresh);
+    const int rc = uploadCollisionAll(c);
+    if (rc != SGE_OK) {
+        std::swap(slot, fresh);
+        // the capacity checks come before any device work; anything else may have left the device buffers half written
+        if (rc != SGE_ERR_CAPACITY) (void)uploadCollisionAll(c);
+    }
+    return rc;
+}
 } // namespace
 
 int sge_collision_rebuild_static(sge_context* c, const sge_static_mesh_entity* ents, int32_t count) {
@@ -799,8 +818,7 @@ int sge_collision_rebuild_static(sge_context* c, const sge_static_mesh_entity* e
     if (!c || count < 0 || (count > 0 && !ents)) { set_error("sge_collision_rebuild_static: bad argument"); return SGE_ERR_INVALID; }
     int rc = checkEntities(ents, count);
     if (rc != SGE_OK) return rc;
-    c->hostCol.rebuild(ents, count);
-    return uploadCollisionAll(c);
+    return rebuildSet(c, c->hostCol, ents, count);
 }
 
 int sge_collision_rebuild_dynamic(sge_context* c, const sge_static_mesh_entity* ents, int32_t count) {
@@ -808,8 +826,7 @@ int sge_collision_rebuild_dynamic(sge_context* c, const sge_static_mesh_entity* 
     if (!c || count < 0 || (count > 0 && !ents)) { set_error("sge_collision_rebuild_dynamic: bad argument"); return SGE_ERR_INVALID; }
     int rc = checkEntities(ents, count);
     if (rc != SGE_OK) return rc;
-    c->hostDyn.rebuild(ents, count);
-    return uploadCollisionAll(c);
+    return rebuildSet(c, c->hostDyn, ents, count);
 }
 
 int sge_collision_update_transforms(sge_context* c, int32_t set, const int32_t* entities, const float* matrices, int32_t n) {
@@ -1176,6 +1193,8 @@ int sge_blas_build(sge_context* c, const uint32_t* indices, int32_t index_count)
     HostBlas hb;
     if (!hb.build(c->hostMeshPos.data(), c->mesh.vertexCount, indices, index_count, err)) { set_error(err); return SGE_ERR_INVALID; }
     int rc;
+    // a closest-hit query pops the newest wide node first: at most 63 siblings stay pending per level
+    if (hb.levels * 63 + 1 > kBlasTraversalStackCap) { set_error("sge_blas_build: hierarchy too deep for the closest-hit traversal stack"); return SGE_ERR_CAPACITY; }
     hipStream_t s = c->stream;
     if ((rc = upload(c->dBlasEntryLink, hb.entryLink.data(), hb.entryLink.size() * 4, s)) != SGE_OK) return rc;
     if ((rc = upload(c->dBlasWideFirst, hb.wideFirst.data(), hb.wideFirst.size() * 4, s)) != SGE_OK) return rc;

@@ -114,11 +114,12 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, 
 
 template <int TILE>
 static int launchRefitTile(const DevBlas& B, const float* p, int layout, long long firstVertex, int chars, float* bounds, int grid, size_t lds, hipStream_t s) {
-    static bool attrSet = false;
-    if (!attrSet) {
+    static bool attrSet[kMaxDevices] = {};
+    const int devSlot = currentDeviceSlot();
+    if (!attrSet[devSlot]) {
         SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blas_refit_kernel<3, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlasMaxLdsBytes));
         SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blas_refit_kernel<4, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlasMaxLdsBytes));
-        attrSet = true;
+        attrSet[devSlot] = true;
     }
     if (layout == SGE_LAYOUT_PADDED16) hipLaunchKernelGGL((blas_refit_kernel<4, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, B, p, firstVertex, chars, bounds);
     else hipLaunchKernelGGL((blas_refit_kernel<3, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, B, p, firstVertex, chars, bounds);
@@ -128,13 +129,7 @@ static int launchRefitTile(const DevBlas& B, const float* p, int layout, long lo
 int launch_blas_refit(const DevBlas& B, const void* positions, int layout, long long firstVertex, int chars, float* bounds, hipStream_t s) {
     if (chars <= 0) return SGE_OK;
     const size_t lds = blasRefitLdsBytes(B.entryCount, B.tileCount, B.tileCap);
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        cus = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    }
+    const int cus = currentDeviceCUs();
     // persistent: as many workgroups as stay resident together (LDS allows floor(160 KB / lds) per CU)
     const int perCU = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / (lds + 256)));
     const int grid = std::min(chars, cus * perCU);
@@ -183,7 +178,7 @@ __device__ __forceinline__ F3 mul3(const Inv3& m, F3 v) { return F3{dot(m.r0, v)
 template <int STRIDE>
 __device__ __forceinline__ F3 loadP(const float* base, uint32_t i) { const float* p = base + (size_t)i * STRIDE; return F3{p[0], p[1], p[2]}; }
 
-constexpr int kBlasStack = 256;
+constexpr int kBlasStack = kBlasTraversalStackCap;
 
 __device__ __forceinline__ Aff loadInstance(const float* instances, int inst) {
     const float* Mf = instances + (size_t)inst * 16;
@@ -327,7 +322,7 @@ __global__ __launch_bounds__(kWave) void blas_intersect_kernel(BlasTrace T, cons
 
     if (R.instance >= 0) {
         traverse(R.instance);
-    } else {
+    } else if (T.worldBoxesValid) {
         const F3 inv = invDir(wd);
         const int groups = (T.chars + kWave - 1) / kWave;
         const float* groupBoxes = T.worldBoxes + (size_t)T.chars * 6;
@@ -388,7 +383,8 @@ __global__ __launch_bounds__(kWave) void blas_intersect_kernel(BlasTrace T, cons
     hits[blockIdx.x] = H;
 }
 
-void launch_blas_intersect(const BlasTrace& T, const sge_blas_ray* d_rays, int n, sge_blas_hit* d_hits, bool anyInstance, hipStream_t s) {
+void launch_blas_intersect(BlasTrace T, const sge_blas_ray* d_rays, int n, sge_blas_hit* d_hits, bool anyInstance, hipStream_t s) {
+    T.worldBoxesValid = anyInstance && T.worldBoxes != nullptr ? 1 : 0;
     if (n <= 0) return;
     if (anyInstance && T.chars > 0) hipLaunchKernelGGL(blas_world_boxes_kernel, dim3((T.chars + kWave - 1) / kWave), dim3(kWave), 0, s, T, const_cast<float*>(T.worldBoxes));
     if (T.layout == SGE_LAYOUT_PADDED16) hipLaunchKernelGGL((blas_intersect_kernel<4>), dim3(n), dim3(kWave), 0, s, T, d_rays, n, d_hits);

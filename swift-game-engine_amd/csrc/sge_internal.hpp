@@ -225,6 +225,24 @@ struct MoveLaunch {
     int* orderHist;                        // [64] histogram / cursors of the order list (zero between steps)
     unsigned long long* waveProf;          // diagnostics (SGE_WAVE_PROF=1): [ceil(count / kGroup)][8] cycles of each wavefront of move_group_kernel
 };
+// Per-device launch state: a process may hold contexts on several GPUs (sge_context_create(device_index)), and function attributes
+// and the CU count belong to the device that is current at the launch (every entry point calls hipSetDevice(ctx->device) first).
+constexpr int kMaxDevices = 32;
+inline int currentDeviceSlot() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev < 0 || dev >= kMaxDevices ? 0 : dev;
+}
+inline int currentDeviceCUs() {
+    static int cus[kMaxDevices] = {};
+    const int d = currentDeviceSlot();
+    if (!cus[d]) {
+        int n = 256;
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d);
+        cus[d] = n > 0 ? n : 256;
+    }
+    return cus[d];
+}
 constexpr int kMoveScratchBytes = 256;
 constexpr int kTraversalStackCap = 256; // LDS stack of pending wide nodes per query (sge_ccd.hip)
 constexpr int kStatShards = 256; // device counters: kStatShards lines of 8 x u64
@@ -286,7 +304,10 @@ struct BlasTrace {
     const float* worldBoxes; // [chars + ceil(chars / 64)][6]: per instance, then per 64 consecutive instances; filled by
                              // launch_blas_intersect when a ray asks for every instance
     const float* uvs;        // [V][2] of the shared mesh, or null
+    int worldBoxesValid;     // 0: this launch did not refresh worldBoxes — a ray with instance < 0 reports a miss instead of walking
+                             // boxes that are missing or belong to an earlier frame (the host cannot inspect device-resident rays)
 };
-void launch_blas_intersect(const BlasTrace& T, const sge_blas_ray* d_rays, int n, sge_blas_hit* d_hits, bool anyInstance, hipStream_t s);
+constexpr int kBlasTraversalStackCap = 256; // pending wide nodes of one closest-hit query (sge_blas.hip); sge_blas_build checks it
+void launch_blas_intersect(BlasTrace T, const sge_blas_ray* d_rays, int n, sge_blas_hit* d_hits, bool anyInstance, hipStream_t s);
 
 } // namespace sge

@@ -393,11 +393,12 @@ __global__ __launch_bounds__(kBlasRefitBlock) void skin_refit_kernel(SkinLaunch 
 
 template <int TILE>
 static int launchSkinRefitTile(const SkinLaunch& L, const DevBlas& B, float* bounds, int grid, size_t lds, hipStream_t s) {
-    static bool attrSet = false;
-    if (!attrSet) {
+    static bool attrSet[kMaxDevices] = {};
+    const int devSlot = currentDeviceSlot();
+    if (!attrSet[devSlot]) {
         SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(skin_refit_kernel<3, 3, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(skin_refit_kernel<3, 4, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attrSet = true;
+        attrSet[devSlot] = true;
     }
     if (L.dstLayout == SGE_LAYOUT_PADDED16) hipLaunchKernelGGL((skin_refit_kernel<3, 4, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, L, B, bounds);
     else hipLaunchKernelGGL((skin_refit_kernel<3, 3, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, L, B, bounds);
@@ -408,13 +409,7 @@ static int launchSkinRefitTile(const SkinLaunch& L, const DevBlas& B, float* bou
 int launch_skin_refit(const SkinLaunch& L, const DevBlas& B, float* bounds, hipStream_t s) {
     if (L.chars <= 0 || L.vertexCount <= 0) return SGE_OK;
     const size_t lds = blasRefitLdsBytes(B.entryCount, B.tileCount, B.tileCap) + 16 + (size_t)L.paletteCount * 48;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        cus = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    }
+    const int cus = currentDeviceCUs();
     const int perCU = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / (lds + 256)));
     const int grid = std::min(L.chars, cus * perCU);
     switch (B.tileCap) {

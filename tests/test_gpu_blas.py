@@ -230,6 +230,19 @@ def test_closest_hit_matches_the_triangle_scan(sge, real, layout):
         hd = d_h.cpu().numpy().view(sge.abi.blas_hit_dtype)
         for f in hd.dtype.names:
             assert np.array_equal(hd[f], ga[f]), f
+        # a caller that promises "no ray asks for every instance" and breaks the promise gets misses for those rays, not a walk
+        # over instance boxes this launch did not refresh; rays that name their character are unaffected
+        mixed = r.copy()
+        mixed["instance"][::2] = I[::2]
+        d_r2 = torch.from_numpy(mixed.view(np.uint8).copy()).to("cuda:0")
+        d_h.zero_()
+        torch.cuda.synchronize()
+        gpu.blas_intersect_device(d_r2.data_ptr(), len(O), d_h.data_ptr(), any_instance=False)
+        gpu.synchronize()
+        hm = d_h.cpu().numpy().view(sge.abi.blas_hit_dtype)
+        assert (hm["hit"][1::2] == 0).all()
+        for f in ("hit", "primitive", "instance"):
+            assert np.array_equal(hm[f][::2], g[f][::2]), f
         cols[1] = cols[0]
         for e in (gpu, cpu):
             e.blas_instances(cols)
