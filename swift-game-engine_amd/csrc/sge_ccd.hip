@@ -40,6 +40,17 @@ constexpr int kMaxRays = 6;
 #ifndef SGE_GROUP
 #define SGE_GROUP 4
 #endif
+// Experiment: one collision wavefront per SIMD that cannot take the place of an LBS workgroup (see launch_move)
+#ifndef SGE_CCD_EXCLUSIVE
+#define SGE_CCD_EXCLUSIVE 0
+#endif
+#if SGE_CCD_EXCLUSIVE == 2
+#define SGE_PAD_VGPRS() do { asm volatile("" ::: "v175"); __builtin_amdgcn_s_setprio(3); } while (0)
+#elif SGE_CCD_EXCLUSIVE
+#define SGE_PAD_VGPRS() asm volatile("" ::: "v175")
+#else
+#define SGE_PAD_VGPRS()
+#endif
 #ifndef SGE_GROUP_WAVES
 #define SGE_GROUP_WAVES 3
 #endif
@@ -1432,7 +1443,8 @@ template <int PART, bool AGENTS, bool HEAVY = false>
 #ifndef SGE_MOVE_WAVES1
 #define SGE_MOVE_WAVES1 4
 #endif
-__global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? 4 : (HEAVY ? 1 : SGE_MOVE_WAVES1)) void move_kernel(MoveLaunch K) {
+__global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? (SGE_CCD_EXCLUSIVE ? 2 : 4) : (HEAVY ? 1 : SGE_MOVE_WAVES1)) void move_kernel(MoveLaunch K) {
+    if (PART == 0) SGE_PAD_VGPRS();
     // PART 1 may run over an index list (light / heavy characters of this step, see classify_kernel)
     if (PART == 1 && K.list && (int)blockIdx.x >= *K.listCount) return;
     const int e = (PART == 1 && K.list) ? K.list[blockIdx.x] : K.first + xcdRemap((int)blockIdx.x, K.count);
@@ -2027,7 +2039,8 @@ __device__ __forceinline__ void groupGather(const DevCollision& col, int rb, int
 }
 
 template <bool AGENTS>
-__global__ __launch_bounds__(kWave, SGE_GROUP_WAVES) void move_group_kernel(MoveLaunch K) {
+__global__ __launch_bounds__(kWave, SGE_CCD_EXCLUSIVE ? 2 : SGE_GROUP_WAVES) void move_group_kernel(MoveLaunch K) {
+    SGE_PAD_VGPRS();
     const int lane = laneId();
     WaveStats st{0, 0, 0, 0, 0, 0, 0};
     const DevCollision& col = K.col;
