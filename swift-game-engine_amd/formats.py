@@ -194,19 +194,28 @@ def matrix_from_array_row_major(values):
     return np.ascontiguousarray(_f32(values).reshape(4, 4).T).reshape(16)
 
 
+def _last_component(name):
+    """`name.split(separator: ":").last`: Swift's split omits empty subsequences ("hips:" -> "hips", ":" -> nil)."""
+    parts = [p for p in name.split(":") if p]
+    return parts[-1] if parts else None
+
+
 def make_bone_remap(skin_bone_names, skeleton_names):
     """makeBoneRemap (SkinnedMeshLoader.swift:139-163): skin bone -> skeleton index by lower-cased name, with the
     part after the last ':' registered too; -1 when missing."""
     lookup = {}
     for i, name in enumerate(skeleton_names):
         lookup[name.lower()] = i
-        lookup[name.split(":")[-1].lower()] = i
+        short = _last_component(name)
+        if short is not None:
+            lookup[short.lower()] = i
     out = np.full(len(skin_bone_names), -1, np.int32)
     for i, name in enumerate(skin_bone_names):
         key = name.lower()
         idx = lookup.get(key)
         if idx is None and ":" in key:
-            idx = lookup.get(key.split(":")[-1])
+            short = _last_component(key)  # (the reference force-unwraps: a key made of colons only would trap there)
+            idx = lookup.get(short) if short is not None else None
         if idx is not None:
             out[i] = idx
     missing = int((out < 0).sum())

@@ -9,6 +9,8 @@ import importlib
 import os
 import subprocess
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "libsge_oracle.so")
@@ -98,3 +100,50 @@ def tick_mt(engine, threads, dt=1.0 / 60.0, stages=None, gravity=(0.0, -98.0, 0.
     d.first, d.count = first, count
     rc = engine.t.lib.sgeo_tick_mt(engine.h, C.byref(d), int(threads))
     assert rc == 0
+
+
+def skinned_mesh_build(payload, skeleton_names, skeleton_inv_bind_model, unit_scale):
+    """The oracle's restatement of SkinnedMeshLoader.buildAsset (oracle/sge_oracle_assets.cpp) on a decoded payload
+    (the dict formats.load_payload / json.load gives) -> the same fields formats.load_skinned_mesh returns."""
+    lib = load_oracle()
+    mesh, bones = payload["mesh"], payload["skin"]["bones"]
+    f32 = lambda a: np.ascontiguousarray(np.asarray(a, np.float32).reshape(-1))
+    pos, nrm, uv, wgt = f32(mesh["positions"]), f32(mesh["normals"]), f32(mesh["uvs"]), f32(mesh["weights"])
+    joints = np.ascontiguousarray(np.asarray(mesh["joints"], np.int64).reshape(-1).astype(np.uint32))
+    idx = np.ascontiguousarray(np.asarray(mesh["indices"], np.uint32).reshape(-1))
+    nb, B = len(bones), len(skeleton_names)
+    cstr = lambda names: (C.c_char_p * len(names))(*[n.encode() for n in names])
+    bone_map = np.zeros(max(nb, 1), np.int32)
+    lib.sgeo_skinned_bone_remap.restype = C.c_int
+    lib.sgeo_skinned_bone_remap(C.c_int32(nb), cstr([b["name"] for b in bones]), C.c_int32(B), cstr(list(skeleton_names)), abi.ptr(bone_map))
+    ibm = np.zeros((max(nb, 1), 16), np.float32)
+    ibm_len = np.zeros(max(nb, 1), np.int32)
+    for i, b in enumerate(bones):
+        m = np.asarray(b["inverseBindMatrix"], np.float32).reshape(-1)
+        ibm_len[i] = len(m)
+        ibm[i, :min(len(m), 16)] = m[:16]
+    skel_ib = np.ascontiguousarray(np.asarray(skeleton_inv_bind_model, np.float32).reshape(-1))
+    V = len(pos) // 3
+    out = {"positions": np.zeros((max(V, 1), 3), np.float32), "normals": np.zeros((max(V, 1), 3), np.float32),
+           "uvs": np.zeros((max(V, 1), 2), np.float32), "boneIndices": np.zeros((max(V, 1), 4), np.uint16),
+           "boneWeights": np.zeros((max(V, 1), 4), np.float32), "invBindModel": np.zeros((B, 16), np.float32)}
+    lib.sgeo_skinned_mesh_build.restype = C.c_int
+    made = lib.sgeo_skinned_mesh_build(
+        C.c_int32(len(pos)), abi.ptr(pos), C.c_int32(len(nrm)), abi.ptr(nrm), C.c_int32(len(uv)), abi.ptr(uv),
+        C.c_int32(len(joints)), abi.ptr(joints), C.c_int32(len(wgt)), abi.ptr(wgt),
+        C.c_int32(nb), abi.ptr(bone_map), abi.ptr(ibm), abi.ptr(ibm_len), C.c_int32(B), abi.ptr(skel_ib), C.c_float(unit_scale),
+        abi.ptr(out["positions"]), abi.ptr(out["normals"]), abi.ptr(out["uvs"]), abi.ptr(out["boneIndices"]),
+        abi.ptr(out["boneWeights"]), abi.ptr(out["invBindModel"]))
+    out = {k: (v[:made] if k != "invBindModel" else v) for k, v in out.items()}
+    out["vertexCount"] = made
+    out["boneMap"] = bone_map[:nb]
+    subs = mesh.get("submeshes") or [{"start": 0, "count": len(idx), "material": "Default"}]
+    out["meshes"] = []
+    lib.sgeo_skinned_submesh.restype = C.c_int
+    for sub in subs if made else []:
+        s0, e0, fits = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        if lib.sgeo_skinned_submesh(C.c_int32(int(sub["start"])), C.c_int32(int(sub["count"])), abi.ptr(idx), C.c_int32(len(idx)),
+                                    C.byref(s0), C.byref(e0), C.byref(fits)):
+            out["meshes"].append({"name": "SkinnedMesh:%s" % sub["material"], "indices": idx[s0.value:e0.value].copy(), "fits16": bool(fits.value)})
+    return out
+

@@ -218,6 +218,58 @@ def test_skinned_loader_semantics(sge, ybot):
     assert F.load_skinned_mesh("/nonexistent.json", ybot, built["invBindModel"]) is None
 
 
+def _same_skinned(a, o):
+    assert a["vertexCount"] == o["vertexCount"]
+    if a["vertexCount"] == 0:
+        assert a["meshes"] == [] and o["meshes"] == []
+        return
+    assert a["boneMap"].tolist() == o["boneMap"].tolist()
+    for k in ("positions", "normals", "uvs", "boneIndices", "boneWeights", "invBindModel"):
+        assert np.array_equal(np.asarray(a[k]).reshape(-1), np.asarray(o[k]).reshape(-1)), k  # bit for bit: same float32 operations
+    assert [m["name"] for m in a["meshes"]] == [m["name"] for m in o["meshes"]]
+    for ma, mo in zip(a["meshes"], o["meshes"]):
+        assert np.array_equal(ma["indices"], mo["indices"])
+
+
+def test_skinned_loader_matches_the_oracle_restatement(sge, ybot):
+    """formats.load_skinned_mesh (the product's host loader) against oracle/sge_oracle_assets.cpp, the C++ restatement of
+    SkinnedMeshLoader.buildAsset (SkinnedMeshLoader.swift:32-188): the small adversarial payload, the FBX-derived Y-Bot, and
+    seeded random payloads (unmapped / out-of-range joints, zero and negative weight sums, prefixed / upper-case / unknown
+    bone names, wrong-length inverse binds, ragged attribute counts, clamped and empty submeshes)."""
+    F = sge.formats
+    built = ob.oracle_engine().build_skeleton(ybot)
+    inv = built["invBindModel"]
+    cases = [small_skinned_payload(), F.load_payload(os.path.join(GOLDEN, "ybot_skinned.npz"))]
+    rng = np.random.default_rng(77)
+    names = list(ybot.names)
+    for k in range(12):
+        V, nb = int(rng.integers(1, 40)), int(rng.integers(1, 12))
+        bones = []
+        for b in range(nb):
+            base = names[int(rng.integers(0, len(names)))]
+            pick = int(rng.integers(0, 6))
+            nm = [base, base.upper(), base.split(":")[-1], "rig:" + base.split(":")[-1], "Unknown%d" % b, base.split(":")[-1].lower() + ":"][pick]
+            m = rng.normal(size=16 if rng.random() > 0.2 else int(rng.integers(0, 20))).astype(np.float32).tolist()
+            bones.append({"name": nm, "inverseBindMatrix": m})
+        w = rng.uniform(-0.2, 1.0, (V, 4)).astype(np.float32)
+        w[rng.random((V, 4)) < 0.3] = 0
+        idx = rng.integers(0, V, int(rng.integers(0, 30))).astype(np.uint32).tolist()
+        payload = {"version": 1,
+                   "mesh": {"positions": rng.normal(size=V * 3).astype(np.float32).tolist(), "normals": rng.normal(size=V * 3).astype(np.float32).tolist(),
+                            "uvs": rng.uniform(size=V * 2).astype(np.float32).tolist(), "joints": rng.integers(0, nb + 3, V * 4).tolist(),
+                            "weights": w.reshape(-1).tolist(), "indices": idx,
+                            "submeshes": [{"start": int(rng.integers(-3, 10)), "count": int(rng.integers(0, 25)), "material": "M%d" % j} for j in range(int(rng.integers(0, 4)))]},
+                   "skin": {"bones": bones}}
+        if k == 5:
+            payload["mesh"]["weights"] = payload["mesh"]["weights"][:-1]  # ragged: both sides produce nothing
+        cases.append(payload)
+    for payload in cases:
+        a = F.load_skinned_mesh(payload, ybot, inv)
+        o = ob.skinned_mesh_build(payload, ybot.names, inv, ybot.unit_scale)
+        _same_skinned(a, o)
+    assert cases[1]["mesh"]["positions"].size == 35440 * 3
+
+
 def test_static_loader_semantics(sge, tmp_path):
     F = sge.formats
     js = {"version": 1, "meshes": [
