@@ -279,6 +279,7 @@ __device__ __forceinline__ void heavyMarch(const DevCollision& col, WaveStats& s
     tri.v0 = tri.v1 = tri.v2 = F3{0, 0, 0}; tri.triIndex = -1; tri.rank = 0x7fffffff;
     F3 triNormal{0, 0, 0};
     float t = 0, lastSafeT = 0, lo = 0, hi = 0, tEval = 0, len = 0;
+    int crawlRun = 0; // consecutive march steps that advanced by exactly minAdvance
     unsigned evals = 0;
     while (true) {
         const unsigned long long want = __ballot(phase == PH_DONE && more);
@@ -297,7 +298,7 @@ __device__ __forceinline__ void heavyMarch(const DevCollision& col, WaveStats& s
                     len = sh.rayLen[myRay];
                     maxIter = sh.rayMaxIter[myRay];
                     phase = PH_MARCH;
-                    t = 0; lastSafeT = 0; lo = 0; hi = 0; tEval = 0; iter = 0; refineK = 0;
+                    t = 0; lastSafeT = 0; lo = 0; hi = 0; tEval = 0; iter = 0; refineK = 0; crawlRun = 0;
                 } else {
                     more = false;
                 }
@@ -313,23 +314,52 @@ __device__ __forceinline__ void heavyMarch(const DevCollision& col, WaveStats& s
             if (lo > bestToi) phase = PH_DONE;
             else tEval = 0.5f * (lo + hi);
         }
+        // ---- speculative crawl (see groupSweep): once the workgroup's queue has run dry, the idle lanes of THIS wavefront evaluate
+        // a creeping item at t_{k+1}, t_{k+2}, ... in the trip in which its owner evaluates t_k. Shuffles and ballots only: the
+        // wavefronts of the workgroup run different numbers of trips, there is no barrier in here.
+        const unsigned long long crawlMask = __ballot(phase == PH_MARCH && crawlRun >= 3);
+        const unsigned long long helpMask = __ballot(phase == PH_DONE && !more);
+        const int nHelp = __popcll(helpMask);
+        const bool spec = crawlMask != 0 && nHelp >= kWave / 2;
+        const int owner = spec ? __ffsll((long long)crawlMask) - 1 : 0;
+        const bool helper = spec && ((helpMask >> lane) & 1);
+        const int h = prefixCount(helpMask); // helper h evaluates t_{k+1+h}
+        bool cEval = phase != PH_DONE;
+        float cT = tEval, cPrev = 0;
+        F3 cFrom = sh.rayFrom[myRay], cDir = sh.rayDir[myRay], c0 = tri.v0, c1 = tri.v1, c2 = tri.v2;
+        if (spec) {
+            const int bRay = __shfl(myRay, owner, kWave), bIter = __shfl(iter, owner, kWave), bMaxIter = __shfl(maxIter, owner, kWave);
+            const float bT = __shfl(t, owner, kWave), bLen = __shfl(len, owner, kWave);
+            const F3 b0{__shfl(tri.v0.x, owner, kWave), __shfl(tri.v0.y, owner, kWave), __shfl(tri.v0.z, owner, kWave)};
+            const F3 b1{__shfl(tri.v1.x, owner, kWave), __shfl(tri.v1.y, owner, kWave), __shfl(tri.v1.z, owner, kWave)};
+            const F3 b2{__shfl(tri.v2.x, owner, kWave), __shfl(tri.v2.y, owner, kWave), __shfl(tri.v2.z, owner, kWave)};
+            if (helper) {
+                c0 = b0; c1 = b1; c2 = b2;
+                cFrom = sh.rayFrom[bRay]; cDir = sh.rayDir[bRay];
+                cT = bT;
+            }
+            for (int k = 0; k < nHelp; ++k) if (helper && k <= h) { cPrev = cT; cT += minAdvance; } // the march's own sequential additions
+            if (helper) cEval = (bIter + h < bMaxIter) && !(cT > bLen); // loop head of :1303-1307 for this evaluation
+        }
+        float dist = 0;
+        F3 segP{0, 0, 0}, triP{0, 0, 0};
+        if (cEval) dist = segmentTriangleDistance(cFrom + cDir * cT, halfHeight, c0, c1, c2, segP, triP);
         if (phase != PH_DONE) {
             evals += 1;
-            const F3 from = sh.rayFrom[myRay], dir = sh.rayDir[myRay];
-            F3 center = from + dir * tEval;
-            F3 segP, triP;
-            float dist = segmentTriangleDistance(center, halfHeight, tri.v0, tri.v1, tri.v2, segP, triP);
+            const F3 dir = cDir;
             if (phase == PH_MARCH) {
                 if (dist <= radius + contactEps) {
-                    float c0 = smax(0.0f, smin(lastSafeT, len));
-                    float c1 = smax(0.0f, smin(t, len));
-                    lo = smin(c0, c1);
-                    hi = smax(c0, c1);
+                    float k0 = smax(0.0f, smin(lastSafeT, len));
+                    float k1 = smax(0.0f, smin(t, len));
+                    lo = smin(k0, k1);
+                    hi = smax(k0, k1);
                     if (hi - lo < 1e-5f) { phase = PH_FINAL; tEval = hi; }
                     else { phase = PH_REFINE; refineK = 0; }
+                    crawlRun = 0;
                 } else {
                     lastSafeT = t;
                     float advance = smax(dist - radius, minAdvance);
+                    crawlRun = advance == minAdvance ? crawlRun + 1 : 0;
                     if (advance <= 0) t += minAdvance; else t += advance;
                 }
             } else if (phase == PH_REFINE) {
@@ -351,6 +381,38 @@ __device__ __forceinline__ void heavyMarch(const DevCollision& col, WaveStats& s
                 }
                 if (ok && hasMinNormalY) ok = !(triN.y < minNormalY);
                 if (ok) atomicMin(&sh.rayKey[myRay], ((unsigned long long)__float_as_uint(tHit) << 32) | (unsigned)tri.rank);
+            }
+        }
+        if (spec) {
+            // did the owner's own evaluation of this trip creep (still marching, advance == minAdvance)? then the helpers' points are its
+            const int ownerCrept = __shfl((int)(phase == PH_MARCH && crawlRun > 0), owner, kWave);
+            if (ownerCrept) {
+                const bool contact = helper && cEval && dist <= radius + contactEps;
+                const float adv = smax(dist - radius, minAdvance);
+                const bool breaks = helper && cEval && !contact && adv != minAdvance;
+                const unsigned long long ev = __ballot(helper && (!cEval || contact || breaks));
+                const int lastHelper = 63 - __clzll((long long)helpMask);
+                const int jl = ev ? __ffsll((long long)ev) - 1 : lastHelper; // the helper whose evaluation decides
+                const int rJ = __shfl(h, jl, kWave);
+                const float tJ = __shfl(cT, jl, kWave), tPrev = __shfl(cPrev, jl, kWave), advJ = __shfl(adv, jl, kWave);
+                const int evalJ = __shfl((int)cEval, jl, kWave), contactJ = __shfl((int)contact, jl, kWave);
+                if (lane == owner) {
+                    if (!ev) {                    // every helper found another creeping step
+                        iter += nHelp; evals += nHelp; crawlRun += nHelp; lastSafeT = tJ; t = tJ + minAdvance;
+                    } else if (!evalJ) {          // the loop ends at helper rJ's evaluation (budget or t > maxDistance): the next head sees it
+                        iter += rJ; evals += rJ; lastSafeT = tPrev; t = tJ; crawlRun = 0;
+                    } else if (contactJ) {        // contact: refineTOI(t0: lastSafeT, t1: t) :1361-1377
+                        iter += rJ + 1; evals += rJ + 1; lastSafeT = tPrev; t = tJ; crawlRun = 0;
+                        float k0 = smax(0.0f, smin(lastSafeT, len));
+                        float k1 = smax(0.0f, smin(t, len));
+                        lo = smin(k0, k1);
+                        hi = smax(k0, k1);
+                        if (hi - lo < 1e-5f) { phase = PH_FINAL; tEval = hi; }
+                        else { phase = PH_REFINE; refineK = 0; }
+                    } else {                      // this evaluation advances further than minAdvance: back to the ordinary march
+                        iter += rJ + 1; evals += rJ + 1; lastSafeT = tJ; t = tJ + advJ; crawlRun = 0;
+                    }
+                }
             }
         }
     }
@@ -378,9 +440,11 @@ __device__ __forceinline__ void heavyHelperLoop(const DevCollision& col, WaveSta
 // independent capsuleCastCombined call of the reference; a work item is a (ray, triangle) pair whose
 // triangle AABB overlaps THAT ray's swept box, so every ray sees exactly its own candidate set.
 // Results: sh.rayKey[r] != initial  <=>  hit, record in sh.rayRec[r].
+// farRay (multi-wave kernel only): the ground probe's 200-unit fall probe, which shares origin and capsule with the snap cast — see
+// the near / far passes of move_group_kernel.
 template <bool HEAVY = false>
 __device__ __forceinline__ void waveCastRays(const DevCollision& col, float radius, float halfHeight, bool blockingOnly,
-                                             bool hasMinNormalY, float minNormalY, uint32_t mask, WaveStats& st) {
+                                             bool hasMinNormalY, float minNormalY, uint32_t mask, WaveStats& st, int farRay = -1) {
     const int lane = laneId();
     const int R = sh.rayCount;
     // per-ray setup (:1021-1035), lanes 0..R-1 in parallel
@@ -428,40 +492,74 @@ __device__ __forceinline__ void waveCastRays(const DevCollision& col, float radi
             hv.radius = radius; hv.halfHeight = halfHeight; hv.minNormalY = minNormalY;
             hv.blockingOnly = blockingOnly ? 1 : 0; hv.hasMinNormalY = hasMinNormalY ? 1 : 0;
         }
-        int hCount = 0;
-        while (true) {
-            while ((stackSize > 0 || rangeCount > 0 || candCount > 0) && hCount <= kHeavyItemCap - kWave * kMaxRays) {
-                while ((stackSize > 0 || rangeCount > 0) && candCount < kWave) expandNodes(col, minP, maxP, mask, stackSize, rangeCount, candCount, st);
-                int n = candCount < kWave ? candCount : kWave;
-                candCount -= n;
-                st.candidates += n;
-                int slot = -1;
-                F3 v0{0, 0, 0}, v1{0, 0, 0}, v2{0, 0, 0};
-                if (lane < n) {
-                    slot = sh.cand[candCount + lane];
-                    const float4* tp = reinterpret_cast<const float4*>(col.tris + slot);
-                    float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
-                    v0 = F3{t0.x, t0.y, t0.z}; v1 = F3{t0.w, t1.x, t1.y}; v2 = F3{t1.z, t1.w, t2.x};
-                    if (hasMinNormalY && tooSteepForGroundCast(v0, v1, v2, minNormalY)) { slot = -1; st.pruned += R; }
+        // one traversal over [bMin, bMax] making items for rays [r0, r1); triangles whose AABB overlaps the skip box belong to an
+        // earlier pass of the same rays
+        auto runPass = [&](F3 bMin, F3 bMax, int r0, int r1, bool skip, F3 sMin, F3 sMax) {
+            int hCount = 0;
+            while (true) {
+                while ((stackSize > 0 || rangeCount > 0 || candCount > 0) && hCount <= kHeavyItemCap - kWave * kMaxRays) {
+                    while ((stackSize > 0 || rangeCount > 0) && candCount < kWave) expandNodes(col, bMin, bMax, mask, stackSize, rangeCount, candCount, st);
+                    int n = candCount < kWave ? candCount : kWave;
+                    candCount -= n;
+                    st.candidates += n;
+                    int slot = -1;
+                    F3 v0{0, 0, 0}, v1{0, 0, 0}, v2{0, 0, 0};
+                    if (lane < n) {
+                        slot = sh.cand[candCount + lane];
+                        const float4* tp = reinterpret_cast<const float4*>(col.tris + slot);
+                        float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                        v0 = F3{t0.x, t0.y, t0.z}; v1 = F3{t0.w, t1.x, t1.y}; v2 = F3{t1.z, t1.w, t2.x};
+                        if (hasMinNormalY && tooSteepForGroundCast(v0, v1, v2, minNormalY)) { slot = -1; st.pruned += r1 - r0; }
+                    }
+                    const F3 bmin = vmin(v0, vmin(v1, v2)), bmax = vmax(v0, vmax(v1, v2));
+                    if (skip && !boxDisjoint(bmin, bmax, sMin, sMax)) slot = -1;
+                    for (int r = r0; r < r1; ++r) {
+                        bool c = slot >= 0 && sh.rayValid[r] && !boxDisjoint(bmin, bmax, sh.rayMin[r], sh.rayMax[r]);
+                        if (c && sh.rayVertical[r]) { c = !verticalSweepMisses(sh.rayFrom[r].x, sh.rayFrom[r].z, radius, v0, v1, v2); st.pruned += c ? 0 : 1; }
+                        unsigned long long mc = __ballot(c);
+                        if (c) hv.items[hCount + prefixCount(mc)] = (int)(((unsigned)r << kItemRayShift) | (unsigned)slot);
+                        hCount += __popcll(mc);
+                    }
+                    __syncthreads();
                 }
-                const F3 bmin = vmin(v0, vmin(v1, v2)), bmax = vmax(v0, vmax(v1, v2));
-                for (int r = 0; r < R; ++r) {
-                    bool c = slot >= 0 && sh.rayValid[r] && !boxDisjoint(bmin, bmax, sh.rayMin[r], sh.rayMax[r]);
-                    if (c && sh.rayVertical[r]) { c = !verticalSweepMisses(sh.rayFrom[r].x, sh.rayFrom[r].z, radius, v0, v1, v2); st.pruned += c ? 0 : 1; }
-                    unsigned long long mc = __ballot(c);
-                    if (c) hv.items[hCount + prefixCount(mc)] = (int)(((unsigned)r << kItemRayShift) | (unsigned)slot);
-                    hCount += __popcll(mc);
-                }
+                if (hCount == 0) break;
+                if (lane == 0) { hv.count = hCount; hv.cursor = 0; hv.cmd = HCMD_MARCH; }
                 __syncthreads();
+                heavyMarch(col, st);
+                __syncthreads();
+                if (lane == 0) hv.cmd = HCMD_NONE;
+                hCount = 0;
+                if (!(stackSize > 0 || rangeCount > 0 || candCount > 0)) break;
             }
-            if (hCount == 0) break;
-            if (lane == 0) { hv.count = hCount; hv.cursor = 0; hv.cmd = HCMD_MARCH; }
-            __syncthreads();
-            heavyMarch(col, st);
-            __syncthreads();
-            if (lane == 0) hv.cmd = HCMD_NONE;
-            hCount = 0;
-            if (!(stackSize > 0 || rangeCount > 0 || candCount > 0)) break;
+        };
+        // near pass: with a fall probe among the rays (and a snap cast beside it) the traversal box is everybody else's; the fall
+        // probe takes its items from the same candidates
+        const bool twoPass = farRay == 1 && R >= 2 && sh.rayValid[0] && sh.rayValid[1]; // ray 0: the snap cast from the same origin
+        F3 nMin = minP, nMax = maxP;
+        if (twoPass) {
+            nMin = F3{kFloatMax, kFloatMax, kFloatMax}; nMax = F3{-kFloatMax, -kFloatMax, -kFloatMax};
+            for (int r = 0; r < R; ++r)
+                if (r != farRay && sh.rayValid[r]) { nMin = vmin(nMin, sh.rayMin[r]); nMax = vmax(nMax, sh.rayMax[r]); }
+        }
+        runPass(nMin, nMax, 0, R, false, nMin, nMax);
+        if (twoPass) {
+            // far pass: the rest of the fall probe's box, clipped to the best hit so far — a triangle entirely below the capsule's
+            // lowest point at t = bestToi cannot be touched before bestToi
+            const int r = farRay;
+            const F3 from = sh.rayFrom[r];
+            const float len = sh.rayLen[r];
+            float reach = len;
+            if (rayHit(r)) reach = smin(len, __uint_as_float((unsigned)(sh.rayKey[r] >> 32)) + (0.05f + 1e-4f * fabsf(from.y)));
+            const F3 ext{radius, radius, radius};
+            const F3 fMin = F3{from.x, from.y - halfHeight - reach, from.z} - ext;
+            const F3 fMax = F3{from.x, from.y + halfHeight, from.z} + ext;
+            if (!(fMin.y >= nMin.y)) { // otherwise inside the near box (same x / z extent: same origin and capsule)
+                __syncthreads();
+                if (lane == 0) { sh.rayMin[r] = vmax(sh.rayMin[r], fMin); sh.rayMax[r] = vmin(sh.rayMax[r], fMax); }
+                stackSize = initTraversal(col); rangeCount = 0; candCount = 0;
+                __syncthreads();
+                runPass(sh.rayMin[r], sh.rayMax[r], r, r + 1, true, nMin, nMax);
+            }
         }
         // rebuild each hit ray's record from its winning (toi, visit rank): the FINAL evaluation of that triangle again
         if (lane < R && rayHit(lane)) {
@@ -1604,7 +1702,8 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? (S
         // ---------------- 2. the query ----------------
         int nOverlap = 0;
         if (PART == 0 && doOverlap) nOverlap = waveCapsuleOverlapAll(col, ms.position, P.radius, P.halfHeight, 8, P.collisionMask, st);
-        if (PART == 1 && doCast) waveCastRays<HEAVY>(col, P.radius, P.halfHeight, blocking, !blocking, P.minGroundDot, P.collisionMask, st);
+        if (PART == 1 && doCast) waveCastRays<HEAVY>(col, P.radius, P.halfHeight, blocking, !blocking, P.minGroundDot, P.collisionMask, st,
+                                                     HEAVY && phase == MP_GROUND_CENTER ? 1 : -1);
         // ---------------- 3. consume ----------------
 #ifdef SGE_DEBUG_RAYS
         if (PART == 1 && lane == 0 && (e == 42 || e == 84) && phase == MP_GROUND_CENTER) {

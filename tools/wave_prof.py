@@ -8,13 +8,18 @@ sge = importlib.import_module("swift-game-engine_amd")
 abi = sge.abi
 which = tuple(sys.argv[1].split(",")) if len(sys.argv) > 1 else ("cheese",)
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+overlap = len(sys.argv) > 3 and sys.argv[3] == "overlap"  # the whole default step: the grouped kernel beside the LBS launch
 eng = sge.CharacterEngine(0)
 ybot = sge.assets.YBotAssets()
-sge.crowd.upload_character_assets(eng, ybot, rings=3, segments=3)
+if overlap:
+    eng.set_option(abi.OPT_OVERLAP_SKIN, 1)
+    sge.crowd.upload_character_assets(eng, ybot)
+else:
+    sge.crowd.upload_character_assets(eng, ybot, rings=3, segments=3)
 scene = sge.crowd.upload_terrain(eng) if which == ("synthetic",) else sge.crowd.upload_asset_scene(eng, which)
 n = 10000
 sge.crowd.spawn_crowd(eng, ybot, n, scene)
-st = abi.STAGE_INTENT | abi.STAGE_GRAVITY | abi.STAGE_MOVE | abi.STAGE_LOCOMOTION | abi.STAGE_ACTION | abi.STAGE_WRITEBACK
+st = abi.STAGE_ALL if overlap else (abi.STAGE_INTENT | abi.STAGE_GRAVITY | abi.STAGE_MOVE | abi.STAGE_LOCOMOTION | abi.STAGE_ACTION | abi.STAGE_WRITEBACK)
 for _ in range(150):
     eng.tick(stages=st)
 eng.synchronize()
@@ -32,7 +37,9 @@ print("rounds median %.0f max %.0f; trips median %.0f max %.0f; steps median %.0
 t0 = p[:, 7].min()
 end = (p[:, 7] - t0 + tot)
 print("launch span %.0f ticks; last wave starts at %.0f" % (end.max(), (p[:, 7] - t0).max()))
-for w in np.argsort(-tot)[:8]:
-    print("wave %5d total %.0f gather %.0f sweep %.0f consume %.0f rounds %d trips %d steps %d start %.0f costs(consecutive, not members) %s" % (
-        w, tot[w], p[w, 1], p[w, 2], p[w, 3], p[w, 4], p[w, 5], p[w, 6], p[w, 7] - t0, cost[w * G:(w + 1) * G].tolist()))
+hist = np.percentile(end, [50, 90, 99, 100])
+print("wave END times after the first start: median %.0f p90 %.0f p99 %.0f max %.0f" % tuple(hist))
+for w in np.argsort(-end)[:8]:
+    print("wave %5d end %.0f total %.0f gather %.0f sweep %.0f consume %.0f rounds %d trips %d steps %d start %.0f costs(consecutive, not members) %s" % (
+        w, end[w], tot[w], p[w, 1], p[w, 2], p[w, 3], p[w, 4], p[w, 5], p[w, 6], p[w, 7] - t0, cost[w * G:(w + 1) * G].tolist()))
 eng.close()
