@@ -61,6 +61,7 @@ struct sge_context {
     float placementMs = 0; int placementTried = 0;
     int overlapSkinWorkgroups = 3; // LBS workgroups per CU while it shares the chip with the next step's collision kernels
     int heavyThreshold = 4000; // distance evaluations in a character's last step above which it takes the multi-wave kernel; < 0: off
+    int heavyCap = 2048;       // most characters the multi-wave launch takes per step (= its grid: workgroups beyond the list exit at once)
     bool skinPending[2] = {false, false}, overlapSkin = false, customStream = false;
     // options
     bool storePoseDebug = false, profile = false;
@@ -389,6 +390,7 @@ sge_context* sge_context_create(int device_index) {
     sge_context* c = new sge_context();
     c->device = device_index;
     if (getenv("SGE_HEAVY_THRESHOLD")) c->heavyThreshold = atoi(getenv("SGE_HEAVY_THRESHOLD")); // experiments
+    if (getenv("SGE_HEAVY_CAP")) c->heavyCap = std::max(1, atoi(getenv("SGE_HEAVY_CAP")));
     if (getenv("SGE_OVERLAP_SKIN_WORKGROUPS")) c->overlapSkinWorkgroups = atoi(getenv("SGE_OVERLAP_SKIN_WORKGROUPS"));
     // the latency-bound collision / pose launches go first when they compete with a streaming skin launch (overlap option)
     int prLeast = 0, prGreatest = 0;
@@ -1095,7 +1097,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         MoveLaunch L{c->crowd, c->col, c->agents, d->dt, d->gravity[0], d->gravity[1], d->gravity[2], st, first, count,
                      c->dStats.as<unsigned long long>(), c->dMoveScratch.p, c->dPlatforms.as<sge_platform_state>(), c->platformCount,
                      c->dCost.as<int>(), getenv("SGE_NO_SPEC") ? nullptr : c->dHint.as<uint8_t>(), c->dLists.as<int>(), c->dListCounts.as<int>(), c->dHeavyFlags.as<uint8_t>(),
-                     c->heavyThreshold, 2048, c->heavyStream, c->evClassified, c->evHeavyDone, nullptr, nullptr, nullptr, nullptr, c->dOrderHist.as<int>(), nullptr};
+                     c->heavyThreshold, c->heavyCap, c->heavyStream, c->evClassified, c->evHeavyDone, nullptr, nullptr, nullptr, nullptr, c->dOrderHist.as<int>(), nullptr};
         if (getenv("SGE_WAVE_PROF")) {
             if (c->dWaveProf.alloc((size_t)c->crowd.count * 64) != SGE_OK) return SGE_ERR_DEVICE;
             SGE_HIP(hipMemsetAsync(c->dWaveProf.p, 0, (size_t)c->crowd.count * 64, c->stream));
