@@ -397,7 +397,22 @@ sge_context* sge_context_create(int device_index) {
     (void)hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest);
     if (hipStreamCreateWithPriority(&c->ownStream, hipStreamNonBlocking, prGreatest) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
     c->stream = c->ownStream;
-    if (hipStreamCreateWithPriority(&c->skinStream, hipStreamNonBlocking, prLeast) != hipSuccess ||
+    // experiment (SGE_SKIN_CUS=n[:pattern]): the skin stream on a subset of the CUs, the rest left to the collision side alone
+    hipError_t skinRc;
+    if (getenv("SGE_SKIN_CUS")) {
+        int n = 256, pattern = 0;
+        sscanf(getenv("SGE_SKIN_CUS"), "%d:%d", &n, &pattern);
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // pattern 0: the first n bits; pattern 1: the first n / 8 bits of every 32-bit word
+        for (int i = 0; i < 256; ++i) {
+            const bool on = pattern == 0 ? i < n : (i % 32) < n / 8;
+            if (on) mask[i / 32] |= 1u << (i % 32);
+        }
+        skinRc = hipExtStreamCreateWithCUMask(&c->skinStream, 8, mask);
+    } else {
+        skinRc = hipStreamCreateWithPriority(&c->skinStream, hipStreamNonBlocking, prLeast);
+    }
+    if (skinRc != hipSuccess ||
         hipEventCreateWithFlags(&c->evPoseDone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evSkinDone[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evSkinDone[1], hipEventDisableTiming) != hipSuccess ||
