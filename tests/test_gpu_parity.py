@@ -955,3 +955,56 @@ def test_api_edge_cases(sge):
     assert lib.sge_tick(h, C.byref(d)) != 0
     assert lib.sge_context_set_option(h, 99, 1) != 0
     gpu.close()
+
+
+def test_full_size_kernel_paths_agree_on_the_real_scene(sge):
+    """BASELINE.json configs[2] on the mesh it names (17-Cheese) at full size, where the oracle is too slow to follow: the three
+    schedules of the move stage must give the same state bit for bit — the default (four characters per wavefront, the expensive
+    few in the multi-wave launch), everybody in the multi-wave launch (its near / far passes and crawl speculation on 10,000
+    characters), and nobody in it (the densely tessellated rim of the cheese, ~900 candidates per cast, inside the grouped kernel:
+    queue overflow sweeps, far passes, speculation at full lane count) — and an oracle run over a random subset must reproduce
+    the default run for those characters."""
+    abi = sge.abi
+    ybot = sge.assets.YBotAssets()
+    n, steps = 10000, 120
+    st = abi.STAGE_ALL & ~abi.STAGE_SKIN  # the skinned output is a function of the palettes, which are compared
+
+    def run(threshold):
+        eng = sge.CharacterEngine(0)
+        sge.crowd.upload_character_assets(eng, ybot, rings=3, segments=3)
+        scene = sge.crowd.upload_asset_scene(eng, ("cheese",))
+        eng.set_option(abi.OPT_HEAVY_THRESHOLD, threshold)
+        state0 = sge.crowd.spawn_crowd(eng, ybot, n, scene)
+        for _ in range(steps):
+            eng.tick(stages=st)
+        eng.synchronize()
+        out = eng.download()
+        pal = eng.palettes(0, 64)[0]
+        stats = eng.move_stats()
+        eng.close()
+        return state0, scene, out, pal, stats
+
+    state0, scene, base, pal0, stats0 = run(4000)
+    assert stats0.overflow == 0
+    for threshold in (0, -1):
+        _, _, other, pal, stats = run(threshold)
+        assert stats.overflow == 0
+        for k in ("bodies", "controllers", "locomotion", "actions"):
+            assert_struct_equal(base[k], other[k], "%s (heavy threshold %d vs default)" % (k, threshold))
+        assert np.array_equal(pal0, pal)
+    # subset against the oracle
+    cpu = ob.oracle_engine()
+    sge.crowd.upload_character_assets(cpu, ybot, rings=3, segments=3)
+    sge.crowd.upload_asset_scene(cpu, ("cheese",))
+    rng = np.random.default_rng(3)
+    cost_rank = np.argsort(-np.abs(base["bodies"]["position"][:, 0]))  # characters near the rim are the expensive ones
+    pick = np.sort(np.unique(np.concatenate([rng.choice(n, 40, replace=False), cost_rank[:24]])))
+    cpu.resize(len(pick))
+    cpu.upload(**{k: v[pick] for k, v in state0.items()})
+    for _ in range(steps):
+        cpu.tick(stages=st)
+    c = cpu.download()
+    assert_struct_equal(base["bodies"][pick], c["bodies"], "bodies(subset vs oracle)")
+    assert_struct_equal(base["controllers"][pick], c["controllers"], "controllers(subset vs oracle)")
+    cpu.close()
+
