@@ -169,10 +169,14 @@ int refreshInvBind(sge_context* c, const float* meshInvBind, int meshInvBindCoun
     return rc;
 }
 
-// The three skinned output streams are the path's HBM traffic (40 B per vertex per step). On MI355X the rate at which a
-// buffer can be streamed to depends on where the driver placed it: the same store pattern runs at 5.3 or at 6.9 TB/s on
-// different hipMalloc results of one process, reproducibly per allocation (tools/alloc_bw.hip, tools/lbs_alloc.py). So a
-// large output set is chosen among a few candidate placements by timing the LBS store pattern on each.
+// The three skinned output streams are the path's HBM traffic (40 B per vertex per step). On MI355X the rate of the three-stream
+// store pattern depends on where the driver placed the buffers: 0.81 or 1.05-1.10 ms for 5.63 GB, bimodal and reproducible per
+// allocation. What decides is the placement of ONE stream — in every exchange of single buffers between a fast and a slow set the
+// 16-byte tangent stream carried the property with it (tools/alloc_probe.hip), and inside one 96 GiB arena the tangent stream is fast
+// anywhere in the first 64 GiB and slow in the rest, with positions and normals fixed (tools/tan_scan.hip); each buffer by itself
+// streams at the same rate wherever it lies. So the streams are probed one at a time, tangents first: candidates for one stream are
+// allocated (and held, so that they land in different places) and timed in the real three-stream pattern with the other two fixed.
+// A candidate costs 16 (or 12) bytes per vertex instead of 40: a crowd that fills half the memory can still be probed.
 int allocCrowdOutputs(sge_context* c) {
     const size_t verts = (size_t)c->crowd.count * (size_t)c->mesh.vertexCount;
     const size_t stride = c->skinLayout == SGE_LAYOUT_PADDED16 ? 16 : 12;
@@ -181,55 +185,60 @@ int allocCrowdOutputs(sge_context* c) {
     c->outLayoutAllocated = c->skinLayout;
     if (need[0] <= bufs[0]->bytes && need[1] <= bufs[1]->bytes && need[2] <= bufs[2]->bytes && bufs[0]->p) return SGE_OK;
     const size_t total = need[0] + need[1] + need[2];
-    int attempts = c->placementProbes;
-    size_t freeB = 0, totalB = 0;
-    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && total > 0) {
-        for (DevBuf* b : bufs) freeB += b->bytes; // about to be released
-        attempts = (int)std::min<size_t>((size_t)std::max(attempts, 1), std::max<size_t>(freeB / 2 / total, 1));
-    }
     for (DevBuf* b : bufs) b->release();
     if (total == 0) return SGE_OK;
-    if (attempts <= 1 || total < ((size_t)256 << 20)) {
-        int rc;
-        for (int k = 0; k < 3; ++k) if ((rc = bufs[k]->alloc(need[k])) != SGE_OK) return rc;
-        return SGE_OK;
-    }
-    struct Candidate { void* p[3]; float ms; };
-    std::vector<Candidate> cands;
+    int rc;
+    for (int k = 0; k < 3; ++k) if ((rc = bufs[k]->alloc(need[k])) != SGE_OK) return rc;
+    c->placementMs = 0;
+    c->placementTried = 1;
+    if (c->placementProbes <= 1 || total < ((size_t)256 << 20)) return SGE_OK;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     SGE_HIP(hipEventCreate(&e0));
     SGE_HIP(hipEventCreate(&e1));
-    const float goodMs = (float)((double)verts * (stride == 16 ? 48.0 : 40.0) / 6.5e12 * 1e3); // 6.5 TB/s: a good placement
-    int best = -1;
-    for (int a = 0; a < attempts; ++a) {
-        Candidate cd{{nullptr, nullptr, nullptr}, 1e30f};
-        bool ok = true;
-        for (int k = 0; k < 3 && ok; ++k) ok = hipMalloc(&cd.p[k], need[k]) == hipSuccess;
-        if (!ok) { for (void* q : cd.p) if (q) (void)hipFree(q); (void)hipGetLastError(); break; }
-        launch_store_probe(cd.p[0], cd.p[1], cd.p[2], c->crowd.count, c->mesh.vertexCount, c->skinLayout, c->stream); // warm: first touch
+    void* cur[3] = {bufs[0]->p, bufs[1]->p, bufs[2]->p};
+    auto probe = [&](void* const p[3], float& ms) -> int {
+        launch_store_probe(p[0], p[1], p[2], c->crowd.count, c->mesh.vertexCount, c->skinLayout, c->stream); // warm: first touch
         SGE_HIP(hipEventRecord(e0, c->stream));
-        for (int r = 0; r < 2; ++r) launch_store_probe(cd.p[0], cd.p[1], cd.p[2], c->crowd.count, c->mesh.vertexCount, c->skinLayout, c->stream);
+        for (int r = 0; r < 2; ++r) launch_store_probe(p[0], p[1], p[2], c->crowd.count, c->mesh.vertexCount, c->skinLayout, c->stream);
         SGE_HIP(hipEventRecord(e1, c->stream));
         SGE_HIP(hipEventSynchronize(e1));
-        SGE_HIP(hipEventElapsedTime(&cd.ms, e0, e1));
-        cd.ms *= 0.5f;
-        cands.push_back(cd);
-        if (best < 0 || cd.ms < cands[best].ms) best = (int)cands.size() - 1;
-        if (cd.ms <= goodMs) break;
+        SGE_HIP(hipEventElapsedTime(&ms, e0, e1));
+        ms *= 0.5f;
+        return SGE_OK;
+    };
+    const float goodMs = (float)((double)verts * (stride == 16 ? 48.0 : 40.0) / 6.5e12 * 1e3); // 6.5 TB/s: a good placement
+    const bool debug = getenv("SGE_DEBUG_PLACEMENT") != nullptr;
+    float bestMs = 0;
+    if ((rc = probe(cur, bestMs)) != SGE_OK) return rc;
+    if (debug) fprintf(stderr, "[sge] output placement: first allocation %.3f ms (good <= %.3f)\n", bestMs, goodMs);
+    const int order[3] = {2, 0, 1}; // tangents, positions, normals
+    for (int oi = 0; oi < 3 && bestMs > goodMs; ++oi) {
+        const int s = order[oi];
+        size_t freeB = 0, totalB = 0;
+        int attempts = c->placementProbes - 1;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) attempts = (int)std::min<size_t>((size_t)attempts, freeB / 2 / need[s]);
+        std::vector<void*> held; // candidates of stream s, all alive until the stream is decided
+        void* best = cur[s];
+        for (int a = 0; a < attempts && bestMs > goodMs; ++a) {
+            void* cand = nullptr;
+            if (hipMalloc(&cand, need[s]) != hipSuccess) { (void)hipGetLastError(); break; }
+            held.push_back(cand);
+            void* trial[3] = {cur[0], cur[1], cur[2]};
+            trial[s] = cand;
+            float ms = 0;
+            if ((rc = probe(trial, ms)) != SGE_OK) return rc;
+            c->placementTried += 1;
+            if (debug) fprintf(stderr, "[sge]   stream %d candidate %p: %.3f ms\n", s, cand, ms);
+            if (ms < bestMs) { bestMs = ms; best = cand; }
+        }
+        if (best != cur[s]) { (void)hipFree(cur[s]); cur[s] = best; }
+        for (void* q : held) if (q != best) (void)hipFree(q);
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    if (best < 0) { set_error("out of device memory for the skinned output streams"); return SGE_ERR_DEVICE; }
-    for (int a = 0; a < (int)cands.size(); ++a)
-        if (a != best) for (void* q : cands[a].p) (void)hipFree(q);
-    for (int k = 0; k < 3; ++k) { bufs[k]->p = cands[best].p[k]; bufs[k]->bytes = need[k]; }
-    c->placementMs = cands[best].ms;
-    c->placementTried = (int)cands.size();
-    if (getenv("SGE_DEBUG_PLACEMENT")) {
-        fprintf(stderr, "[sge] output placement: %d candidates, probe ms:", (int)cands.size());
-        for (auto& cd : cands) fprintf(stderr, " %.3f", cd.ms);
-        fprintf(stderr, " -> %.3f (good <= %.3f)\n", cands[best].ms, goodMs);
-    }
+    for (int k = 0; k < 3; ++k) { bufs[k]->p = cur[k]; bufs[k]->bytes = need[k]; }
+    c->placementMs = bestMs;
+    if (debug) fprintf(stderr, "[sge] output placement: %d timed, kept %.3f ms\n", c->placementTried, bestMs);
     return SGE_OK;
 }
 
@@ -391,6 +400,7 @@ sge_context* sge_context_create(int device_index) {
     c->device = device_index;
     if (getenv("SGE_HEAVY_THRESHOLD")) c->heavyThreshold = atoi(getenv("SGE_HEAVY_THRESHOLD")); // experiments
     if (getenv("SGE_HEAVY_CAP")) c->heavyCap = std::max(1, atoi(getenv("SGE_HEAVY_CAP")));
+    if (getenv("SGE_PLACEMENT_PROBES")) c->placementProbes = std::max(1, atoi(getenv("SGE_PLACEMENT_PROBES")));
     if (getenv("SGE_OVERLAP_SKIN_WORKGROUPS")) c->overlapSkinWorkgroups = atoi(getenv("SGE_OVERLAP_SKIN_WORKGROUPS"));
     // the latency-bound collision / pose launches go first when they compete with a streaming skin launch (overlap option)
     int prLeast = 0, prGreatest = 0;
