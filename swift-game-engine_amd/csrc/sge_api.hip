@@ -218,8 +218,18 @@ int allocCrowdOutputs(sge_context* c) {
         int attempts = c->placementProbes - 1;
         if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) attempts = (int)std::min<size_t>((size_t)attempts, freeB / 2 / need[s]);
         std::vector<void*> held; // candidates of stream s, all alive until the stream is decided
+        // fast and slow regions are tens of GiB wide (the candidate sets of 5.6 GB each that this loop used to compare met a fast
+        // one every 6-8 sets): untouched spacers between the candidates make the search stride ~12 GiB whatever the stream's size
+        std::vector<void*> spacers;
+        const size_t stride12 = (size_t)12 << 30;
+        size_t spacer = need[s] < stride12 ? stride12 - need[s] : 0;
+        if (attempts > 0) spacer = std::min(spacer, freeB / 4 / (size_t)attempts);
         void* best = cur[s];
         for (int a = 0; a < attempts && bestMs > goodMs; ++a) {
+            if (spacer >= ((size_t)64 << 20)) {
+                void* sp = nullptr;
+                if (hipMalloc(&sp, spacer) == hipSuccess) spacers.push_back(sp); else (void)hipGetLastError();
+            }
             void* cand = nullptr;
             if (hipMalloc(&cand, need[s]) != hipSuccess) { (void)hipGetLastError(); break; }
             held.push_back(cand);
@@ -233,6 +243,7 @@ int allocCrowdOutputs(sge_context* c) {
         }
         if (best != cur[s]) { (void)hipFree(cur[s]); cur[s] = best; }
         for (void* q : held) if (q != best) (void)hipFree(q);
+        for (void* q : spacers) (void)hipFree(q);
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
