@@ -58,6 +58,9 @@ struct VertexIn { float3 p, n; float4 t; ushort4 idx; float4 w; };
 template <int SRC_STRIDE>
 __device__ __forceinline__ VertexIn loadVertex(const SkinLaunch& L, int gid) {
     VertexIn v;
+#ifdef SGE_SKIN_EXPERIMENT_SMALL_SOURCE // diagnostic build: every load hits the same 256 source vertices (L1 resident)
+    gid &= 255;
+#endif
     const float* sp = reinterpret_cast<const float*>(L.srcPos) + (unsigned)gid * SRC_STRIDE;
     const float* sn = reinterpret_cast<const float*>(L.srcNrm) + (unsigned)gid * SRC_STRIDE;
     v.p = make_float3(sp[0], sp[1], sp[2]);
