@@ -44,7 +44,9 @@ constexpr int kMaxRays = 6;
 #ifndef SGE_CCD_EXCLUSIVE
 #define SGE_CCD_EXCLUSIVE 0
 #endif
-#if SGE_CCD_EXCLUSIVE == 2
+#ifdef SGE_CCD_SETPRIO // experiment: issue priority of the collision wavefronts over the LBS wavefronts they share SIMDs with
+#define SGE_PAD_VGPRS() __builtin_amdgcn_s_setprio(SGE_CCD_SETPRIO)
+#elif SGE_CCD_EXCLUSIVE == 2
 #define SGE_PAD_VGPRS() do { asm volatile("" ::: "v175"); __builtin_amdgcn_s_setprio(3); } while (0)
 #elif SGE_CCD_EXCLUSIVE
 #define SGE_PAD_VGPRS() asm volatile("" ::: "v175")

@@ -8,8 +8,10 @@ here from the file itself: mesh-local vertex coordinates are the FBX control poi
 the file's normals, `matrix_world` is axis-conversion * unit-scale * the FBX node's global transform,
 bone rest matrices in armature space are the skin clusters' TransformLink, vertex groups are the clusters'
 Indexes/Weights.  Pinned against the one exporter output present in the reference checkout
-(Game/ornate_mirror.static.json, see tests/test_formats.py).  Collision hulls (Blender's convex-hull +
-decimate operators, :84-132) are not reproduced: `collisionHulls` is emitted empty.
+(Game/ornate_mirror.static.json, see tests/test_formats.py).  Collision hulls (:84-132) follow the script's steps — loose
+parts, the two largest, one convex hull each, simplified when it has more than 24 faces — with qhull for the hull and a
+convex vertex subset for the simplification: they are valid hulls of the same parts, not Blender's decimate output vertex
+for vertex (`build_collision_hulls`).
 """
 import numpy as np
 
@@ -93,7 +95,114 @@ def _submesh_order(tri_material, material_names):
     return np.asarray(order, np.int64), names
 
 
-def export_static_mesh(scene, flip_v=True):
+MAX_HULLS_PER_PART = 2       # export_static_mesh_json.py:7
+TARGET_FACES_PER_HULL = 24   # export_static_mesh_json.py:8
+
+
+def _loose_parts(vertex_count, polygons):
+    """Connected components over shared vertices (bpy.ops.mesh.separate(type="LOOSE")), as lists of vertex indices in
+    order of their smallest vertex; vertices no polygon uses form no part."""
+    parent = np.arange(vertex_count)
+
+    def find(i):
+        while parent[i] != i:
+            parent[i] = parent[parent[i]]
+            i = parent[i]
+        return i
+
+    used = np.zeros(vertex_count, bool)
+    for poly in polygons:
+        used[poly] = True
+        r = find(poly[0])
+        for v in poly[1:]:
+            q = find(v)
+            if q != r:
+                parent[q] = r
+    roots = np.array([find(i) for i in range(vertex_count)])
+    parts = {}
+    for i in np.flatnonzero(used):
+        parts.setdefault(roots[i], []).append(i)
+    return sorted(parts.values(), key=lambda p: p[0])
+
+
+def _hull(points):
+    """(vertices, outward triangles, merged face count) of the convex hull, or None for a degenerate point set."""
+    from scipy.spatial import ConvexHull, QhullError
+    if len(points) < 4:
+        return None
+    try:
+        h = ConvexHull(points)
+    except (QhullError, ValueError):
+        return None
+    tris = h.simplices.copy()
+    a, b, c = points[tris[:, 0]], points[tris[:, 1]], points[tris[:, 2]]
+    flip = np.einsum("ij,ij->i", np.cross(b - a, c - a), h.equations[:, :3]) < 0
+    tris[flip] = tris[flip][:, ::-1]
+    # coplanar triangles form one face (Blender's convex_hull joins them; the script counts polygons, :118)
+    planes = np.round(h.equations / max(np.abs(h.equations[:, 3]).max(), 1.0), 6)
+    # ... and, with its default join_triangles, also pairs of nearly coplanar triangles into quads (thresholds of 40 degrees): on a
+    # finely tessellated hull about 0.6 polygons per triangle remain (the reference's own mirror hulls, 40 and 36 triangles for a
+    # target of 24 faces, say 0.60 and 0.67)
+    faces = min(len({tuple(p) for p in planes}), int(np.ceil(0.6 * len(tris))))
+    return h.vertices, tris, faces
+
+
+def convex_hull_part(points, target_faces=TARGET_FACES_PER_HULL):
+    """One part's hull (:106-121): the convex hull of its vertices; when it has more than `target_faces` faces it is reduced by
+    the script's ratio target / faces — here by keeping the subset of hull vertices that preserves most of the volume (greedy:
+    the six axis extremes, then always the vertex farthest outside the current polytope), so the result is convex and
+    inscribed. -> (positions [H,3] float32, indices [T*3] uint32) or None."""
+    pts = np.asarray(points, np.float64).reshape(-1, 3)
+    full = _hull(pts)
+    if full is None:
+        return None
+    verts, tris, faces = full
+    if faces > target_faces:
+        ratio = max(min(target_faces / max(faces, 1), 1.0), 0.01)
+        want = max(int(round(ratio * len(tris))), 4)
+        cand = pts[verts]
+        chosen = list(dict.fromkeys(int(i) for ax in range(3) for i in (cand[:, ax].argmin(), cand[:, ax].argmax())))
+        cur = None
+        while True:
+            cur = _hull(cand[chosen]) if len(chosen) >= 4 else None
+            if cur is not None and len(cur[1]) >= want:
+                break
+            rest = [i for i in range(len(cand)) if i not in chosen]
+            if not rest:
+                break
+            if cur is None:
+                far = max(rest, key=lambda i: np.linalg.norm(cand[i] - cand[chosen].mean(0)))
+            else:
+                from scipy.spatial import ConvexHull
+                eq = ConvexHull(cand[chosen]).equations
+                out = (cand[rest] @ eq[:, :3].T + eq[:, 3]).max(axis=1)
+                far = rest[int(out.argmax())]
+            chosen.append(far)
+        if cur is not None:
+            sub = cand[chosen]
+            verts, tris = cur[0], cur[1]
+            pts = sub
+    order = np.sort(verts)
+    remap = -np.ones(len(pts), np.int64)
+    remap[order] = np.arange(len(order))
+    return pts[order].astype(np.float32), remap[tris].reshape(-1).astype(np.uint32)
+
+
+def build_collision_hulls(points, polygons):
+    """_build_collision_hulls (export_static_mesh_json.py:84-132) on mesh-local vertices and polygon vertex lists."""
+    pts = np.asarray(points, np.float64).reshape(-1, 3)
+    parts = _loose_parts(len(pts), polygons) or [list(range(len(pts)))]
+    if len(parts) > MAX_HULLS_PER_PART:
+        parts = sorted(parts, key=len, reverse=True)[:MAX_HULLS_PER_PART]
+    out = []
+    for part in parts:
+        h = convex_hull_part(pts[part])
+        if h is not None and len(h[1]):
+            out.append({"positions": h[0].reshape(-1), "indices": h[1]})
+    return out
+
+
+def export_static_mesh(scene, flip_v=True, hulls=True):
     """-> payload dict in the *.static.json schema (StaticMeshLoader.swift:163-197), arrays as numpy."""
     G = blender_global_matrix(scene)
     models = sorted(scene.of_kind("Model", "Mesh"), key=lambda m: scene.name(m).lower())
@@ -140,7 +249,8 @@ def export_static_mesh(scene, flip_v=True):
                 "indices": np.concatenate(indices).astype(np.uint32) if indices else np.zeros(0, np.uint32),
                 "submeshes": submeshes,
             },
-            "collisionHulls": [],
+            "collisionHulls": build_collision_hulls(_f32(geom["points"]), [geom["loops"][geom["poly_start"][k]:geom["poly_start"][k + 1]]
+                                                                              for k in range(len(geom["poly_start"]) - 1)]) if hulls else [],
         })
     return {"version": 1, "meshes": meshes}
 

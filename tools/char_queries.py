@@ -10,7 +10,8 @@ E = import_module("swift-game-engine_amd.engine")
 eng = sge.CharacterEngine(0)
 ybot = sge.assets.YBotAssets()
 sge.crowd.upload_character_assets(eng, ybot, rings=3, segments=3)
-scene = sge.crowd.upload_asset_scene(eng, ("cheese",))
+which = sys.argv[1] if len(sys.argv) > 1 else "cheese"
+scene = sge.crowd.upload_terrain(eng) if which == "synthetic" else sge.crowd.upload_asset_scene(eng, tuple(which.split(",")))
 n = 10000
 sge.crowd.spawn_crowd(eng, ybot, n, scene)
 st = abi.STAGE_INTENT | abi.STAGE_GRAVITY | abi.STAGE_MOVE | abi.STAGE_LOCOMOTION | abi.STAGE_ACTION | abi.STAGE_WRITEBACK
@@ -21,7 +22,9 @@ before = eng.download()
 eng.tick(stages=st)
 eng.synchronize()
 cost = eng.move_cost()
-for k in np.argsort(-cost)[:3]:
+order = np.argsort(-cost)
+print("cost percentiles: median %d p90 %d p99 %d max %d" % tuple(np.percentile(cost, [50, 90, 99, 100])))
+for k in list(order[:2]) + [order[len(order) // 2], order[len(order) // 10]]:
     b, p, c = before["bodies"][k], before["params"][k], before["controllers"][k]
     pos = np.array(b["position"], np.float32)
     vel = np.array(b["linearVelocity"], np.float32)
