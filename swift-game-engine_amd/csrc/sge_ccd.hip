@@ -1707,13 +1707,6 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? (S
         if (PART == 1 && doCast) waveCastRays<HEAVY>(col, P.radius, P.halfHeight, blocking, !blocking, P.minGroundDot, P.collisionMask, st,
                                                      HEAVY && phase == MP_GROUND_CENTER ? 1 : -1);
         // ---------------- 3. consume ----------------
-#ifdef SGE_DEBUG_RAYS
-        if (PART == 1 && lane == 0 && (e == 42 || e == 84) && phase == MP_GROUND_CENTER) {
-            printf("O e %d sampleK %d pos %.9g %.9g %.9g :", e, ms.sampleK, ms.position.x, ms.position.y, ms.position.z);
-            for (int r = 0; r < 6; ++r) printf(" [%d toi %.9g tri %d]", rayHit(r) ? 1 : 0, sh.rayRec[r].toi, sh.rayRec[r].triIndex);
-            printf("\n");
-        }
-#endif
         if (PART == 0) consumeDepen(0, nOverlap);
         else if (phase == MP_SLIDE) {
             if (AGENTS && useAgents) { // AgentSweepSolver.bestHit :1053-1091 (independent of the static hit)
@@ -1761,9 +1754,6 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? (S
         // this step's sweep cost decides which kernel takes the character next step
         if (PART == 1 && K.cost && lane == 0) K.cost[e] = HEAVY ? (int)hv.evalSum : (int)v;
         // did this step need the four offset ground casts? (next step's centre pass then carries them along)
-#ifdef SGE_DEBUG_RAYS
-        if (PART == 1 && lane == 0 && e == 42) printf("OEND e %d hintWas %d sampled %d haveCenter %d ctoi %.9g ny %.9g wasNear %d near %d pos %.9g\n", e, (int)K.hint[e], ms.sampled, ms.haveCenter, ms.centerHit.toi, ms.centerHit.triNormal.y, ms.wasGroundedNear, ms.nearGround, ms.position.x);
-#endif
         if (PART == 1 && K.hint && lane == 0) K.hint[e] = (uint8_t)(ms.sampled != 0);
     }
     if (K.stats) {
@@ -2291,17 +2281,6 @@ __global__ __launch_bounds__(kWave, SGE_CCD_EXCLUSIVE ? 2 : SGE_GROUP_WAVES) voi
             }
             groupSweep(col, itemCount, st);
         }
-#ifdef SGE_DEBUG_RAYS
-        for (int g = 0; g < kGroup; ++g) {
-            const int phase = (int)((phasePack >> (4 * g)) & 0xF);
-            const int e = sGroupE[g];
-            if (lane == 0 && (e == 42) && (phase == MP_GROUND_CENTER || phase == MP_GROUND_SAMPLE)) {
-                printf("G e %d phase %d sampleK %d pos %.9g %.9g %.9g pack %x:", e, phase, msA[g].sampleK, msA[g].position.x, msA[g].position.y, msA[g].position.z, phasePack);
-                for (int r = g * kMaxRays; r < g * kMaxRays + 6; ++r) printf(" [%d toi %.9g tri %d ny %.6g from %.6g %.6g]", rayHit(r) ? 1 : 0, sh.rayRec[r].toi, sh.rayRec[r].triIndex, sh.rayRec[r].triNormal.y, sh.rayFrom[r].x, sh.rayFrom[r].z);
-                printf("\n");
-            }
-        }
-#endif
         // ---------------- 3. every character consumes its rays ----------------
         for (int g = 0; g < kGroup; ++g) {
             const int phase = (int)((phasePack >> (4 * g)) & 0xF);
@@ -2356,9 +2335,6 @@ __global__ __launch_bounds__(kWave, SGE_CCD_EXCLUSIVE ? 2 : SGE_GROUP_WAVES) voi
         if (lane < 24) gb[lane] = reinterpret_cast<const uint32_t*>(&sBodyA[g])[lane];
         if (lane < 32) gc[lane] = reinterpret_cast<const uint32_t*>(&sCtrlA[g])[lane];
         if (lane == 0) {
-#ifdef SGE_DEBUG_RAYS
-            if (e == 42) printf("GEND e %d hintWas %d sampled %d haveCenter %d ctoi %.9g ny %.9g wasNear %d near %d pos %.9g\n", e, (int)K.hint[e], ms.sampled, ms.haveCenter, ms.centerHit.toi, ms.centerHit.triNormal.y, ms.wasGroundedNear, ms.nearGround, ms.position.x);
-#endif
             if (K.cost) K.cost[e] = sGroupCost[g];
             if (K.hint) K.hint[e] = (uint8_t)(ms.sampled != 0);
         }
