@@ -50,3 +50,22 @@ def test_allgather_host_sample_on_gpu(tmp_path, sge):
     out = subprocess.run([build_allgather(tmp_path)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "allgather smoke ok" in out.stdout
+
+
+def test_swift_binding_sources_refer_only_to_declared_c_names():
+    """No Swift toolchain here: what can be checked of swift-game-engine_amd/host/swift/*.swift is that every C function, struct and
+    constant they name exists in include/sge_amd.h and that the files are balanced."""
+    import glob
+    import re
+    hdr = open(os.path.join(ROOT, "include", "sge_amd.h")).read()
+    declared = set(re.findall(r"\b(sge_[a-z_0-9]+)\b", hdr)) | set(re.findall(r"\b(SGE_[A-Z_0-9]+)\b", hdr))
+    files = sorted(glob.glob(os.path.join(ROOT, "swift-game-engine_amd", "host", "swift", "*.swift")))
+    assert len(files) >= 5
+    for f in files:
+        text = re.sub(r"//.*", "", open(f).read())
+        text = re.sub(r'"(\\.|[^"\\])*"', '""', text)
+        for a, b in ("{}", "()", "[]"):
+            assert text.count(a) == text.count(b), (os.path.basename(f), a)
+        used = set(re.findall(r"\b(sge_[a-z_0-9]+)\b", text)) | set(re.findall(r"\b(SGE_[A-Z_0-9]+)\b", text))
+        assert not (used - declared), (os.path.basename(f), sorted(used - declared))
+
