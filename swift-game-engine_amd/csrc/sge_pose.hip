@@ -105,6 +105,12 @@ __device__ __forceinline__ BoneEval evalBone(const DevSkeleton& sk, const DevPro
     return r;
 }
 
+// Run-time index into a four-entry array that lives in registers: written as selects, because a dynamic subscript makes the
+// compiler spill the whole enclosing struct (the locomotion state, 100 B per lane) to scratch and fetch every access from there.
+template <class T> __device__ __forceinline__ T at4(const T (&a)[4], int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3])); }
+template <class T> __device__ __forceinline__ void set4(T (&a)[4], int i, T v) {
+    a[0] = i == 0 ? v : a[0]; a[1] = i == 1 ? v : a[1]; a[2] = i == 2 ? v : a[2]; a[3] = (i != 0 && i != 1 && i != 2) ? v : a[3];
+}
 __device__ __forceinline__ float cycleOf(const DevProfiles& pf, int p) { return smax(pf.cycleRaw[p], 0.001f); }
 
 // Systems.swift:297-324
@@ -166,17 +172,17 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
         }
         if (nextState != L.state) {
             int fromState = L.state;
-            float fromCycle = cycleOf(pf, L.profile[fromState]);
-            float fromPhase = smax(0.0f, smin(L.time[fromState] / fromCycle, 1.0f));
-            float toCycle = cycleOf(pf, L.profile[nextState]);
-            L.time[nextState] = fromPhase * toCycle;
+            float fromCycle = cycleOf(pf, at4(L.profile, fromState));
+            float fromPhase = smax(0.0f, smin(at4(L.time, fromState) / fromCycle, 1.0f));
+            float toCycle = cycleOf(pf, at4(L.profile, nextState));
+            set4(L.time, nextState, fromPhase * toCycle);
             L.fromState = L.state;
             L.state = nextState;
             L.flags |= SGE_LOCO_IS_BLENDING;
             L.blendT = 0;
             if (nextState == SGE_LOCO_IDLE) L.idleInertia = 1.0f;
         }
-        L.motionTime = L.time[L.state];
+        L.motionTime = at4(L.time, L.state);
     }
 
     // ---- ActionAnimationSystem (Systems.swift:482-516) ----
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
             float phase4[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) phase4[s] = smax(0.0f, smin(L.time[s] / cyc[s], 1.0f));
-            L.posePhase = phase4[L.state & 3];
+            L.posePhase = at4(phase4, L.state & 3);
 
             const int fromState = (isBlending ? L.fromState : L.state) & 3;
             const int toState = L.state & 3;
@@ -265,11 +271,11 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
             }
             runLeanWeight = runWeight;
 
-            const int fromProf = L.profile[fromState], toProf = L.profile[toState];
+            const int fromProf = at4(L.profile, fromState), toProf = at4(L.profile, toState);
             Harmonics hTo, hFrom;
-            harmonics(phase4[toState], pf.order[toProf], hTo);
+            harmonics(at4(phase4, toState), pf.order[toProf], hTo);
             const bool sameEval = fromState == toState;
-            if (!sameEval) harmonics(phase4[fromState], pf.order[fromProf], hFrom);
+            if (!sameEval) harmonics(at4(phase4, fromState), pf.order[fromProf], hFrom);
             for (int i = lane; i < B; i += kWave) {
                 BoneEval to = evalBone(sk, pf, toProf, i, hTo, inPlace, rootFix);
                 if (sameEval && !isBlending) {
