@@ -116,7 +116,7 @@ def main():
     stages = abi.STAGE_ALL if mode == "ccd" else (abi.STAGE_LOCOMOTION | abi.STAGE_ACTION | abi.STAGE_POSE | abi.STAGE_WRITEBACK | abi.STAGE_SKIN)
     if args.refit:
         eng.blas_build(eng.mesh["indices"])
-        eng.set_option(abi.OPT_FUSE_BLAS_REFIT, 1 if args.fuse else 0)
+        eng.set_option(abi.OPT_FUSE_BLAS_REFIT, 2 if args.fuse else 0)  # explicit either way: the refit kernel keeps its own line
         stages |= abi.STAGE_BLAS_REFIT
     exchange = None
     if args.workload == "agents":

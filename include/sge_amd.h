@@ -238,8 +238,10 @@ enum {
     SGE_OPT_PLACEMENT_PROBES = 6, /* how many candidate placements of the skinned output streams are timed when they are
                                    * (re)allocated; the fastest is kept (default 8, stops early at 6.5 TB/s; <= 1: take the
                                    * first). Takes effect at the next sge_characters_resize / layout change. */
-    SGE_OPT_FUSE_BLAS_REFIT = 7,  /* 1: a tick with both SGE_STAGE_SKIN and SGE_STAGE_BLAS_REFIT folds the refit into the LBS
-                                   * kernel (the boxes are reduced from the positions while they are still in registers) */
+    SGE_OPT_FUSE_BLAS_REFIT = 7,  /* 1 (default): a tick with both SGE_STAGE_SKIN and SGE_STAGE_BLAS_REFIT folds the refit into the LBS
+                                   * kernel (the boxes are reduced from the positions while they are still on chip), except
+                                   * under SGE_OPT_OVERLAP_SKIN, where the fused kernel would keep the next step's collision
+                                   * kernels off the chip; 2: always; 0: two launches, the refit reads the positions back */
     SGE_OPT_OVERLAP_SKIN = 4      /* 1: run the skin stage on a second stream so that it overlaps the next
                                      step's move stage (ignored on a caller-provided stream) */
 };
@@ -657,8 +659,8 @@ int sge_blas_set_uvs(sge_context* ctx, const float* uvs, int32_t vertex_count);
 
 /* encoder.refit(..., options: .vertexData) (RTAccelerationBuilder.swift:113-145) for characters [first, first+count)
  * over the context's skinned positions. Asynchronous; also runs as SGE_STAGE_BLAS_REFIT of sge_tick, after the skin
- * stage. With SGE_OPT_FUSE_BLAS_REFIT the skin stage of the same tick produces the boxes itself and the skinned
- * positions are not read back. */
+ * stage. With SGE_OPT_FUSE_BLAS_REFIT (the default) the skin stage of the same tick produces the boxes itself and the
+ * skinned positions are not read back. */
 int sge_blas_refit(sge_context* ctx, int32_t first, int32_t count);
 /* The same over caller-owned device buffers: d_positions in `layout`, character k at vertex first_vertex + k * vertexCount;
  * d_bounds receives [count][entryCount + 1][6]. */

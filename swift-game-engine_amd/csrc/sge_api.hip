@@ -60,6 +60,7 @@ struct sge_context {
     int placementProbes = 8;   // candidate placements of the skinned output streams compared at allocation time
     float placementMs = 0; int placementTried = 0;
     int overlapSkinWorkgroups = 3; // LBS workgroups per CU while it shares the chip with the next step's collision kernels
+    int overlapFusedWorkgroups = 0; // cap for the persistent workgroups of the fused LBS + refit kernel (0: as many as the LDS holds; measured 1 / 2 / 3: 1.53 / 1.47 / 1.44 ms per step)
     int heavyThreshold = 4000; // distance evaluations in a character's last step above which it takes the multi-wave kernel; < 0: off
     int heavyCap = 2048;       // most characters the multi-wave launch takes per step (= its grid: workgroups beyond the list exit at once)
     bool skinPending[2] = {false, false}, overlapSkin = false, customStream = false;
@@ -96,10 +97,13 @@ struct sge_context {
     std::vector<float> hostMeshPos; // source positions as uploaded: the topology is built from them
     HostBlas hostBlas;
     DevBlas blas{};
-    bool fuseBlas = false;
+    // a tick with both the skin and the refit stage: 1 = one kernel unless the skin stage overlaps the next step (its persistent
+    // workgroups hold 448 of every SIMD's 512 VGPRs, no collision kernel (128-176) fits beside them and the two sides run one
+    // after the other: 1.49 against 1.46 ms per step; serial order 1.85 -> 1.61 ms), 2 = always, 0 = never
+    int fuseBlas = 1;
     int blasBoundsChars = 0;
     DevBuf dBlasEntryLink, dBlasWideFirst, dBlasWideParent, dBlasWideLevel, dBlasSlotIdx, dBlasSlotTri,
-           dBlasIndices, dBlasBounds, dBlasInstances, dBlasRays, dBlasHits, dBlasTileStart, dBlasRoundLen, dBlasRoundCluster, dBlasRoundIds, dBlasWorldBoxes, dBlasUVs;
+           dBlasIndices, dBlasBounds, dBlasInstances, dBlasRays, dBlasHits, dBlasTileStart, dBlasRoundLen, dBlasRoundCluster, dBlasRoundIds, dBlasWorldBoxes, dBlasUVs, dBlasQueue;
     bool blasHasUVs = false;
     // stats / profiling
     DevBuf dStats, dWaveProf, dOrderHist, dSepAgents, dSepCounts;
@@ -413,6 +417,7 @@ sge_context* sge_context_create(int device_index) {
     if (getenv("SGE_HEAVY_CAP")) c->heavyCap = std::max(1, atoi(getenv("SGE_HEAVY_CAP")));
     if (getenv("SGE_PLACEMENT_PROBES")) c->placementProbes = std::max(1, atoi(getenv("SGE_PLACEMENT_PROBES")));
     if (getenv("SGE_OVERLAP_SKIN_WORKGROUPS")) c->overlapSkinWorkgroups = atoi(getenv("SGE_OVERLAP_SKIN_WORKGROUPS"));
+    if (getenv("SGE_OVERLAP_FUSED_WORKGROUPS")) c->overlapFusedWorkgroups = atoi(getenv("SGE_OVERLAP_FUSED_WORKGROUPS"));
     // the latency-bound collision / pose launches go first when they compete with a streaming skin launch (overlap option)
     int prLeast = 0, prGreatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest);
@@ -457,7 +462,7 @@ void sge_context_destroy(sge_context* c) {
                       &c->dCellCursor, &c->dAgentMinMax, &c->dAgentGrid, &c->dAgentsAll, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats,
                       &c->dBlasEntryLink, &c->dBlasWideFirst, &c->dBlasWideParent, &c->dBlasWideLevel, &c->dBlasSlotIdx, &c->dBlasSlotTri,
                       &c->dBlasIndices, &c->dBlasBounds, &c->dBlasInstances, &c->dBlasRays, &c->dBlasHits, &c->dBlasTileStart,
-                      &c->dBlasRoundLen, &c->dBlasRoundCluster, &c->dBlasRoundIds, &c->dBlasWorldBoxes, &c->dBlasUVs};
+                      &c->dBlasRoundLen, &c->dBlasRoundCluster, &c->dBlasRoundIds, &c->dBlasWorldBoxes, &c->dBlasUVs, &c->dBlasQueue};
     for (DevBuf* b : bufs) b->release();
     if (c->evPoseDone) (void)hipEventDestroy(c->evPoseDone);
     for (hipEvent_t e : c->evSkinDone) if (e) (void)hipEventDestroy(e);
@@ -491,7 +496,7 @@ int sge_synchronize(sge_context* c) {
 }
 
 int sge_context_set_option(sge_context* c, int option, int value) {
-    if (c && option == SGE_OPT_FUSE_BLAS_REFIT) { c->fuseBlas = value != 0; return SGE_OK; }
+    if (c && option == SGE_OPT_FUSE_BLAS_REFIT) { c->fuseBlas = value < 0 ? 0 : (value > 2 ? 2 : value); return SGE_OK; }
     if (!c) return SGE_ERR_INVALID;
     switch (option) {
     case SGE_OPT_STORE_POSE_DEBUG: c->storePoseDebug = value != 0; break;
@@ -1196,10 +1201,10 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         const bool refit = (st & SGE_STAGE_BLAS_REFIT) != 0;
         if (refit && c->blas.entryCount == 0) { set_error("SGE_STAGE_BLAS_REFIT needs sge_blas_build"); return SGE_ERR_STATE; }
         float* boxes = refit ? c->dBlasBounds.as<float>() + (size_t)first * (c->blas.entryCount + 1) * 6 : nullptr;
-        if (refit && c->fuseBlas) {
+        if (refit && (c->fuseBlas == 2 || (c->fuseBlas == 1 && !overlap))) {
             // one launch: the LBS kernel keeps every position it computes in an LDS tile and reduces the boxes from there
             Bracket br(c, &c->evSkin, ss);
-            int rc = launch_skin_refit(L, c->blas, boxes, ss);
+            int rc = launch_skin_refit(L, c->blas, boxes, c->dBlasQueue.as<int>(), ss, overlap ? c->overlapFusedWorkgroups : 0);
             if (rc != SGE_OK) return rc;
         } else {
             {
@@ -1208,7 +1213,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
             }
             if (refit) { // RTAccelerationBuilder.build is enqueued right behind the skinning encoder (RayTracingScene.swift:35-43)
                 Bracket br(c, &c->evBlas, ss);
-                int rc = launch_blas_refit(c->blas, c->dOutPos.p, c->skinLayout, (long long)first * c->mesh.vertexCount, count, boxes, ss);
+                int rc = launch_blas_refit(c->blas, c->dOutPos.p, c->skinLayout, (long long)first * c->mesh.vertexCount, count, boxes, c->dBlasQueue.as<int>(), ss);
                 if (rc != SGE_OK) return rc;
             }
         }
@@ -1233,6 +1238,8 @@ int sge_blas_build(sge_context* c, const uint32_t* indices, int32_t index_count)
     int rc;
     // a closest-hit query pops the newest wide node first: at most 63 siblings stay pending per level
     if (hb.levels * 63 + 1 > kBlasTraversalStackCap) { set_error("sge_blas_build: hierarchy too deep for the closest-hit traversal stack"); return SGE_ERR_CAPACITY; }
+    // ticket counters of the refit kernels: [0] launches of sge_tick (possibly on the skin stream), [16] the stand-alone entry points
+    if ((rc = c->dBlasQueue.alloc(256)) != SGE_OK) return rc;
     hipStream_t s = c->stream;
     if ((rc = upload(c->dBlasEntryLink, hb.entryLink.data(), hb.entryLink.size() * 4, s)) != SGE_OK) return rc;
     if ((rc = upload(c->dBlasWideFirst, hb.wideFirst.data(), hb.wideFirst.size() * 4, s)) != SGE_OK) return rc;
@@ -1285,7 +1292,7 @@ int sge_blas_refit(sge_context* c, int32_t first, int32_t count) {
     { int rcj = joinSkin(c); if (rcj != SGE_OK) return rcj; }
     Bracket br(c, &c->evBlas);
     int rc = launch_blas_refit(c->blas, c->dOutPos.p, c->outLayoutAllocated, (long long)first * c->mesh.vertexCount, count,
-                               c->dBlasBounds.as<float>() + (size_t)first * (c->blas.entryCount + 1) * 6, c->stream);
+                               c->dBlasBounds.as<float>() + (size_t)first * (c->blas.entryCount + 1) * 6, c->dBlasQueue.as<int>() + 16, c->stream);
     if (rc != SGE_OK) return rc;
     SGE_HIP(hipGetLastError());
     return SGE_OK;
@@ -1300,7 +1307,7 @@ int sge_blas_refit_buffers(sge_context* c, const void* d_positions, int32_t layo
     (void)hipSetDevice(c->device);
     { int rcj = joinSkin(c); if (rcj != SGE_OK) return rcj; }
     Bracket br(c, &c->evBlas);
-    int rc = launch_blas_refit(c->blas, d_positions, layout, (long long)first_vertex, count, reinterpret_cast<float*>(d_bounds), c->stream);
+    int rc = launch_blas_refit(c->blas, d_positions, layout, (long long)first_vertex, count, reinterpret_cast<float*>(d_bounds), c->dBlasQueue.as<int>() + 16, c->stream);
     if (rc != SGE_OK) return rc;
     SGE_HIP(hipGetLastError());
     return SGE_OK;

@@ -43,12 +43,15 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // table is written out coalesced and re-initialised.
 template <int STRIDE, int TILE>
 __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, const float* __restrict__ positions, long long firstVertex,
-                                                                     int chars, float* __restrict__ bounds) {
+                                                                     int chars, float* __restrict__ bounds, int* __restrict__ queue) {
     extern __shared__ float lds[];
     const int rows = B.entryCount + 1, tid = threadIdx.x;
     float* tab = lds;
     float* X = lds + rows * 6; // Y = X + TILE, Z = X + 2 * TILE
     int* trs = reinterpret_cast<int*>(X + 3 * TILE);
+    // the next character of this workgroup, behind the round ranges (in the dynamic region: a static __shared__ variable would
+    // move the region's base off its 16-byte alignment)
+    int& sNextChar = trs[B.tileCount + 1];
     blasTableInit(tab, rows, tid, kBlasRefitBlock);
     for (int i = tid; i <= B.tileCount; i += kBlasRefitBlock) trs[i] = B.tileRoundStart[i];
     __syncthreads();
@@ -75,16 +78,22 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, 
     if (c >= chars) return;
     // characters start at different tiles, so that the ones in flight at one time do not all read the same offset of their
     // (equally spaced) vertex ranges
-    int tile = c % n, done = 0;
+    // Characters after the first are handed out through a ticket counter (zeroed by the launcher), gridDim.x + ticket: with a
+    // fixed stride the workgroups that get one character more than the rest (10,000 over 768: 14 against 13) are the tail of
+    // the launch, and so is every workgroup that found its place on a CU late. The ticket is drawn at the start of a
+    // character and is needed in its last step, where the next character's first tile is requested.
+    int tile = c % n, done = 0, ticket = 0;
     fetchPos(c, tile);
     while (true) {
         const int nv = min(B.tileVerts, B.vertexCount - tile * B.tileVerts);
+        if (done == 0 && tid == 0) ticket = atomicAdd(queue, 1);
         __syncthreads(); // the previous step's rounds have read X/Y/Z; a finished character's table has been re-initialised
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
             const int v = tid + k * kBlasRefitBlock;
             if (v < nv) { X[v] = px[k]; X[v + TILE] = py[k]; X[v + 2 * TILE] = pz[k]; }
         }
+        if (done == 0 && tid == 0) sNextChar = (int)gridDim.x + ticket; // read below in this character's last step, behind the barrier
         __syncthreads();
         const int rEnd = trs[tile + 1];
         int r = trs[tile] + wave;
@@ -92,7 +101,7 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, 
         if (r < rEnd) blasFetchRound(B, r, lastRound, lane, R); // wave-uniform; a wavefront without a round in this tile loads nothing
         // the next step: this character's next tile, or the next character's first
         const bool last = done + 1 == n;
-        const int cNext = last ? c + (int)gridDim.x : c;
+        const int cNext = last ? __builtin_amdgcn_readfirstlane(sNextChar) : c;
         const int tileNext = last ? cNext % n : (tile + 1 == n ? 0 : tile + 1);
         fetchPos(min(cNext, chars - 1), tileNext); // unconditional (a branch here would make the waits below conservative); after the last step: unused
         if (r < rEnd) blasWalk<TILE>(tab, rows, X, R); // wave-uniform
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, 
 }
 
 template <int TILE>
-static int launchRefitTile(const DevBlas& B, const float* p, int layout, long long firstVertex, int chars, float* bounds, int grid, size_t lds, hipStream_t s) {
+static int launchRefitTile(const DevBlas& B, const float* p, int layout, long long firstVertex, int chars, float* bounds, int* queue, int grid, size_t lds, hipStream_t s) {
     static bool attrSet[kMaxDevices] = {};
     const int devSlot = currentDeviceSlot();
     if (!attrSet[devSlot]) {
@@ -121,23 +130,24 @@ static int launchRefitTile(const DevBlas& B, const float* p, int layout, long lo
         SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blas_refit_kernel<4, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlasMaxLdsBytes));
         attrSet[devSlot] = true;
     }
-    if (layout == SGE_LAYOUT_PADDED16) hipLaunchKernelGGL((blas_refit_kernel<4, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, B, p, firstVertex, chars, bounds);
-    else hipLaunchKernelGGL((blas_refit_kernel<3, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, B, p, firstVertex, chars, bounds);
+    if (layout == SGE_LAYOUT_PADDED16) hipLaunchKernelGGL((blas_refit_kernel<4, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, B, p, firstVertex, chars, bounds, queue);
+    else hipLaunchKernelGGL((blas_refit_kernel<3, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, B, p, firstVertex, chars, bounds, queue);
     return SGE_OK;
 }
 
-int launch_blas_refit(const DevBlas& B, const void* positions, int layout, long long firstVertex, int chars, float* bounds, hipStream_t s) {
+int launch_blas_refit(const DevBlas& B, const void* positions, int layout, long long firstVertex, int chars, float* bounds, int* queue, hipStream_t s) {
     if (chars <= 0) return SGE_OK;
-    const size_t lds = blasRefitLdsBytes(B.entryCount, B.tileCount, B.tileCap);
+    SGE_HIP(hipMemsetAsync(queue, 0, sizeof(int), s));
+    const size_t lds = blasRefitLdsBytes(B.entryCount, B.tileCount, B.tileCap) + 16; // + the ticket slot
     const int cus = currentDeviceCUs();
     // persistent: as many workgroups as stay resident together (LDS allows floor(160 KB / lds) per CU)
     const int perCU = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / (lds + 256)));
     const int grid = std::min(chars, cus * perCU);
     const float* p = reinterpret_cast<const float*>(positions);
     switch (B.tileCap) {
-    case 3072: return launchRefitTile<3072>(B, p, layout, firstVertex, chars, bounds, grid, lds, s);
-    case 2048: return launchRefitTile<2048>(B, p, layout, firstVertex, chars, bounds, grid, lds, s);
-    default: return launchRefitTile<4096>(B, p, layout, firstVertex, chars, bounds, grid, lds, s);
+    case 3072: return launchRefitTile<3072>(B, p, layout, firstVertex, chars, bounds, queue, grid, lds, s);
+    case 2048: return launchRefitTile<2048>(B, p, layout, firstVertex, chars, bounds, queue, grid, lds, s);
+    default: return launchRefitTile<4096>(B, p, layout, firstVertex, chars, bounds, queue, grid, lds, s);
     }
 }
 

@@ -322,7 +322,7 @@ __device__ __forceinline__ void blendAndTransform(const float4* pal, const Verte
 }
 
 template <int SRC_STRIDE, int DST_STRIDE, int TILE>
-__global__ __launch_bounds__(kBlasRefitBlock) void skin_refit_kernel(SkinLaunch L, DevBlas B, float* __restrict__ bounds) {
+__global__ __launch_bounds__(kBlasRefitBlock) void skin_refit_kernel(SkinLaunch L, DevBlas B, float* __restrict__ bounds, int* __restrict__ queue) {
     extern __shared__ float lds[];
     const int rows = B.entryCount + 1, tid = threadIdx.x;
     float* tab = lds;
@@ -336,8 +336,14 @@ __global__ __launch_bounds__(kBlasRefitBlock) void skin_refit_kernel(SkinLaunch 
     constexpr int kWaves = kBlasRefitBlock / kBlasWave, kPerThread = TILE / kBlasRefitBlock;
     const int n = B.tileCount, lastRound = trs[n] - 1;
     float* palf = reinterpret_cast<float*>(pal);
+    // the ticket's slot lies behind the palette: a static __shared__ variable would shift the dynamic region to offset 4 and
+    // with it every 16-byte palette read off its alignment (measured: the kernel takes twice as long)
+    int& sNextChar = *reinterpret_cast<int*>(pal + L.paletteCount * 3);
 
-    for (int c = blockIdx.x; c < L.chars; c += gridDim.x) {
+    // Characters are handed out through a ticket counter (zeroed by the launcher): the first is blockIdx.x, every later one
+    // gridDim.x + ticket. Beside the collision kernels of the next step (SGE_OPT_OVERLAP_SKIN) some workgroups find their
+    // place on a CU late; with a fixed stride they would finish that much later than the rest.
+    for (int c = blockIdx.x; c < L.chars;) {
         // stage the palette: thread -> one float4 COLUMN (coalesced), scattered into rows (as skinRange does)
         const float4* gp = reinterpret_cast<const float4*>(L.palettes + (size_t)c * L.paletteCount * 16);
         for (int i = tid; i < L.paletteCount * 4; i += kBlasRefitBlock) {
@@ -388,14 +394,19 @@ __global__ __launch_bounds__(kBlasRefitBlock) void skin_refit_kernel(SkinLaunch 
                 blasWalk<TILE>(tab, rows, X, R);
             }
         }
+        int ticket = 0;
+        if (tid == 0) ticket = atomicAdd(queue, 1); // answered behind the reduction and the write-out below
         blasFinishCharacter(B, tab, rows, tid, kBlasRefitBlock, bounds + (size_t)c * rows * 6);
         // the next character's palette staging writes `pal` only after every wavefront has left the last walk (barriers inside
-        // blasFinishCharacter), and its first tile's barrier orders the table re-initialisation before any fold
+        // blasFinishCharacter), and the barrier below orders the table re-initialisation before any fold
+        if (tid == 0) sNextChar = (int)gridDim.x + ticket;
+        __syncthreads();
+        c = sNextChar; // next written after the barriers of the next character
     }
 }
 
 template <int TILE>
-static int launchSkinRefitTile(const SkinLaunch& L, const DevBlas& B, float* bounds, int grid, size_t lds, hipStream_t s) {
+static int launchSkinRefitTile(const SkinLaunch& L, const DevBlas& B, float* bounds, int* queue, int perCU, size_t lds, hipStream_t s) {
     static bool attrSet[kMaxDevices] = {};
     const int devSlot = currentDeviceSlot();
     if (!attrSet[devSlot]) {
@@ -403,22 +414,31 @@ static int launchSkinRefitTile(const SkinLaunch& L, const DevBlas& B, float* bou
         SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(skin_refit_kernel<3, 4, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attrSet[devSlot] = true;
     }
-    if (L.dstLayout == SGE_LAYOUT_PADDED16) hipLaunchKernelGGL((skin_refit_kernel<3, 4, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, L, B, bounds);
-    else hipLaunchKernelGGL((skin_refit_kernel<3, 3, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, L, B, bounds);
+    // persistent: exactly the workgroups that are resident together. Registers bind before the LDS does (112 VGPRs: four
+    // wavefronts per SIMD, two workgroups per CU); a workgroup beyond that would start when the others leave and do its first
+    // character, fixed by its index, as the tail of the launch.
+    int resident = 0;
+    if (L.dstLayout == SGE_LAYOUT_PADDED16) SGE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, skin_refit_kernel<3, 4, TILE>, kBlasRefitBlock, lds));
+    else SGE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, skin_refit_kernel<3, 3, TILE>, kBlasRefitBlock, lds));
+    const int grid = std::min(L.chars, currentDeviceCUs() * std::max(1, std::min(perCU, resident)));
+    if (L.dstLayout == SGE_LAYOUT_PADDED16) hipLaunchKernelGGL((skin_refit_kernel<3, 4, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, L, B, bounds, queue);
+    else hipLaunchKernelGGL((skin_refit_kernel<3, 3, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, L, B, bounds, queue);
     return SGE_OK;
 }
 
-// the crowd's skin stage and refit stage as one launch; the source mesh is the context's (packed)
-int launch_skin_refit(const SkinLaunch& L, const DevBlas& B, float* bounds, hipStream_t s) {
+// the crowd's skin stage and refit stage as one launch; the source mesh is the context's (packed).
+// maxWorkgroupsPerCU > 0 launches fewer persistent workgroups than the LDS would hold, which leaves the rest of it to the
+// collision kernels of the next step (SGE_OPT_OVERLAP_SKIN): these workgroups never leave, so nothing else frees a place.
+int launch_skin_refit(const SkinLaunch& L, const DevBlas& B, float* bounds, int* queue, hipStream_t s, int maxWorkgroupsPerCU) {
     if (L.chars <= 0 || L.vertexCount <= 0) return SGE_OK;
-    const size_t lds = blasRefitLdsBytes(B.entryCount, B.tileCount, B.tileCap) + 16 + (size_t)L.paletteCount * 48;
-    const int cus = currentDeviceCUs();
-    const int perCU = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / (lds + 256)));
-    const int grid = std::min(L.chars, cus * perCU);
+    SGE_HIP(hipMemsetAsync(queue, 0, sizeof(int), s));
+    const size_t lds = blasRefitLdsBytes(B.entryCount, B.tileCount, B.tileCap) + 16 + (size_t)L.paletteCount * 48 + 16; // + the ticket slot
+    int perCU = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / (lds + 256)));
+    if (maxWorkgroupsPerCU > 0) perCU = std::min(perCU, maxWorkgroupsPerCU);
     switch (B.tileCap) {
-    case 3072: return launchSkinRefitTile<3072>(L, B, bounds, grid, lds, s);
-    case 2048: return launchSkinRefitTile<2048>(L, B, bounds, grid, lds, s);
-    default: return launchSkinRefitTile<4096>(L, B, bounds, grid, lds, s);
+    case 3072: return launchSkinRefitTile<3072>(L, B, bounds, queue, perCU, lds, s);
+    case 2048: return launchSkinRefitTile<2048>(L, B, bounds, queue, perCU, lds, s);
+    default: return launchSkinRefitTile<4096>(L, B, bounds, queue, perCU, lds, s);
     }
 }
 

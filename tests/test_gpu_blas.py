@@ -39,6 +39,7 @@ def test_refit_boxes_are_exact(sge, real, layout):
         topo = _topology(sge, gpu)
         assert (info.entryCount, info.wideCount, info.clusterCount) == (topo["info"].entryCount, topo["info"].wideCount, topo["info"].clusterCount)
         V = gpu.vertex_count
+        gpu.set_option(sge.abi.OPT_FUSE_BLAS_REFIT, 0)  # this test is about blas_refit_kernel (the fused form: test_fused_skin_and_refit)
         for step in range(3):
             gpu.tick(stages=sge.abi.STAGE_ALL | sge.abi.STAGE_BLAS_REFIT)  # refit enqueued behind the skinning of the same step
             pos, _, _ = gpu.skinned()
@@ -80,6 +81,7 @@ def test_fused_skin_and_refit(sge, real, layout):
         topo = _topology(sge, gpu)
         V = gpu.vertex_count
         st = sge.abi.STAGE_ALL | sge.abi.STAGE_BLAS_REFIT
+        gpu.set_option(sge.abi.OPT_FUSE_BLAS_REFIT, 0)  # the two-kernel path is the reference here
         for _ in range(3):
             gpu.tick(stages=st)
         ref = [a.copy() for a in gpu.skinned()]
@@ -101,7 +103,6 @@ def test_fused_skin_and_refit(sge, real, layout):
         boxes = gpu.blas_bounds()
         for c in range(n):
             assert np.array_equal(boxes[c], expected_bounds(topo, gpu.mesh["indices"], pos[c * V:(c + 1) * V])), c
-        gpu.set_option(sge.abi.OPT_FUSE_BLAS_REFIT, 0)
     finally:
         gpu.close()
 
@@ -298,8 +299,7 @@ def test_odd_meshes(sge, case):
         topo = sge.CharacterEngine.blas_topology(pos, idx)
         if case.startswith("soup"):
             assert info.incidenceCount / 16 / 64 > 8, "this case is meant to have more than eight rounds in its tile"
-        if case == "soup-fused":
-            gpu.set_option(sge.abi.OPT_FUSE_BLAS_REFIT, 1)
+        gpu.set_option(sge.abi.OPT_FUSE_BLAS_REFIT, 1 if case == "soup-fused" else 0)
         gpu.tick(dt=0.0, stages=sge.abi.STAGE_POSE | sge.abi.STAGE_SKIN | sge.abi.STAGE_BLAS_REFIT)
         p = gpu.skinned()[0]
         V = len(pos)
@@ -356,20 +356,26 @@ def test_full_size_refit_properties(sge):
         sge.crowd.spawn_crowd(gpu, ybot, n, terrain, seed=3, mode="ccd", mixed=True)
         info = gpu.blas_build(gpu.mesh["indices"])
         topo = _topology(sge, gpu)
-        for _ in range(3):
-            gpu.tick(stages=sge.abi.STAGE_ALL | sge.abi.STAGE_BLAS_REFIT)
-        V = gpu.vertex_count
-        b = gpu.blas_bounds()
-        assert np.isfinite(b).all() and (b[:, :, :3] <= b[:, :, 3:]).all()
-        used = np.unique(gpu.mesh["indices"])
-        for c in (0, 1, 4999, 9999):
-            p = gpu.skinned(first_vertex=c * V, vertex_count=V, normals=False, tangents=False)[0]
-            assert np.array_equal(b[c, -1, :3], p[used].min(0)) and np.array_equal(b[c, -1, 3:], p[used].max(0))
-            assert np.array_equal(b[c], expected_bounds(topo, gpu.mesh["indices"], p))
-        link, first, parent = topo["entryLink"], topo["wideFirst"], topo["wideParentEntry"]
-        for w in range(info.wideCount):
-            dst = info.entryCount if parent[w] < 0 else parent[w]
-            rows = slice(first[w], first[w + 1])
-            assert np.array_equal(b[:, rows, :3].min(1), b[:, dst, :3]) and np.array_equal(b[:, rows, 3:].max(1), b[:, dst, 3:])
+        for fused in (0, 1):  # two launches (blas_refit_kernel), then the default: folded into the LBS kernel (skin_refit_kernel)
+            gpu.set_option(sge.abi.OPT_FUSE_BLAS_REFIT, fused)
+            for _ in range(3 if fused == 0 else 2):
+                gpu.tick(stages=sge.abi.STAGE_ALL | sge.abi.STAGE_BLAS_REFIT)
+            V = gpu.vertex_count
+            b = gpu.blas_bounds()
+            assert np.isfinite(b).all() and (b[:, :, :3] <= b[:, :, 3:]).all()
+            used = np.unique(gpu.mesh["indices"])
+            for c in (0, 1, 4999, 9999):
+                p = gpu.skinned(first_vertex=c * V, vertex_count=V, normals=False, tangents=False)[0]
+                assert np.array_equal(b[c, -1, :3], p[used].min(0)) and np.array_equal(b[c, -1, 3:], p[used].max(0))
+                assert np.array_equal(b[c], expected_bounds(topo, gpu.mesh["indices"], p))
+            # the fused kernel hands characters out through a ticket counter: a wider sample of root boxes against this step's positions
+            for c in np.random.default_rng(17 + fused).integers(0, n, 48):
+                p = gpu.skinned(first_vertex=int(c) * V, vertex_count=V, normals=False, tangents=False)[0]
+                assert np.array_equal(b[c, -1, :3], p[used].min(0)) and np.array_equal(b[c, -1, 3:], p[used].max(0)), c
+            link, first, parent = topo["entryLink"], topo["wideFirst"], topo["wideParentEntry"]
+            for w in range(info.wideCount):
+                dst = info.entryCount if parent[w] < 0 else parent[w]
+                rows = slice(first[w], first[w + 1])
+                assert np.array_equal(b[:, rows, :3].min(1), b[:, dst, :3]) and np.array_equal(b[:, rows, 3:].max(1), b[:, dst, 3:])
     finally:
         gpu.close()
