@@ -60,6 +60,7 @@ struct sge_context {
     int placementProbes = 8;   // candidate placements of the skinned output streams compared at allocation time
     float placementMs = 0; int placementTried = 0;
     int overlapSkinWorkgroups = 3; // LBS workgroups per CU while it shares the chip with the next step's collision kernels
+    bool skinPersistent = false; // experiment (SGE_SKIN_PERSISTENT): resident LBS workgroups + ticket counter in overlap mode
     int overlapFusedWorkgroups = 0; // cap for the persistent workgroups of the fused LBS + refit kernel (0: as many as the LDS holds; measured 1 / 2 / 3: 1.53 / 1.47 / 1.44 ms per step)
     int heavyThreshold = 4000; // distance evaluations in a character's last step above which it takes the multi-wave kernel; < 0: off
     int heavyCap = 2048;       // most characters the multi-wave launch takes per step (= its grid: workgroups beyond the list exit at once)
@@ -103,7 +104,7 @@ struct sge_context {
     int fuseBlas = 1;
     int blasBoundsChars = 0;
     DevBuf dBlasEntryLink, dBlasWideFirst, dBlasWideParent, dBlasWideLevel, dBlasSlotIdx, dBlasSlotTri,
-           dBlasIndices, dBlasBounds, dBlasInstances, dBlasRays, dBlasHits, dBlasTileStart, dBlasRoundLen, dBlasRoundCluster, dBlasRoundIds, dBlasWorldBoxes, dBlasUVs, dBlasQueue;
+           dBlasIndices, dBlasBounds, dBlasInstances, dBlasRays, dBlasHits, dBlasTileStart, dBlasRoundLen, dBlasRoundCluster, dBlasRoundIds, dBlasWorldBoxes, dBlasUVs, dBlasQueue, dSkinQueue;
     bool blasHasUVs = false;
     // stats / profiling
     DevBuf dStats, dWaveProf, dOrderHist, dSepAgents, dSepCounts;
@@ -417,6 +418,7 @@ sge_context* sge_context_create(int device_index) {
     if (getenv("SGE_HEAVY_CAP")) c->heavyCap = std::max(1, atoi(getenv("SGE_HEAVY_CAP")));
     if (getenv("SGE_PLACEMENT_PROBES")) c->placementProbes = std::max(1, atoi(getenv("SGE_PLACEMENT_PROBES")));
     if (getenv("SGE_OVERLAP_SKIN_WORKGROUPS")) c->overlapSkinWorkgroups = atoi(getenv("SGE_OVERLAP_SKIN_WORKGROUPS"));
+    if (getenv("SGE_SKIN_PERSISTENT") && atoi(getenv("SGE_SKIN_PERSISTENT")) && c->dSkinQueue.alloc(256) == SGE_OK) c->skinPersistent = true; // experiment
     if (getenv("SGE_OVERLAP_FUSED_WORKGROUPS")) c->overlapFusedWorkgroups = atoi(getenv("SGE_OVERLAP_FUSED_WORKGROUPS"));
     // the latency-bound collision / pose launches go first when they compete with a streaming skin launch (overlap option)
     int prLeast = 0, prGreatest = 0;
@@ -462,7 +464,7 @@ void sge_context_destroy(sge_context* c) {
                       &c->dCellCursor, &c->dAgentMinMax, &c->dAgentGrid, &c->dAgentsAll, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats,
                       &c->dBlasEntryLink, &c->dBlasWideFirst, &c->dBlasWideParent, &c->dBlasWideLevel, &c->dBlasSlotIdx, &c->dBlasSlotTri,
                       &c->dBlasIndices, &c->dBlasBounds, &c->dBlasInstances, &c->dBlasRays, &c->dBlasHits, &c->dBlasTileStart,
-                      &c->dBlasRoundLen, &c->dBlasRoundCluster, &c->dBlasRoundIds, &c->dBlasWorldBoxes, &c->dBlasUVs, &c->dBlasQueue};
+                      &c->dBlasRoundLen, &c->dBlasRoundCluster, &c->dBlasRoundIds, &c->dBlasWorldBoxes, &c->dBlasUVs, &c->dBlasQueue, &c->dSkinQueue};
     for (DevBuf* b : bufs) b->release();
     if (c->evPoseDone) (void)hipEventDestroy(c->evPoseDone);
     for (hipEvent_t e : c->evSkinDone) if (e) (void)hipEventDestroy(e);
@@ -1209,7 +1211,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         } else {
             {
                 Bracket br(c, &c->evSkin, ss);
-                launch_skin(L, ss, overlap ? c->overlapSkinWorkgroups : 0);
+                launch_skin(L, ss, overlap ? c->overlapSkinWorkgroups : 0, overlap && c->skinPersistent ? c->dSkinQueue.as<int>() : nullptr);
             }
             if (refit) { // RTAccelerationBuilder.build is enqueued right behind the skinning encoder (RayTracingScene.swift:35-43)
                 Bracket br(c, &c->evBlas, ss);

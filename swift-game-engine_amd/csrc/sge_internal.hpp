@@ -272,7 +272,7 @@ struct SkinLaunch {
     int srcLayout, dstLayout;
     void* outPos; void* outNrm; void* outTan;
 };
-void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU = 0);
+void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU = 0, int* persistentQueue = nullptr);
 // one record per RTSkinningJob of a batched encode (device copy)
 struct SkinJobDev {
     const void* srcPos; const void* srcNrm; const void* srcTan; const void* srcIdx; const void* srcWgt;

@@ -214,6 +214,25 @@ __global__ __launch_bounds__(kSkinBlock, SGE_SKIN_MIN_BLOCKS) void skin_kernel(S
     }
 }
 
+// Experiment (SGE_SKIN_PERSISTENT): as many workgroups as are meant to stay resident, work units after the first drawn from a
+// ticket counter (see skin_refit_kernel). The workgroups never leave, so no collision workgroup can take an LBS workgroup's place.
+template <int SRC_STRIDE, int DST_STRIDE>
+__global__ __launch_bounds__(kSkinBlock, SGE_SKIN_MIN_BLOCKS) void skin_ticket_kernel(SkinLaunch L, int splits, int vertsPerSplit, int* __restrict__ queue) {
+    __shared__ float4 pal[SGE_MAX_BONES * 3];
+    __shared__ int sNextUnit;
+    for (int u = blockIdx.x; u < L.chars * splits;) {
+        const int c = u / splits;
+        const int sp = u - c * splits;
+        const int vBegin = sp * vertsPerSplit;
+        int ticket = 0;
+        if (threadIdx.x == 0) ticket = atomicAdd(queue, 1);
+        skinRange<SRC_STRIDE, DST_STRIDE>(L, c, vBegin, min(L.vertexCount, vBegin + vertsPerSplit), pal);
+        if (threadIdx.x == 0) sNextUnit = (int)gridDim.x + ticket;
+        __syncthreads(); // also: every thread is done with the palette
+        u = sNextUnit; // the next write follows the next unit's barrier in skinRange
+    }
+}
+
 // RTSkinningEncoder.encode over a heterogeneous job list (RTSkinningEncoder.swift:37-54 dispatches once per job): ONE launch.
 // blockJob[b] = (job, first vertex) of workgroup b; every job keeps its own source streams, palette and destination offset.
 template <int DST_STRIDE>
@@ -265,7 +284,7 @@ void launch_store_probe(void* outPos, void* outNrm, void* outTan, int chars, int
 // maxWorkgroupsPerCU > 0 caps the kernel's residency with dynamic-LDS padding: beside the next step's collision kernels
 // (SGE_OPT_OVERLAP_SKIN) three workgroups per CU stream as fast as five do alone, and the rest of the register file goes to the
 // latency-bound side (measured: 1.50 ms per step uncapped, 1.31 ms capped at three, 1.74 ms without overlap).
-void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU) {
+void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU, int* persistentQueue) {
     if (L.chars <= 0 || L.vertexCount <= 0) return;
     // enough workgroups to fill 256 CUs x 8 resident blocks several times over; small crowds split characters
     int splits = 1;
@@ -279,6 +298,15 @@ void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU) {
         static const int totalOverride = getenv("SGE_SKIN_LDS_TOTAL") ? atoi(getenv("SGE_SKIN_LDS_TOTAL")) : 0; // experiments
         const int perWorkgroup = totalOverride > 0 ? totalOverride : 160 * 1024 / maxWorkgroupsPerCU, own = (int)sizeof(float4) * SGE_MAX_BONES * 3;
         ldsPad = perWorkgroup > own + 256 ? (perWorkgroup - own - 256) & ~255 : 0;
+    }
+    if (persistentQueue && maxWorkgroupsPerCU > 0 && L.srcLayout != SGE_LAYOUT_PADDED16) { // experiment: resident workgroups + ticket counter
+        (void)hipMemsetAsync(persistentQueue, 0, sizeof(int), s);
+        static const int quarters = getenv("SGE_SKIN_PERSISTENT") ? atoi(getenv("SGE_SKIN_PERSISTENT")) : 0; // > 1: workgroups per CU in quarters
+        const size_t want = quarters > 1 ? (size_t)currentDeviceCUs() * quarters / 4 : (size_t)currentDeviceCUs() * maxWorkgroupsPerCU;
+        dim3 pgrid((unsigned)std::min<size_t>((size_t)splits * L.chars, want));
+        if (ds == 3) hipLaunchKernelGGL((skin_ticket_kernel<3, 3>), pgrid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit, persistentQueue);
+        else hipLaunchKernelGGL((skin_ticket_kernel<3, 4>), pgrid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit, persistentQueue);
+        return;
     }
     static const int prio = getenv("SGE_SKIN_SETPRIO") ? atoi(getenv("SGE_SKIN_SETPRIO")) : 0;
     const int wp = maxWorkgroupsPerCU > 0 ? prio : 0;
