@@ -900,6 +900,38 @@ def test_overlap_mode_parity(sge):
     cpu.close()
 
 
+def test_resident_lbs_experiment_writes_the_same_streams(sge, monkeypatch):
+    """SGE_SKIN_PERSISTENT (experiment switch, read when a context is created): in overlap mode the LBS kernel runs as resident
+    workgroups that draw their characters from a ticket counter. Same arithmetic, so the three output streams must be bit-identical
+    to the shipped launch: a small crowd whose characters are split over several work units, and a larger one; both have more units than
+    the 512 resident workgroups (two per CU), so most units are drawn from the counter."""
+    ybot = sge.assets.YBotAssets()
+    for n in (37, 1500):
+        outs = []
+        for persistent in (None, "8"):
+            if persistent:
+                monkeypatch.setenv("SGE_SKIN_PERSISTENT", persistent)
+            else:
+                monkeypatch.delenv("SGE_SKIN_PERSISTENT", raising=False)
+            gpu = sge.CharacterEngine(0)
+            try:
+                gpu.set_option(sge.abi.OPT_OVERLAP_SKIN, 1)
+                sge.crowd.upload_character_assets(gpu, ybot)
+                terrain = sge.crowd.upload_terrain(gpu)
+                sge.crowd.spawn_crowd(gpu, ybot, n, terrain, seed=21, mode="ccd", mixed=True)
+                for _ in range(4):
+                    gpu.tick()
+                V = gpu.vertex_count
+                first = max(0, n - 3) * V  # the last characters: certainly drawn from the counter
+                outs.append([a.copy() for a in gpu.skinned(first_vertex=first, vertex_count=3 * V)] +
+                            [a.copy() for a in gpu.skinned(first_vertex=0, vertex_count=2 * V)])
+            finally:
+                gpu.close()
+        for a, b in zip(*outs):
+            assert np.array_equal(a, b), n
+    monkeypatch.delenv("SGE_SKIN_PERSISTENT", raising=False)
+
+
 def test_api_edge_cases(sge):
     """Empty crowd, empty world, state errors and argument checks of the C ABI (status codes, no crashes)."""
     gpu = sge.CharacterEngine(0)
