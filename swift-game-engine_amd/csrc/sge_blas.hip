@@ -126,8 +126,8 @@ static int launchRefitTile(const DevBlas& B, const float* p, int layout, long lo
     static bool attrSet[kMaxDevices] = {};
     const int devSlot = currentDeviceSlot();
     if (!attrSet[devSlot]) {
-        SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blas_refit_kernel<3, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlasMaxLdsBytes));
-        SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blas_refit_kernel<4, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlasMaxLdsBytes));
+        SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blas_refit_kernel<3, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlasMaxLdsBytes + 64)); // + the ticket slot
+        SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blas_refit_kernel<4, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlasMaxLdsBytes + 64)); // + the ticket slot
         attrSet[devSlot] = true;
     }
     if (layout == SGE_LAYOUT_PADDED16) hipLaunchKernelGGL((blas_refit_kernel<4, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, B, p, firstVertex, chars, bounds, queue);
