@@ -60,7 +60,10 @@ struct sge_context {
     int placementProbes = 8;   // candidate placements of the skinned output streams compared at allocation time
     float placementMs = 0; int placementTried = 0;
     int overlapSkinWorkgroups = 3; // LBS workgroups per CU while it shares the chip with the next step's collision kernels
-    bool skinPersistent = false; // experiment (SGE_SKIN_PERSISTENT): resident LBS workgroups + ticket counter in overlap mode
+    // overlap mode, LBS as resident workgroups with a ticket counter (quarters of a workgroup per CU): -1 = by crowd size (8 from
+    // kResidentSkinCharacters characters on when the tick has a move stage: +3 ... +8 % per step at 16k-40k characters on both scenes,
+    // -0.5 % at 10k, -6 % at 2.5k and for LBS-only ticks at any size), 0 = never, q > 0 = always (SGE_SKIN_PERSISTENT)
+    int residentSkinQuarters = -1;
     int overlapFusedWorkgroups = 0; // cap for the persistent workgroups of the fused LBS + refit kernel (0: as many as the LDS holds; measured 1 / 2 / 3: 1.53 / 1.47 / 1.44 ms per step)
     int heavyThreshold = 4000; // distance evaluations in a character's last step above which it takes the multi-wave kernel; < 0: off
     int heavyCap = 2048;       // most characters the multi-wave launch takes per step (= its grid: workgroups beyond the list exit at once)
@@ -418,7 +421,7 @@ sge_context* sge_context_create(int device_index) {
     if (getenv("SGE_HEAVY_CAP")) c->heavyCap = std::max(1, atoi(getenv("SGE_HEAVY_CAP")));
     if (getenv("SGE_PLACEMENT_PROBES")) c->placementProbes = std::max(1, atoi(getenv("SGE_PLACEMENT_PROBES")));
     if (getenv("SGE_OVERLAP_SKIN_WORKGROUPS")) c->overlapSkinWorkgroups = atoi(getenv("SGE_OVERLAP_SKIN_WORKGROUPS"));
-    if (getenv("SGE_SKIN_PERSISTENT") && atoi(getenv("SGE_SKIN_PERSISTENT")) && c->dSkinQueue.alloc(256) == SGE_OK) c->skinPersistent = true; // experiment
+    if (getenv("SGE_SKIN_PERSISTENT")) c->residentSkinQuarters = atoi(getenv("SGE_SKIN_PERSISTENT"));
     if (getenv("SGE_OVERLAP_FUSED_WORKGROUPS")) c->overlapFusedWorkgroups = atoi(getenv("SGE_OVERLAP_FUSED_WORKGROUPS"));
     // the latency-bound collision / pose launches go first when they compete with a streaming skin launch (overlap option)
     int prLeast = 0, prGreatest = 0;
@@ -448,6 +451,7 @@ sge_context* sge_context_create(int device_index) {
         hipEventCreateWithFlags(&c->evClassified, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evHeavyDone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evTablesCopied, hipEventDisableTiming) != hipSuccess) { set_error("stream/event creation failed"); delete c; return nullptr; }
+    if (c->dSkinQueue.alloc(256) != SGE_OK) { delete c; return nullptr; }
     if (c->dStats.alloc((size_t)kStatShards * 64) != SGE_OK || hipMemsetAsync(c->dStats.p, 0, (size_t)kStatShards * 64, c->stream) != hipSuccess) { delete c; return nullptr; }
     return c;
 }
@@ -1211,7 +1215,9 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         } else {
             {
                 Bracket br(c, &c->evSkin, ss);
-                launch_skin(L, ss, overlap ? c->overlapSkinWorkgroups : 0, overlap && c->skinPersistent ? c->dSkinQueue.as<int>() : nullptr);
+                const int quarters = !overlap ? 0 : c->residentSkinQuarters >= 0 ? c->residentSkinQuarters
+                                     : ((st & SGE_STAGE_MOVE) && count >= kResidentSkinCharacters ? 8 : 0);
+                launch_skin(L, ss, overlap ? c->overlapSkinWorkgroups : 0, c->dSkinQueue.as<int>(), quarters);
             }
             if (refit) { // RTAccelerationBuilder.build is enqueued right behind the skinning encoder (RayTracingScene.swift:35-43)
                 Bracket br(c, &c->evBlas, ss);

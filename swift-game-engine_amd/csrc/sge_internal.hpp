@@ -246,6 +246,7 @@ inline int currentDeviceCUs() {
 constexpr int kMoveScratchBytes = 256;
 constexpr int kTraversalStackCap = 256; // LDS stack of pending wide nodes per query (sge_ccd.hip)
 constexpr int kStatShards = 256; // device counters: kStatShards lines of 8 x u64
+constexpr int kResidentSkinCharacters = 16384; // overlap mode: crowds from this size on skin with resident workgroups (sge_api.hip)
 void launch_move(const MoveLaunch& L, hipStream_t s);
 constexpr size_t kSeparationAgentBytes = 56; // SepAgentDev (sge_ccd.hip)
 void launch_separation(const DevCrowd& crowd, const DevCollision& col, int iterations, float separationMargin, float heightMargin,
@@ -272,7 +273,8 @@ struct SkinLaunch {
     int srcLayout, dstLayout;
     void* outPos; void* outNrm; void* outTan;
 };
-void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU = 0, int* persistentQueue = nullptr);
+// residentQueue + residentQuarters > 0: the resident form (quarters of a workgroup per CU, one device int as the ticket counter)
+void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU = 0, int* residentQueue = nullptr, int residentQuarters = 0);
 // one record per RTSkinningJob of a batched encode (device copy)
 struct SkinJobDev {
     const void* srcPos; const void* srcNrm; const void* srcTan; const void* srcIdx; const void* srcWgt;

@@ -214,8 +214,11 @@ __global__ __launch_bounds__(kSkinBlock, SGE_SKIN_MIN_BLOCKS) void skin_kernel(S
     }
 }
 
-// Experiment (SGE_SKIN_PERSISTENT): as many workgroups as are meant to stay resident, work units after the first drawn from a
-// ticket counter (see skin_refit_kernel). The workgroups never leave, so no collision workgroup can take an LBS workgroup's place.
+// The resident form: as many workgroups as are meant to stay on the chip, work units after the first drawn from a ticket counter
+// (see skin_refit_kernel). The workgroups never leave, so no collision workgroup can take an LBS workgroup's place: beside the
+// next step's collision kernels the launch keeps its own rate and the collision side gets what is left. sge_tick uses it for
+// large crowds, where the shipped hand-over of places lets the big collision launches hold every place until they drain
+// (DESIGN.md 3.5); SGE_SKIN_PERSISTENT=q forces q/4 workgroups per CU, 0 switches it off.
 template <int SRC_STRIDE, int DST_STRIDE>
 __global__ __launch_bounds__(kSkinBlock, SGE_SKIN_MIN_BLOCKS) void skin_ticket_kernel(SkinLaunch L, int splits, int vertsPerSplit, int* __restrict__ queue) {
     __shared__ float4 pal[SGE_MAX_BONES * 3];
@@ -284,7 +287,7 @@ void launch_store_probe(void* outPos, void* outNrm, void* outTan, int chars, int
 // maxWorkgroupsPerCU > 0 caps the kernel's residency with dynamic-LDS padding: beside the next step's collision kernels
 // (SGE_OPT_OVERLAP_SKIN) three workgroups per CU stream as fast as five do alone, and the rest of the register file goes to the
 // latency-bound side (measured: 1.50 ms per step uncapped, 1.31 ms capped at three, 1.74 ms without overlap).
-void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU, int* persistentQueue) {
+void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU, int* residentQueue, int residentQuarters) {
     if (L.chars <= 0 || L.vertexCount <= 0) return;
     // enough workgroups to fill 256 CUs x 8 resident blocks several times over; small crowds split characters
     int splits = 1;
@@ -299,13 +302,11 @@ void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU, int
         const int perWorkgroup = totalOverride > 0 ? totalOverride : 160 * 1024 / maxWorkgroupsPerCU, own = (int)sizeof(float4) * SGE_MAX_BONES * 3;
         ldsPad = perWorkgroup > own + 256 ? (perWorkgroup - own - 256) & ~255 : 0;
     }
-    if (persistentQueue && maxWorkgroupsPerCU > 0 && L.srcLayout != SGE_LAYOUT_PADDED16) { // experiment: resident workgroups + ticket counter
-        (void)hipMemsetAsync(persistentQueue, 0, sizeof(int), s);
-        static const int quarters = getenv("SGE_SKIN_PERSISTENT") ? atoi(getenv("SGE_SKIN_PERSISTENT")) : 0; // > 1: workgroups per CU in quarters
-        const size_t want = quarters > 1 ? (size_t)currentDeviceCUs() * quarters / 4 : (size_t)currentDeviceCUs() * maxWorkgroupsPerCU;
-        dim3 pgrid((unsigned)std::min<size_t>((size_t)splits * L.chars, want));
-        if (ds == 3) hipLaunchKernelGGL((skin_ticket_kernel<3, 3>), pgrid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit, persistentQueue);
-        else hipLaunchKernelGGL((skin_ticket_kernel<3, 4>), pgrid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit, persistentQueue);
+    if (residentQueue && residentQuarters > 0 && L.srcLayout != SGE_LAYOUT_PADDED16) { // resident workgroups + ticket counter
+        (void)hipMemsetAsync(residentQueue, 0, sizeof(int), s);
+        dim3 pgrid((unsigned)std::min<size_t>((size_t)splits * L.chars, (size_t)currentDeviceCUs() * residentQuarters / 4));
+        if (ds == 3) hipLaunchKernelGGL((skin_ticket_kernel<3, 3>), pgrid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit, residentQueue);
+        else hipLaunchKernelGGL((skin_ticket_kernel<3, 4>), pgrid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit, residentQueue);
         return;
     }
     static const int prio = getenv("SGE_SKIN_SETPRIO") ? atoi(getenv("SGE_SKIN_SETPRIO")) : 0;

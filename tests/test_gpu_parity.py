@@ -900,19 +900,20 @@ def test_overlap_mode_parity(sge):
     cpu.close()
 
 
-def test_resident_lbs_experiment_writes_the_same_streams(sge, monkeypatch):
-    """SGE_SKIN_PERSISTENT (experiment switch, read when a context is created): in overlap mode the LBS kernel runs as resident
-    workgroups that draw their characters from a ticket counter. Same arithmetic, so the three output streams must be bit-identical
-    to the shipped launch: a small crowd whose characters are split over several work units, and a larger one; both have more units than
-    the 512 resident workgroups (two per CU), so most units are drawn from the counter."""
+def test_resident_lbs_form_writes_the_same_streams(sge, monkeypatch):
+    """Overlap mode skins large crowds (>= 16,384 characters with a move stage) with resident workgroups that draw their work units
+    from a ticket counter; SGE_SKIN_PERSISTENT (read when a context is created) forces the form on (q/4 workgroups per CU) or off (0).
+    Same arithmetic either way, so the three output streams must be bit-identical: a small crowd whose characters are split over
+    several work units and a larger one with the form forced, then the automatic choice at 16,500 characters against the form
+    switched off. All have more units than resident workgroups, so most units are drawn from the counter."""
     ybot = sge.assets.YBotAssets()
-    for n in (37, 1500):
+    for n, settings in ((37, ("0", "8")), (1500, ("0", "7")), (16500, ("0", None))):
         outs = []
-        for persistent in (None, "8"):
-            if persistent:
-                monkeypatch.setenv("SGE_SKIN_PERSISTENT", persistent)
-            else:
+        for setting in settings:
+            if setting is None:
                 monkeypatch.delenv("SGE_SKIN_PERSISTENT", raising=False)
+            else:
+                monkeypatch.setenv("SGE_SKIN_PERSISTENT", setting)
             gpu = sge.CharacterEngine(0)
             try:
                 gpu.set_option(sge.abi.OPT_OVERLAP_SKIN, 1)
@@ -924,7 +925,7 @@ def test_resident_lbs_experiment_writes_the_same_streams(sge, monkeypatch):
                 V = gpu.vertex_count
                 first = max(0, n - 3) * V  # the last characters: certainly drawn from the counter
                 outs.append([a.copy() for a in gpu.skinned(first_vertex=first, vertex_count=3 * V)] +
-                            [a.copy() for a in gpu.skinned(first_vertex=0, vertex_count=2 * V)])
+                            [a.copy() for a in gpu.skinned(first_vertex=(n // 2) * V, vertex_count=2 * V)])
             finally:
                 gpu.close()
         for a, b in zip(*outs):
