@@ -70,6 +70,7 @@ struct sge_context {
     bool skinPending[2] = {false, false}, overlapSkin = false, customStream = false;
     // options
     bool storePoseDebug = false, profile = false;
+    bool waveProfOn = false; // SGE_WAVE_PROF=1: in-kernel cycle stamps of the move and pose kernels (diagnostics, tools/wave_prof.py)
     int skinLayout = SGE_LAYOUT_PACKED;
     // skeleton
     int boneCount = 0;
@@ -417,6 +418,7 @@ sge_context* sge_context_create(int device_index) {
     if (hipSetDevice(device_index) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
     sge_context* c = new sge_context();
     c->device = device_index;
+    c->waveProfOn = getenv("SGE_WAVE_PROF") != nullptr;
     if (getenv("SGE_HEAVY_THRESHOLD")) c->heavyThreshold = atoi(getenv("SGE_HEAVY_THRESHOLD")); // experiments
     if (getenv("SGE_HEAVY_CAP")) c->heavyCap = std::max(1, atoi(getenv("SGE_HEAVY_CAP")));
     if (getenv("SGE_PLACEMENT_PROBES")) c->placementProbes = std::max(1, atoi(getenv("SGE_PLACEMENT_PROBES")));
@@ -1145,9 +1147,9 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
                      c->dStats.as<unsigned long long>(), c->dMoveScratch.p, c->dPlatforms.as<sge_platform_state>(), c->platformCount,
                      c->dCost.as<int>(), getenv("SGE_NO_SPEC") ? nullptr : c->dHint.as<uint8_t>(), c->dLists.as<int>(), c->dListCounts.as<int>(), c->dHeavyFlags.as<uint8_t>(),
                      c->heavyThreshold, c->heavyCap, c->heavyStream, c->evClassified, c->evHeavyDone, nullptr, nullptr, nullptr, nullptr, c->dOrderHist.as<int>(), nullptr};
-        if (getenv("SGE_WAVE_PROF")) {
-            if (c->dWaveProf.alloc((size_t)c->crowd.count * 64) != SGE_OK) return SGE_ERR_DEVICE;
-            SGE_HIP(hipMemsetAsync(c->dWaveProf.p, 0, (size_t)c->crowd.count * 64, c->stream));
+        if (c->waveProfOn) {
+            if (c->dWaveProf.alloc((size_t)c->crowd.count * 3 * 64) != SGE_OK) return SGE_ERR_DEVICE;
+            SGE_HIP(hipMemsetAsync(c->dWaveProf.p, 0, (size_t)c->crowd.count * 3 * 64, c->stream));
             L.waveProf = c->dWaveProf.as<unsigned long long>();
         }
         if (!(st & SGE_STAGE_AGENTS) || !c->agents.grid) L.agents.all = nullptr;
@@ -1178,7 +1180,8 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
             }
             c->crowd.palettes = c->dPalettes[c->palRead].as<float>();
         }
-        PoseLaunch L{c->crowd, c->sk, c->prof, d->dt, st, first, count};
+        PoseLaunch L{c->crowd, c->sk, c->prof, d->dt, st, first, count,
+                     c->waveProfOn && c->dWaveProf.p ? c->dWaveProf.as<unsigned long long>() + (size_t)c->crowd.count * 2 * 8 : nullptr};
         Bracket br(c, &c->evPose);
         launch_pose(L, c->stream);
     }

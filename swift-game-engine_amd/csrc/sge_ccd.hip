@@ -53,6 +53,11 @@ constexpr int kMaxRays = 6;
 #else
 #define SGE_PAD_VGPRS()
 #endif
+#ifdef SGE_CCD_SETPRIO
+#define SGE_HEAVY_PRIO() __builtin_amdgcn_s_setprio(SGE_CCD_SETPRIO)
+#else
+#define SGE_HEAVY_PRIO()
+#endif
 #ifndef SGE_GROUP_WAVES
 #define SGE_GROUP_WAVES 3
 #endif
@@ -1543,8 +1548,15 @@ template <int PART, bool AGENTS, bool HEAVY = false>
 #ifndef SGE_MOVE_WAVES1
 #define SGE_MOVE_WAVES1 4
 #endif
-__global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? (SGE_CCD_EXCLUSIVE ? 2 : 4) : (HEAVY ? 1 : SGE_MOVE_WAVES1)) void move_kernel(MoveLaunch K) {
+// (the multi-wave form: three waves per SIMD = at most 168 VGPRs, so that its 2 waves per SIMD fit into the 336 registers two resident
+// LBS wavefronts leave of a SIMD's 512; at the 176 the compiler takes when asked for less, the workgroup found no CU beside a resident
+// LBS launch and ran only after it: DESIGN.md 3.5)
+#ifndef SGE_HEAVY_WAVES_EU
+#define SGE_HEAVY_WAVES_EU 3
+#endif
+__global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? (SGE_CCD_EXCLUSIVE ? 2 : 4) : (HEAVY ? SGE_HEAVY_WAVES_EU : SGE_MOVE_WAVES1)) void move_kernel(MoveLaunch K) {
     if (PART == 0) SGE_PAD_VGPRS();
+    if (HEAVY) SGE_HEAVY_PRIO();
     // PART 1 may run over an index list (light / heavy characters of this step, see classify_kernel)
     if (PART == 1 && K.list && (int)blockIdx.x >= *K.listCount) return;
     const int e = (PART == 1 && K.list) ? K.list[blockIdx.x] : K.first + xcdRemap((int)blockIdx.x, K.count);
@@ -1552,6 +1564,8 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? (S
     const int lane = laneId();
     WaveStats st{0, 0, 0, 0, 0, 0, 0};
     const DevCollision& col = K.col;
+    const long long pT0 = (PART == 0 && K.waveProf) ? (long long)__builtin_amdgcn_s_memtime() : 0; // diagnostics (SGE_WAVE_PROF)
+    long long pQuery = 0;
     if (HEAVY) {
         if (threadIdx.x == 0) { hv.cmd = HCMD_NONE; hv.evalSum = 0; }
         __syncthreads();
@@ -1703,7 +1717,11 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? (S
         __syncthreads();
         // ---------------- 2. the query ----------------
         int nOverlap = 0;
-        if (PART == 0 && doOverlap) nOverlap = waveCapsuleOverlapAll(col, ms.position, P.radius, P.halfHeight, 8, P.collisionMask, st);
+        if (PART == 0 && doOverlap) {
+            const long long pq = K.waveProf ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            nOverlap = waveCapsuleOverlapAll(col, ms.position, P.radius, P.halfHeight, 8, P.collisionMask, st);
+            if (K.waveProf) pQuery += (long long)__builtin_amdgcn_s_memtime() - pq;
+        }
         if (PART == 1 && doCast) waveCastRays<HEAVY>(col, P.radius, P.halfHeight, blocking, !blocking, P.minGroundDot, P.collisionMask, st,
                                                      HEAVY && phase == MP_GROUND_CENTER ? 1 : -1);
         // ---------------- 3. consume ----------------
@@ -1742,6 +1760,11 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? (S
         atomicAdd(&g_cycTotal, (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - tStart));
     }
 #endif
+    if (PART == 0 && K.waveProf && lane == 0) { // region 1 of the diagnostics buffer: one row per character
+        unsigned long long* w = K.waveProf + ((size_t)K.crowd.count + (size_t)e) * 8;
+        w[0] = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - pT0); w[1] = (unsigned long long)pQuery;
+        w[2] = st.steps; w[3] = st.trips; w[7] = (unsigned long long)pT0;
+    }
     if (HEAVY) { // release the helper waves
         if (lane == 0) hv.cmd = HCMD_EXIT;
         __syncthreads();

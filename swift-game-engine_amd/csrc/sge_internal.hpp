@@ -223,7 +223,9 @@ struct MoveLaunch {
     const int* list; const int* listCount; // what a part-1 launch iterates over (set by launch_move)
     const int* order; const int* orderCount; // grouped launch: characters sorted by last step's cost (device), its length
     int* orderHist;                        // [64] histogram / cursors of the order list (zero between steps)
-    unsigned long long* waveProf;          // diagnostics (SGE_WAVE_PROF=1): [ceil(count / kGroup)][8] cycles of each wavefront of move_group_kernel
+    // diagnostics (SGE_WAVE_PROF=1), rows of 8 x u64 in three regions of crowd.count rows each: [0] one row per wavefront of
+    // move_group_kernel, [1] one row per character of move_kernel<0>, [2] one row per character of pose_kernel
+    unsigned long long* waveProf;
 };
 // Per-device launch state: a process may hold contexts on several GPUs (sge_context_create(device_index)), and function attributes
 // and the CU count belong to the device that is current at the launch (every entry point calls hipSetDevice(ctx->device) first).
@@ -262,6 +264,7 @@ void launch_overlap_deepest_queries(const DevCollision& col, const sge_capsule_q
 struct PoseLaunch {
     DevCrowd crowd; DevSkeleton sk; DevProfiles prof;
     float dt; uint32_t stages; int first, count;
+    unsigned long long* waveProf; // diagnostics: region [2] of MoveLaunch::waveProf, or null
 };
 void launch_pose(const PoseLaunch& L, hipStream_t s);
 

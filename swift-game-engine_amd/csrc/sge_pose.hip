@@ -140,6 +140,9 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
     // local and model matrices of this character's bones, 12 floats each: sized by the launch for the skeleton's bone count
     // (a fixed SGE_MAX_BONES-sized array would cap the CU at 6 workgroups for a 65-bone rig)
     extern __shared__ float sPose[];
+#ifdef SGE_POSE_SETPRIO // experiment: issue priority over the LBS wavefronts on the same SIMD
+    __builtin_amdgcn_s_setprio(SGE_POSE_SETPRIO);
+#endif
     float* const sLocal = sPose;
     float* const sModel = sPose + (size_t)K.sk.boneCount * 12;
     const int e = K.first + blockIdx.x;
@@ -148,6 +151,10 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
     const DevProfiles& pf = K.prof;
     const int B = sk.boneCount;
     const float dt = K.dt;
+    // diagnostics (SGE_WAVE_PROF): cycle stamps of the phases, one row of 8 x u64 per character
+    long long pS[6] = {0, 0, 0, 0, 0, 0};
+#define SGE_POSE_STAMP(k) do { if (K.waveProf) pS[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    SGE_POSE_STAMP(0);
 
     sge_locomotion_state L = K.crowd.locomotion[e];
     sge_action_state A = K.crowd.actions[e];
@@ -215,6 +222,7 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
         if (exiting) A.flags |= SGE_ACTION_EXITING;
     }
 
+    SGE_POSE_STAMP(1);
     if (K.stages & SGE_STAGE_POSE) {
         const bool loop = (L.flags & SGE_MOTION_LOOP) != 0;
         const bool inPlace = (L.flags & SGE_MOTION_IN_PLACE) != 0;
@@ -324,6 +332,7 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
             for (int i = lane; i < B; i += kWave) storeAff12(sLocal + i * 12, loadAff12(sk.bindLocal + i * 12));
         }
         __syncthreads();
+        SGE_POSE_STAMP(2);
 
         // ---- action layer :286-338 ----
         if ((A.flags & SGE_ACTION_PRESENT) && (A.flags & SGE_ACTION_ACTIVE) && A.weight > 0.001f) {
@@ -399,6 +408,7 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
             }
         }
 
+        SGE_POSE_STAMP(3);
         // ---- model transforms, then the palette :396-402 ----
         // model[i] = model[parent] * local[i] unrolls to local[root] * ... * local[i] multiplied left to right; every lane
         // walks its own bone's ancestor path in that order (the same sequence of products, hence the same bits, as the
@@ -414,6 +424,7 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
             }
             __syncthreads();
         }
+        SGE_POSE_STAMP(4);
         float* pal = K.crowd.palettes + ((size_t)e * B) * 16;
         for (int i = lane; i < B; i += kWave) {
             Aff M = loadAff12(sModel + i * 12);
@@ -440,6 +451,14 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
         }
     }
 
+    if (K.waveProf && lane == 0) { // state machines | locals | action + ground align + lean | model products | palette
+        SGE_POSE_STAMP(5);
+        unsigned long long* w = K.waveProf + (size_t)e * 8;
+        w[0] = (unsigned long long)(pS[5] - pS[0]);
+        for (int k = 1; k <= 5; ++k) w[k] = (unsigned long long)(pS[k] - pS[k - 1]);
+        w[7] = (unsigned long long)pS[0];
+    }
+#undef SGE_POSE_STAMP
     if (lane == 0) {
         if (K.stages & (SGE_STAGE_LOCOMOTION | SGE_STAGE_POSE)) K.crowd.locomotion[e] = L;
         if (K.stages & SGE_STAGE_ACTION) K.crowd.actions[e] = A;
