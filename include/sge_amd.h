@@ -242,8 +242,12 @@ enum {
                                    * kernel (the boxes are reduced from the positions while they are still on chip), except
                                    * under SGE_OPT_OVERLAP_SKIN, where the fused kernel would keep the next step's collision
                                    * kernels off the chip; 2: always; 0: two launches, the refit reads the positions back */
-    SGE_OPT_OVERLAP_SKIN = 4      /* 1: run the skin stage on a second stream so that it overlaps the next
-                                     step's move stage (ignored on a caller-provided stream) */
+    SGE_OPT_OVERLAP_SKIN = 4      /* 1: the skin stage of sge_tick runs on the context's second stream, so that skin(n) overlaps
+                                   * move(n+1) + pose(n+1) (the benchmarked schedule). Holds on a caller-provided stream as well
+                                   * (sge_context_set_stream): the skin launch is ordered behind the pose stage on that stream by
+                                   * events. What is enqueued on the caller's stream behind sge_tick is then NOT ordered behind
+                                   * the skin launch by itself: a consumer of the skinned streams calls sge_skin_wait first
+                                   * (sge_blas_refit*, sge_skinning_encode, the downloads and sge_synchronize join by themselves). */
 };
 enum {
     SGE_LAYOUT_PACKED = 0,  /* positions/normals float[3] (12 B), tangents float[4] */
@@ -351,9 +355,27 @@ int sge_skinning_encode(sge_context* ctx, void* d_outPositions, void* d_outNorma
                         const sge_skinning_job* jobs, int32_t job_count);
 
 /* Device-pointer accessors for the context-owned crowd buffers (for building
- * sge_skinning_job lists or handing the streams to a downstream consumer). */
+ * sge_skinning_job lists or handing the streams to a downstream consumer).
+ * d_palettes is the buffer the NEWEST pose stage wrote. Without SGE_OPT_OVERLAP_SKIN it never changes. With it the palettes
+ * alternate between two buffers (pose(n+1) writes one while skin(n) still reads the other): the pointer is valid until the next
+ * whole-crowd pose stage, so query it again after every tick (RTGeometryCache.makeSkinningJob builds a fresh palette buffer per
+ * job per frame as well, RTGeometryCache.swift:556-566), or take both with sge_crowd_palette_buffers.
+ * The output streams never move between ticks; under SGE_OPT_OVERLAP_SKIN a consumer reads them after sge_skin_wait. */
 int sge_crowd_buffers(sge_context* ctx, void** d_palettes, void** d_outPositions,
                       void** d_outNormals, void** d_outTangents);
+/* Both palette buffers ([2]; they do not move until sge_characters_resize) and the index of the one holding the newest pose. */
+int sge_crowd_palette_buffers(sge_context* ctx, void** d_palettes, int32_t* latest);
+/* Orders `consumer_stream` (a hipStream_t; NULL: the context's own current stream) behind every skin launch and every other kernel
+ * the context has enqueued so far, without a host synchronisation: hipStreamWaitEvent on the newest skin launch's event (+ a
+ * marker on the main stream when the consumer is a different stream). The equivalent of enqueueing behind
+ * RTSkinningEncoder.encode on the same MTLCommandBuffer (RTSkinningEncoder.swift:27-56; consumed at RayTracingScene.swift:35-43). */
+int sge_skin_wait(sge_context* ctx, void* consumer_stream);
+/* The reverse ordering, for a consumer that reads the skinned streams asynchronously on a stream of its own: everything
+ * `consumer_stream` holds so far completes before the context's NEXT skin / refit launch overwrites the streams (an event on the
+ * consumer's stream that the context's streams wait for). Not needed when the consumer runs on the context's stream in serial order,
+ * or synchronises with the host before the next sge_tick. One command buffer per frame gives the reference both orderings
+ * (Renderer.swift:159, 224). */
+int sge_skin_consumed(sge_context* ctx, void* consumer_stream);
 int sge_skinned_mesh_buffers(sge_context* ctx, void** d_positions, void** d_normals,
                              void** d_tangents, void** d_boneIndices, void** d_boneWeights);
 

@@ -261,6 +261,9 @@ PROTOTYPES = {
     "sge_skinned_mesh_upload": (C.c_int, [VP, P(SkinnedMeshDesc)]),
     "sge_skinning_encode": (C.c_int, [VP, VP, VP, VP, i32, P(SkinningJob), i32]),
     "sge_crowd_buffers": (C.c_int, [VP, P(VP), P(VP), P(VP), P(VP)]),
+    "sge_crowd_palette_buffers": (C.c_int, [VP, P(VP), P(i32)]),
+    "sge_skin_wait": (C.c_int, [VP, VP]),
+    "sge_skin_consumed": (C.c_int, [VP, VP]),
     "sge_skinned_mesh_buffers": (C.c_int, [VP, P(VP), P(VP), P(VP), P(VP), P(VP)]),
     "sge_collision_rebuild_static": (C.c_int, [VP, P(StaticMeshEntity), i32]),
     "sge_collision_rebuild_dynamic": (C.c_int, [VP, P(StaticMeshEntity), i32]),

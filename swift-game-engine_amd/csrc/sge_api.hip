@@ -51,7 +51,8 @@ struct sge_context {
     hipStream_t ownStream = nullptr, stream = nullptr;
     // LBS of step n overlaps move/CCD of step n+1: skinning runs on its own stream, ordered by two events
     hipStream_t skinStream = nullptr;
-    hipEvent_t evPoseDone = nullptr, evSkinDone[2] = {nullptr, nullptr};
+    hipEvent_t evPoseDone = nullptr, evSkinDone[2] = {nullptr, nullptr}, evMainMark = nullptr, evConsumed = nullptr;
+    int lastSkin = 0;            // palette buffer (= event slot) of the newest overlapped skin launch
     // two palette buffers: with the overlap option pose(n+1) writes one while skin(n) still reads the other, so that only
     // skin(n+1) -> skin(n) and skin(n+1) -> pose(n+1) remain as dependencies (a single buffer chains pose(n+1) behind skin(n))
     int palRead = 0;             // buffer holding the latest palettes
@@ -66,7 +67,8 @@ struct sge_context {
     int residentSkinQuarters = -1;
     int overlapFusedWorkgroups = 0; // cap for the persistent workgroups of the fused LBS + refit kernel (0: as many as the LDS holds; measured 1 / 2 / 3: 1.53 / 1.47 / 1.44 ms per step)
     int heavyThreshold = 4000; // distance evaluations in a character's last step above which it takes the multi-wave kernel; < 0: off
-    int heavyCap = 2048;       // most characters the multi-wave launch takes per step (= its grid: workgroups beyond the list exit at once)
+    int heavyCap = 2048;       // most characters the multi-wave launch takes per step (its grid is sized by demand, see sge_tick)
+    int* hHeavyDemand = nullptr; // pinned host word the move stage copies its demand count to
     bool skinPending[2] = {false, false}, overlapSkin = false, customStream = false;
     // options
     bool storePoseDebug = false, profile = false;
@@ -76,7 +78,9 @@ struct sge_context {
     int boneCount = 0;
     DevSkeleton sk{};
     std::vector<float> hostSkeletonInvBind; // [B][16] skeleton.invBindModel
-    DevBuf dParent, dDepth, dLeanChain, dPath, dBindLocal, dInvBind, dRestT, dRawRestT, dPreRot;
+    std::vector<int32_t> hostParent;        // [B]
+    std::vector<uint8_t> hostAnimated;      // [B] 1: some uploaded profile has an entry for the bone
+    DevBuf dParent, dDepth, dLeanChain, dPath, dBindLocal, dInvBind, dRestT, dRawRestT, dPreRot, dSlotBone;
     // profiles
     DevProfiles prof{};
     DevBuf dCoeffs, dCoeffCount, dBonePresent;
@@ -176,6 +180,56 @@ int refreshInvBind(sge_context* c, const float* meshInvBind, int meshInvBindCoun
     int rc = upload(c->dInvBind, src, (size_t)c->boneCount * 64, c->stream);
     c->sk.invBind = c->dInvBind.as<float>();
     return rc;
+}
+
+// The order in which pose_kernel's lanes take the bones (DevSkeleton::slotBone). A skeleton whose bone count is not a multiple of
+// 64 leaves its last pass partly filled (the Y-Bot: 65 bones, one lane busy in pass two), and that pass costs the wavefront as much
+// as a full one. The bones put there are therefore the cheapest the rig has: bones no uploaded profile has an entry for (their
+// local matrix is pre-rotation + rest translation, nothing to evaluate), leaves first, and never a bone together with its parent
+// (so that their model matrix is one product with the parent's, finished a pass earlier). Rebuilt after either upload.
+int rebuildPoseSlots(sge_context* c) {
+    const int B = c->boneCount;
+    if (B == 0) return SGE_OK;
+    const std::vector<int32_t>& parent = c->hostParent;
+    std::vector<uint8_t> animated = c->hostAnimated;
+    animated.resize(B, 0);
+    const int passes = (B + 63) / 64, extra = B - 64 * (passes - 1);
+    std::vector<int32_t> slots;
+    std::vector<uint8_t> isExtra(B, 0);
+    if (passes > 1 && extra < 64) {
+        std::vector<uint8_t> hasChild(B, 0);
+        for (int i = 0; i < B; ++i) if (parent[i] >= 0) hasChild[parent[i]] = 1;
+        // preference: static leaves, static inner bones, animated leaves, the rest; inside a class the highest index first
+        int picked = 0;
+        for (int cls = 0; cls < 4 && picked < extra; ++cls)
+            for (int i = B - 1; i >= 1 && picked < extra; --i) { // (bone 0 carries the root special cases: it stays in pass one)
+                if ((animated[i] ? 2 : 0) + (hasChild[i] ? 1 : 0) != cls || isExtra[i]) continue;
+                if (parent[i] >= 0 && isExtra[parent[i]]) continue;      // not together with its parent ...
+                bool childPicked = false;
+                for (int j = i + 1; j < B && !childPicked; ++j) childPicked = isExtra[j] && parent[j] == i; // ... or one of its children
+                if (childPicked) continue;
+                isExtra[i] = 1;
+                picked += 1;
+            }
+        if (picked != extra) std::fill(isExtra.begin(), isExtra.end(), 0); // no such choice on this rig: index order
+    }
+    for (int i = 0; i < B; ++i) if (!isExtra[i]) slots.push_back(i);
+    for (int i = 0; i < B; ++i) if (isExtra[i]) slots.push_back(i);
+    std::vector<int> slotOf(B);
+    for (int s = 0; s < B; ++s) slotOf[slots[s]] = s;
+    int lastPassStatic = passes > 1 ? 1 : 0, parentReady = 1;
+    for (int s = 64; s < B; ++s) {
+        const int p = parent[slots[s]];
+        if (p >= 0 && slotOf[p] / 64 >= s / 64) parentReady = 0; // a bone of a later pass needs its parent's model from an earlier one
+    }
+    for (int s = 64 * (passes - 1); s < B && passes > 1; ++s) if (animated[slots[s]]) lastPassStatic = 0;
+    int rc = upload(c->dSlotBone, slots.data(), (size_t)B * 4, c->stream);
+    if (rc != SGE_OK) return rc;
+    SGE_HIP(hipStreamSynchronize(c->stream));
+    c->sk.slotBone = c->dSlotBone.as<int32_t>();
+    c->sk.lastPassStatic = lastPassStatic;
+    c->sk.extraParentReady = parentReady;
+    return SGE_OK;
 }
 
 // The three skinned output streams are the path's HBM traffic (40 B per vertex per step). On MI355X the rate of the three-stream
@@ -449,11 +503,15 @@ sge_context* sge_context_create(int device_index) {
         hipEventCreateWithFlags(&c->evPoseDone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evSkinDone[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evSkinDone[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evMainMark, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evConsumed, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithPriority(&c->heavyStream, hipStreamNonBlocking, prGreatest) != hipSuccess ||
         hipEventCreateWithFlags(&c->evClassified, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evHeavyDone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evTablesCopied, hipEventDisableTiming) != hipSuccess) { set_error("stream/event creation failed"); delete c; return nullptr; }
     if (c->dSkinQueue.alloc(256) != SGE_OK) { delete c; return nullptr; }
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->hHeavyDemand), sizeof(int), hipHostMallocDefault) == hipSuccess) *c->hHeavyDemand = -1;
+    else { (void)hipGetLastError(); c->hHeavyDemand = nullptr; }
     if (c->dStats.alloc((size_t)kStatShards * 64) != SGE_OK || hipMemsetAsync(c->dStats.p, 0, (size_t)kStatShards * 64, c->stream) != hipSuccess) { delete c; return nullptr; }
     return c;
 }
@@ -463,7 +521,7 @@ void sge_context_destroy(sge_context* c) {
     (void)hipSetDevice(c->device);
     (void)syncAll(c);
     drainEvents(c->evMove); drainEvents(c->evPose); drainEvents(c->evSkin); drainEvents(c->evAgents); drainEvents(c->evBlas);
-    DevBuf* bufs[] = {&c->dParent, &c->dDepth, &c->dLeanChain, &c->dPath, &c->dBindLocal, &c->dInvBind, &c->dRestT, &c->dRawRestT, &c->dPreRot,
+    DevBuf* bufs[] = {&c->dSlotBone, &c->dParent, &c->dDepth, &c->dLeanChain, &c->dPath, &c->dBindLocal, &c->dInvBind, &c->dRestT, &c->dRawRestT, &c->dPreRot,
                       &c->dCoeffs, &c->dCoeffCount, &c->dBonePresent, &c->dMeshPos, &c->dMeshNrm, &c->dMeshTan, &c->dMeshIdx, &c->dMeshWgt,
                       &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dSlotOfRank, &c->dCost, &c->dHint, &c->dHeavyFlags, &c->dJobTable, &c->dBlockJob, &c->dLists, &c->dListCounts, &c->dOrderHist, &c->dWaveProf, &c->dSepAgents, &c->dSepCounts, &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
                       &c->dPalettes[0], &c->dPalettes[1], &c->dPoseModel, &c->dPoseLocal, &c->dMoveScratch, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
@@ -473,6 +531,9 @@ void sge_context_destroy(sge_context* c) {
                       &c->dBlasRoundLen, &c->dBlasRoundCluster, &c->dBlasRoundIds, &c->dBlasWorldBoxes, &c->dBlasUVs, &c->dBlasQueue, &c->dSkinQueue};
     for (DevBuf* b : bufs) b->release();
     if (c->evPoseDone) (void)hipEventDestroy(c->evPoseDone);
+    if (c->hHeavyDemand) (void)hipHostFree(c->hHeavyDemand);
+    if (c->evMainMark) (void)hipEventDestroy(c->evMainMark);
+    if (c->evConsumed) (void)hipEventDestroy(c->evConsumed);
     for (hipEvent_t e : c->evSkinDone) if (e) (void)hipEventDestroy(e);
     if (c->skinStream) (void)hipStreamDestroy(c->skinStream);
     if (c->evClassified) (void)hipEventDestroy(c->evClassified);
@@ -488,7 +549,9 @@ int sge_context_set_stream(sge_context* c, void* hip_stream) {
     int rc = syncAll(c);
     if (rc != SGE_OK) return rc;
     c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->ownStream;
-    c->customStream = hip_stream != nullptr; // on a caller's stream everything stays in that stream's order
+    // (SGE_OPT_OVERLAP_SKIN keeps its meaning on a caller's stream: the skin launch then runs on the context's second stream, ordered
+    // behind the pose stage on the caller's stream by events, and a consumer orders itself behind it with sge_skin_wait)
+    c->customStream = hip_stream != nullptr;
     return SGE_OK;
 }
 
@@ -575,6 +638,8 @@ int sge_skeleton_upload(sge_context* c, const sge_skeleton_desc* d) {
     SGE_HIP(hipStreamSynchronize(s)); // host vectors go out of scope
     c->boneCount = B;
     c->hostSkeletonInvBind.assign(d->invBindModel, d->invBindModel + (size_t)B * 16);
+    c->hostParent.assign(d->parent, d->parent + B);
+    c->hostAnimated.assign(B, 0); // profiles are uploaded against a skeleton: a new skeleton starts without any
     DevSkeleton& sk = c->sk;
     sk.boneCount = B;
     sk.pelvisIndex = d->pelvisIndex;
@@ -595,6 +660,7 @@ int sge_skeleton_upload(sge_context* c, const sge_skeleton_desc* d) {
         for (int r = 0; r < 3; ++r) sk.rootFix[col * 3 + r] = d->rootRotationFix[col * 4 + r];
     rc = refreshInvBind(c, nullptr, 0);
     if (rc != SGE_OK) return rc;
+    if ((rc = rebuildPoseSlots(c)) != SGE_OK) return rc;
     SGE_HIP(hipStreamSynchronize(s));
     // palettes depend on boneCount
     if (c->crowd.count > 0) return sge_characters_resize(c, c->crowd.count);
@@ -621,7 +687,8 @@ int sge_motion_profiles_upload(sge_context* c, const sge_motion_profile_desc* p,
             }
         }
     }
-    std::vector<float> coeffs((size_t)count * B * 6 * stride, 0.f);
+    // (one more full row of zeros at the end: pose_kernel reads 2 KMAX + 1 floats of every row it touches, whatever `stride` is)
+    std::vector<float> coeffs((size_t)count * B * 6 * stride + SGE_MAX_COEFFS, 0.f);
     std::vector<uint8_t> cc((size_t)count * B * 6), present((size_t)count * B);
     for (int k = 0; k < count; ++k) {
         std::memcpy(&cc[(size_t)k * B * 6], p[k].coeffCount, (size_t)B * 6);
@@ -638,11 +705,22 @@ int sge_motion_profiles_upload(sge_context* c, const sge_motion_profile_desc* p,
     DevProfiles& pf = c->prof;
     pf.count = count;
     pf.stride = stride;
-    for (int k = 0; k < count; ++k) { pf.order[k] = p[k].order; pf.cycleRaw[k] = p[k].cycleDuration; }
+    pf.maxOrder = 0;
+    pf.nonRootTranslation = 0;
+    c->hostAnimated.assign(B, 0);
+    for (int k = 0; k < count; ++k) {
+        pf.order[k] = p[k].order; pf.cycleRaw[k] = p[k].cycleDuration;
+        pf.maxOrder = p[k].order > pf.maxOrder ? p[k].order : pf.maxOrder;
+        for (int i = 0; i < B; ++i) {
+            if (p[k].bonePresent[i]) c->hostAnimated[i] = 1;
+            for (int a = 0; a < 3; ++a)
+                if (i > 0 && p[k].bonePresent[i] && p[k].coeffCount[i * 6 + a] != SGE_AXIS_ABSENT) pf.nonRootTranslation |= 1u << k;
+        }
+    }
     pf.coeffs = c->dCoeffs.as<float>();
     pf.coeffCount = c->dCoeffCount.as<uint8_t>();
     pf.bonePresent = c->dBonePresent.as<uint8_t>();
-    return SGE_OK;
+    return rebuildPoseSlots(c);
 }
 
 // ---- skinned mesh ----------------------------------------------------------------
@@ -684,7 +762,47 @@ int sge_skinned_mesh_buffers(sge_context* c, void** p, void** n, void** t, void*
 
 int sge_crowd_buffers(sge_context* c, void** pal, void** op, void** on, void** ot) {
     if (!c || c->crowd.count == 0) { set_error("no characters"); return SGE_ERR_STATE; }
-    if (pal) *pal = c->dPalettes[c->palRead].p; if (op) *op = c->dOutPos.p; if (on) *on = c->dOutNrm.p; if (ot) *ot = c->dOutTan.p;
+    if (pal) *pal = c->dPalettes[c->palRead].p; // the buffer the newest pose stage wrote (and the newest skin launch reads)
+    if (op) *op = c->dOutPos.p; if (on) *on = c->dOutNrm.p; if (ot) *ot = c->dOutTan.p;
+    return SGE_OK;
+}
+
+int sge_crowd_palette_buffers(sge_context* c, void** d_palettes, int32_t* latest) {
+    if (!c || !d_palettes) return SGE_ERR_INVALID;
+    if (c->crowd.count == 0) { set_error("no characters"); return SGE_ERR_STATE; }
+    d_palettes[0] = c->dPalettes[0].p; d_palettes[1] = c->dPalettes[1].p;
+    if (latest) *latest = c->palRead;
+    return SGE_OK;
+}
+
+// The other direction of sge_skin_wait: a consumer that reads the skinned streams on a stream of its own (asynchronously, no host
+// synchronisation) must have finished before the NEXT skin launch overwrites them — in the reference the single command buffer per
+// frame gives that for free (Renderer.swift:159, 224). Orders every later skin / refit launch of the context behind what
+// `consumer_stream` holds so far.
+int sge_skin_consumed(sge_context* c, void* consumer_stream) {
+    if (!c) return SGE_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    hipStream_t s = consumer_stream ? reinterpret_cast<hipStream_t>(consumer_stream) : c->stream;
+    if (s == c->stream && !c->overlapSkin) return SGE_OK; // same stream, serial order: already ordered
+    SGE_HIP(hipEventRecord(c->evConsumed, s));
+    if (c->skinStream) SGE_HIP(hipStreamWaitEvent(c->skinStream, c->evConsumed, 0));
+    if (s != c->stream) SGE_HIP(hipStreamWaitEvent(c->stream, c->evConsumed, 0));
+    return SGE_OK;
+}
+
+// RTSkinningEncoder.encode enqueues on the CALLER's command buffer and what is enqueued behind it sees the skinned streams
+// (RTSkinningEncoder.swift:27-56, RayTracingScene.swift:35-43). Under SGE_OPT_OVERLAP_SKIN the skin stage of sge_tick runs on the
+// context's second stream: this is the ordering primitive that gives a consumer the same guarantee.
+int sge_skin_wait(sge_context* c, void* consumer_stream) {
+    if (!c) return SGE_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    hipStream_t s = consumer_stream ? reinterpret_cast<hipStream_t>(consumer_stream) : c->stream;
+    if (s == c->stream) return joinSkin(c);
+    // launches on the skin stream complete in order: the newest one's event covers them all
+    if (c->skinPending[0] || c->skinPending[1]) SGE_HIP(hipStreamWaitEvent(s, c->evSkinDone[c->lastSkin], 0));
+    // and whatever the context has enqueued on its main stream so far (a serial skin stage, pose, move)
+    SGE_HIP(hipEventRecord(c->evMainMark, c->stream));
+    SGE_HIP(hipStreamWaitEvent(s, c->evMainMark, 0));
     return SGE_OK;
 }
 
@@ -1038,7 +1156,7 @@ int sge_characters_resize(sge_context* c, int32_t count) {
     SGE_ZALLOC(c->dHint, N);
     SGE_ZALLOC(c->dHeavyFlags, N);
     SGE_ZALLOC(c->dLists, 2 * N * sizeof(int));
-    SGE_ZALLOC(c->dListCounts, 2 * sizeof(int));
+    SGE_ZALLOC(c->dListCounts, 4 * sizeof(int));
     SGE_ZALLOC(c->dOrderHist, 64 * sizeof(int));
     if (c->storePoseDebug) { SGE_ZALLOC(c->dPoseModel, N * B * 64); SGE_ZALLOC(c->dPoseLocal, N * B * 64); }
 #undef SGE_ZALLOC
@@ -1146,7 +1264,15 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         MoveLaunch L{c->crowd, c->col, c->agents, d->dt, d->gravity[0], d->gravity[1], d->gravity[2], st, first, count,
                      c->dStats.as<unsigned long long>(), c->dMoveScratch.p, c->dPlatforms.as<sge_platform_state>(), c->platformCount,
                      c->dCost.as<int>(), getenv("SGE_NO_SPEC") ? nullptr : c->dHint.as<uint8_t>(), c->dLists.as<int>(), c->dListCounts.as<int>(), c->dHeavyFlags.as<uint8_t>(),
-                     c->heavyThreshold, c->heavyCap, c->heavyStream, c->evClassified, c->evHeavyDone, nullptr, nullptr, nullptr, nullptr, c->dOrderHist.as<int>(), nullptr};
+                     c->heavyThreshold, c->heavyCap, c->heavyStream, c->evClassified, c->evHeavyDone, c->hHeavyDemand, nullptr, nullptr, nullptr, nullptr, c->dOrderHist.as<int>(), nullptr};
+        // Grid of the multi-wave launch: the characters that asked for it in the newest step whose count has reached the host
+        // (+ 50 % + 8), not the cap — every workgroup of that grid, the ones beyond the list included, has to find a CU with two
+        // free places per SIMD. The list is cut to the grid (classify_kernel); whoever does not fit stays with the grouped launch,
+        // which gives the same result. -1: nothing has come back yet.
+        if (c->hHeavyDemand) {
+            const int demand = *(volatile int*)c->hHeavyDemand;
+            if (demand >= 0) L.heavyCap = std::min(c->heavyCap, demand + demand / 2 + 8);
+        }
         if (c->waveProfOn) {
             if (c->dWaveProf.alloc((size_t)c->crowd.count * 3 * 64) != SGE_OK) return SGE_ERR_DEVICE;
             SGE_HIP(hipMemsetAsync(c->dWaveProf.p, 0, (size_t)c->crowd.count * 3 * 64, c->stream));
@@ -1169,7 +1295,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
     if (st & (SGE_STAGE_LOCOMOTION | SGE_STAGE_ACTION | SGE_STAGE_POSE | SGE_STAGE_WRITEBACK)) {
         if ((st & SGE_STAGE_POSE) && (c->boneCount == 0 || c->prof.count == 0)) { set_error("pose stage needs a skeleton and motion profiles"); return SGE_ERR_STATE; }
         if (st & SGE_STAGE_POSE) {
-            const bool flip = c->overlapSkin && !c->customStream && first == 0 && count == c->crowd.count;
+            const bool flip = c->overlapSkin && first == 0 && count == c->crowd.count;
             if (flip) { // write the buffer no skin launch newer than skin(n-1) reads
                 const int f = c->palRead ^ 1;
                 if (c->skinPending[f]) { SGE_HIP(hipStreamWaitEvent(c->stream, c->evSkinDone[f], 0)); c->skinPending[f] = false; }
@@ -1196,7 +1322,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
                      c->crowd.palettes + (size_t)first * c->boneCount * 16, c->boneCount, c->mesh.vertexCount, count,
                      (long long)first * c->mesh.vertexCount, SGE_LAYOUT_PACKED, c->skinLayout, c->dOutPos.p, c->dOutNrm.p, c->dOutTan.p};
         hipStream_t ss = c->stream;
-        const bool overlap = c->overlapSkin && !c->customStream;
+        const bool overlap = c->overlapSkin;
         if (overlap) {
             // skin(n) on its own stream after pose(n) (and, stream order, after skin(n-1)); move(n+1) and pose(n+1) may run on
             // the main stream meanwhile
@@ -1228,7 +1354,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
                 if (rc != SGE_OK) return rc;
             }
         }
-        if (overlap) { SGE_HIP(hipEventRecord(c->evSkinDone[c->palRead], c->skinStream)); c->skinPending[c->palRead] = true; }
+        if (overlap) { SGE_HIP(hipEventRecord(c->evSkinDone[c->palRead], c->skinStream)); c->skinPending[c->palRead] = true; c->lastSkin = c->palRead; }
     } else if (st & SGE_STAGE_BLAS_REFIT) {
         int rc = sge_blas_refit(c, first, count);
         if (rc != SGE_OK) return rc;

@@ -2155,6 +2155,9 @@ __device__ __forceinline__ void groupGather(const DevCollision& col, int rb, int
 template <bool AGENTS>
 __global__ __launch_bounds__(kWave, SGE_CCD_EXCLUSIVE ? 2 : SGE_GROUP_WAVES) void move_group_kernel(MoveLaunch K) {
     SGE_PAD_VGPRS();
+#ifdef SGE_GROUP_TAIL_PRIO // experiment: issue priority for the launch's first wavefronts only (they hold the most expensive characters)
+    if ((int)blockIdx.x * SGE_GROUP_TAIL_PRIO < (int)gridDim.x) __builtin_amdgcn_s_setprio(3);
+#endif
     const int lane = laneId();
     WaveStats st{0, 0, 0, 0, 0, 0, 0};
     const DevCollision& col = K.col;
@@ -2647,6 +2650,7 @@ __global__ void classify_kernel(const int* cost, int first, int count, int thres
         const int e = first + i;
         uint8_t heavy = 0;
         if (threshold >= 0 && cost[e] > threshold) {
+            atomicAdd(&counts[2], 1); // demand, whatever the cap: sizes the multi-wave grid of the coming steps (sge_tick)
             int pos = atomicAdd(&counts[1], 1);
             if (pos < heavyCap) { lists[count + pos] = e; heavy = 1; }
             else atomicSub(&counts[1], 1);
@@ -2703,32 +2707,42 @@ void launch_move(const MoveLaunch& L, hipStream_t s) {
     const int groups = (L.count + kGroup - 1) / kGroup;
     const int blocks = (L.count + 255) / 256;
     // last step's costs -> heavy list (multi-wave launch) + order list of everybody else (grouped launch)
-    (void)hipMemsetAsync(L.listCounts, 0, 2 * sizeof(int), s);
+    (void)hipMemsetAsync(L.listCounts, 0, 4 * sizeof(int), s);
     hipLaunchKernelGGL(classify_kernel, dim3(blocks), dim3(256), 0, s, L.cost, L.first, L.count, L.heavyThreshold, L.heavyCap, L.lists,
                        L.listCounts, L.heavyFlags, L.orderHist);
-    MoveLaunch G = L;
-    if (grouped) {
-        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, s, L.orderHist, L.listCounts);
-        hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, s, L.cost, L.first, L.count, L.heavyFlags, L.orderHist, L.lists);
-        G.order = L.lists; G.orderCount = L.listCounts;
-    }
     const bool heavy = L.heavyThreshold >= 0;
-    if (heavy) { // heavy characters first, on their own stream, so that their long single-character sweeps overlap the rest
+    MoveLaunch G = L;
+    // The multi-wave launch goes FIRST and stays on the main stream, right behind the classification: its 512-thread workgroups need
+    // two free wavefront places on every SIMD of one CU at the same moment, which they find while the chip holds nothing but the
+    // skin launch of the previous step — and do not find for several hundred microseconds once the one-wave workgroups of the
+    // grouped launch have taken every place that comes free (beside resident LBS workgroups the move stage took 0.94 ms instead of
+    // 0.52 for exactly this reason). So the grouped launch and its two ordering kernels run on the second stream,
+    // behind an event: the cross-stream hand-over is what gives the multi-wave workgroups their head start.
+    hipStream_t gs = heavy ? L.heavyStream : s;
+    if (heavy) {
         (void)hipEventRecord(L.evClassified, s);
-        (void)hipStreamWaitEvent(L.heavyStream, L.evClassified, 0);
         MoveLaunch H = L;
         H.list = L.lists + L.count; H.listCount = L.listCounts + 1;
         const int heavyGrid = L.count < L.heavyCap ? L.count : L.heavyCap;
-        if (agents) hipLaunchKernelGGL((move_kernel<1, true, true>), dim3(heavyGrid), dim3(kWave * kHeavyWaves), 0, L.heavyStream, H);
-        else hipLaunchKernelGGL((move_kernel<1, false, true>), dim3(heavyGrid), dim3(kWave * kHeavyWaves), 0, L.heavyStream, H);
-        (void)hipEventRecord(L.evHeavyDone, L.heavyStream);
+        if (agents) hipLaunchKernelGGL((move_kernel<1, true, true>), dim3(heavyGrid), dim3(kWave * kHeavyWaves), 0, s, H);
+        else hipLaunchKernelGGL((move_kernel<1, false, true>), dim3(heavyGrid), dim3(kWave * kHeavyWaves), 0, s, H);
+        (void)hipStreamWaitEvent(gs, L.evClassified, 0);
+        // how many characters asked for the multi-wave launch: read by the host when it enqueues a later step (pinned memory)
+        if (L.heavyDemandHost) (void)hipMemcpyAsync(L.heavyDemandHost, L.listCounts + 2, sizeof(int), hipMemcpyDeviceToHost, gs);
     }
-    if (grouped) { // kGroup characters per wavefront, members drawn from the order list
-        if (agents) hipLaunchKernelGGL((move_group_kernel<true>), dim3(groups), dim3(kWave), ldsPad, s, G);
-        else hipLaunchKernelGGL((move_group_kernel<false>), dim3(groups), dim3(kWave), ldsPad, s, G);
-    } else if (agents) hipLaunchKernelGGL((move_kernel<1, true>), dim3(L.count), dim3(kWave), 0, s, L); // skips flagged characters
-    else hipLaunchKernelGGL((move_kernel<1, false>), dim3(L.count), dim3(kWave), ldsPad, s, L);
-    if (heavy) (void)hipStreamWaitEvent(s, L.evHeavyDone, 0);
+    if (grouped) {
+        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, gs, L.orderHist, L.listCounts);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, gs, L.cost, L.first, L.count, L.heavyFlags, L.orderHist, L.lists);
+        G.order = L.lists; G.orderCount = L.listCounts;
+        // kGroup characters per wavefront, members drawn from the order list
+        if (agents) hipLaunchKernelGGL((move_group_kernel<true>), dim3(groups), dim3(kWave), ldsPad, gs, G);
+        else hipLaunchKernelGGL((move_group_kernel<false>), dim3(groups), dim3(kWave), ldsPad, gs, G);
+    } else if (agents) hipLaunchKernelGGL((move_kernel<1, true>), dim3(L.count), dim3(kWave), 0, gs, L); // skips flagged characters
+    else hipLaunchKernelGGL((move_kernel<1, false>), dim3(L.count), dim3(kWave), ldsPad, gs, L);
+    if (heavy) {
+        (void)hipEventRecord(L.evHeavyDone, gs);
+        (void)hipStreamWaitEvent(s, L.evHeavyDone, 0);
+    }
 }
 
 // ---- batched single queries (the CollisionQuery facade) ---------------------

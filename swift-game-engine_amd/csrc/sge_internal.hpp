@@ -51,6 +51,9 @@ struct DevSkeleton {
     const int32_t* depth;       // [B]
     const int32_t* leanChain;   // [leanChainLen]
     const int32_t* path;        // [B][maxDepth + 1]: bone i's ancestors root first, i itself at position depth[i]
+    const int32_t* slotBone;    // [B] the order in which pose_kernel's lanes take the bones: slot s (pass s / 64) is bone slotBone[s]
+    int lastPassStatic;         // 1: no uploaded profile has an entry for any bone of the last pass
+    int extraParentReady;       // 1: the parent of every bone in a pass after the first sits in an earlier pass
     const float* bindLocal;     // [B][12] affine by column
     const float* invBind;       // [B][16] full 4x4 used for the palette (mesh re-bind applied at upload)
     const float* restT;         // [B][3]
@@ -62,6 +65,8 @@ struct DevSkeleton {
 struct DevProfiles {
     int count;
     int stride;                 // floats per (bone,axis) = max coefficient count over everything uploaded
+    int maxOrder;               // largest Fourier order uploaded (selects the kernel instantiation)
+    uint32_t nonRootTranslation; // bit p: profile p carries translation for some bone other than bone 0
     int32_t order[SGE_MAX_PROFILES];
     float cycleRaw[SGE_MAX_PROFILES];
     const float* coeffs;        // [P][B][6][stride]
@@ -219,7 +224,8 @@ struct MoveLaunch {
     int* lists; int* listCounts; // heavy list at lists[count..], its length at listCounts[1] (classify_kernel)
     uint8_t* heavyFlags;         // [crowd.count] 1: taken by the multi-wave launch this step
     int heavyThreshold, heavyCap;
-    hipStream_t heavyStream; hipEvent_t evClassified, evHeavyDone;
+    hipStream_t heavyStream; hipEvent_t evClassified, evHeavyDone; // second stream of the move stage (the grouped launch runs there)
+    int* heavyDemandHost;      // pinned: characters above the threshold in the step last copied back, or null
     const int* list; const int* listCount; // what a part-1 launch iterates over (set by launch_move)
     const int* order; const int* orderCount; // grouped launch: characters sorted by last step's cost (device), its length
     int* orderHist;                        // [64] histogram / cursors of the order list (zero between steps)

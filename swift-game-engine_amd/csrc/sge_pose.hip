@@ -20,34 +20,35 @@
 namespace sge {
 
 constexpr int kWave = 64;
+constexpr int kRow = 13; // floats per bone row of the LDS matrices (12 used)
 
-struct Harmonics { float c[SGE_MAX_FOURIER_ORDER], s[SGE_MAX_FOURIER_ORDER]; };
+// harmonics of one profile at one phase: cos / sin of 2 pi k p for k = 1 .. KMAX (KMAX = the largest order uploaded, 4 or 8)
+template <int KMAX> struct Harmonics { float c[KMAX], s[KMAX]; };
 
 // Animation.swift:68,73 — p = clamp(phase), angle = 2 * Float.pi * Float(k) * p
-__device__ __forceinline__ void harmonics(float phase, int order, Harmonics& h) {
+template <int KMAX>
+__device__ __forceinline__ void harmonics(float phase, int order, Harmonics<KMAX>& h) {
     float p = smax(0.0f, smin(phase, 1.0f));
 #pragma unroll
-    for (int k = 1; k <= SGE_MAX_FOURIER_ORDER; ++k) {
+    for (int k = 1; k <= KMAX; ++k) {
         if (k <= order) {
             float angle = 2 * kSwiftPi * (float)k * p;
-            h.c[k - 1] = cosf(angle);
-            h.s[k - 1] = sinf(angle);
+            sincosf(angle, &h.s[k - 1], &h.c[k - 1]);
         } else {
             h.c[k - 1] = 0.f; h.s[k - 1] = 0.f;
         }
     }
 }
 
-// Animation.swift:66-78
-__device__ __forceinline__ float evalAxis(const float* coeffs, int cnt, int order, const Harmonics& h) {
-    if (cnt <= 0) return 0.0f;
-    float result = coeffs[0];
-    int index = 1;
+// Animation.swift:66-78 on coefficients already in registers. The reference's loop leaves at the first k with k > order or
+// index + 1 >= count (index = 2k - 1): both conditions are monotone in k, so "term k is added" == (k <= order && 2k < count).
+template <int KMAX>
+__device__ __forceinline__ float evalAxis(const float (&cf)[2 * KMAX + 1], int cnt, int order, const Harmonics<KMAX>& h) {
+    float result = cnt > 0 ? cf[0] : 0.0f;
 #pragma unroll
-    for (int k = 1; k <= SGE_MAX_FOURIER_ORDER; ++k) {
-        if (k > order || index + 1 >= cnt) break;
-        result += coeffs[index] * h.c[k - 1] + coeffs[index + 1] * h.s[k - 1];
-        index += 2;
+    for (int k = 1; k <= KMAX; ++k) {
+        const float next = result + (cf[2 * k - 1] * h.c[k - 1] + cf[2 * k] * h.s[k - 1]);
+        result = (k <= order && 2 * k < cnt) ? next : result;
     }
     return result;
 }
@@ -62,46 +63,61 @@ __device__ __forceinline__ void storeAff12(float* p, const Aff& a) {
     p[6] = a.c2.x; p[7] = a.c2.y; p[8] = a.c2.z; p[9] = a.c3.x; p[10] = a.c3.y; p[11] = a.c3.z;
 }
 
-// translation + rotation of bone i under one profile (ProceduralPoseSystem.swift:146-200 / 249-271)
+// translation + rotation of bone i under one profile (ProceduralPoseSystem.swift:146-200 / 249-271).
+// Written without data-dependent branches: every load of the bone (rest pose, pre-rotation, axis counts, the Fourier rows of the
+// three rotation axes) is issued up front and the lanes of a pass go through ONE dependent memory latency instead of one per
+// axis. An axis the profile does not have (or a bone it has no entry for) selects the default instead of skipping the evaluation:
+// raw = rest and degrees = 0, which is exactly what the skipped form computes (delta = 0, R(0) = identity). The translation rows
+// are read only by the root and, when some other bone of the profile carries translation, by everybody (pf.nonRootTranslation).
+// The table is padded by one full row at its end, so reading 2 KMAX + 1 floats of a shorter row stays inside it.
+template <int KMAX>
 __device__ __forceinline__ BoneEval evalBone(const DevSkeleton& sk, const DevProfiles& pf, int prof, int i,
-                                             const Harmonics& h, bool inPlace, const Aff& rootFix) {
-    BoneEval r;
+                                             const Harmonics<KMAX>& h, bool inPlace, const Aff& rootFix) {
+    constexpr int NC = 2 * KMAX + 1;
     const int B = sk.boneCount;
-    F3 restScaled{sk.restT[i * 3], sk.restT[i * 3 + 1], sk.restT[i * 3 + 2]};
-    F3 restRaw{sk.rawRestT[i * 3], sk.rawRestT[i * 3 + 1], sk.rawRestT[i * 3 + 2]};
-    r.present = pf.bonePresent[prof * B + i] != 0;
-    if (!r.present) {
-        // the profile has no entry for this bone: raw = rest and all angles 0, so t = rest and rot = preRot * I
-        // (what the arithmetic below yields as well, without its six trig evaluations)
-        r.t = restScaled;
-        r.rot = loadAff12(sk.preRot + i * 12);
-        if (i == 0) r.rot = affMul(rootFix, r.rot);
-        return r;
-    }
+    const uint8_t* ccp = pf.coeffCount + ((size_t)prof * B + i) * 6;
+    const float* co = pf.coeffs + ((size_t)prof * B + i) * 6 * pf.stride;
+    const bool present = pf.bonePresent[prof * B + i] != 0;
+    int cc[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) cc[a] = ccp[a];
+    float cr[3][NC];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int j = 0; j < NC; ++j) cr[a][j] = co[(3 + a) * pf.stride + j];
+    const F3 restScaled{sk.restT[i * 3], sk.restT[i * 3 + 1], sk.restT[i * 3 + 2]};
+    const F3 restRaw{sk.rawRestT[i * 3], sk.rawRestT[i * 3 + 1], sk.rawRestT[i * 3 + 2]};
+    const Aff preRot = loadAff12(sk.preRot + i * 12);
     const int order = pf.order[prof];
     float raw[3] = {restRaw.x, restRaw.y, restRaw.z};
-    float deg[3] = {0.f, 0.f, 0.f};
-    if (r.present) {
-        const uint8_t* cc = pf.coeffCount + ((size_t)prof * B + i) * 6;
-        const float* co = pf.coeffs + ((size_t)prof * B + i) * 6 * pf.stride;
+    if (i == 0 || ((pf.nonRootTranslation >> prof) & 1u)) {
+        float ct[3][NC];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int j = 0; j < NC; ++j) ct[a][j] = co[a * pf.stride + j];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            int cnt = cc[a];
-            if (cnt != SGE_AXIS_ABSENT) raw[a] = evalAxis(co + a * pf.stride, cnt, order, h);
+            const float v = evalAxis<KMAX>(ct[a], cc[a], order, h);
+            raw[a] = (present && cc[a] != SGE_AXIS_ABSENT) ? v : raw[a];
         }
+    }
+    float deg[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            int cnt = cc[3 + a];
-            if (cnt != SGE_AXIS_ABSENT) deg[a] = evalAxis(co + (3 + a) * pf.stride, cnt, order, h);
-        }
+    for (int a = 0; a < 3; ++a) {
+        const float v = evalAxis<KMAX>(cr[a], cc[3 + a], order, h);
+        deg[a] = (present && cc[3 + a] != SGE_AXIS_ABSENT) ? v : 0.0f;
     }
     F3 delta = F3{raw[0], raw[1], raw[2]} - restRaw;
     F3 t = restScaled + (delta * sk.unitScale);
     if (i == 0 && inPlace) { t.x = restScaled.x; t.z = restScaled.z; }
-    Aff rot = affMul(loadAff12(sk.preRot + i * 12), rotationXYZDegrees(F3{deg[0], deg[1], deg[2]}));
+    Aff rot = affMul(preRot, rotationXYZDegrees(F3{deg[0], deg[1], deg[2]}));
     if (i == 0) rot = affMul(rootFix, rot);
+    BoneEval r;
     r.t = t;
     r.rot = rot;
+    r.present = present;
     return r;
 }
 
@@ -136,15 +152,24 @@ __device__ __forceinline__ int groundedNextState(int current, float speed, const
 #ifndef SGE_POSE_WAVES
 #define SGE_POSE_WAVES 1
 #endif
+// Bones are visited by SLOT: slot s of pass s / 64 is bone sk.slotBone[s]. The host orders the slots so that the bones of the LAST,
+// partly filled pass (bone 65 of the Y-Bot's 65) are ones no uploaded profile animates and whose parents sit in earlier passes
+// (sge_api.hip: rebuildPoseSlots): with sk.lastPassStatic that pass evaluates nothing (pre-rotation and rest translation are the
+// local matrix) and with sk.extraParentReady its model matrices are ONE product with the parent's finished model instead of a walk
+// down the ancestor path. Before, the second pass repeated the whole per-bone chain — loads, six trig evaluations, the path walk —
+// for a single lane: 40 % of the wavefront's time.
+template <int KMAX>
 __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch K) {
-    // local and model matrices of this character's bones, 12 floats each: sized by the launch for the skeleton's bone count
+    // local and model matrices of this character's bones: sized by the launch for the skeleton's bone count
     // (a fixed SGE_MAX_BONES-sized array would cap the CU at 6 workgroups for a 65-bone rig)
+    // (rows of kRow = 13 floats: with 12 the lane stride is a multiple of four banks and every per-lane row access a four-way bank
+    // conflict — SQ_LDS_BANK_CONFLICT was 39 % of SQ_LDS_IDX_ACTIVE, profiles/r2_move_pmc_cheese.json)
     extern __shared__ float sPose[];
 #ifdef SGE_POSE_SETPRIO // experiment: issue priority over the LBS wavefronts on the same SIMD
     __builtin_amdgcn_s_setprio(SGE_POSE_SETPRIO);
 #endif
     float* const sLocal = sPose;
-    float* const sModel = sPose + (size_t)K.sk.boneCount * 12;
+    float* const sModel = sPose + (size_t)K.sk.boneCount * kRow;
     const int e = K.first + blockIdx.x;
     const int lane = threadIdx.x;
     const DevSkeleton& sk = K.sk;
@@ -155,6 +180,11 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
     long long pS[6] = {0, 0, 0, 0, 0, 0};
 #define SGE_POSE_STAMP(k) do { if (K.waveProf) pS[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     SGE_POSE_STAMP(0);
+    // this lane's bones of the first two passes, requested before anything else (their latency hides behind the state machines)
+    const int bone0 = lane < B ? sk.slotBone[lane] : 0;
+    const int bone1 = kWave + lane < B ? sk.slotBone[kWave + lane] : 0;
+    auto boneOfSlot = [&](int s) -> int { return s < kWave ? bone0 : (s < 2 * kWave ? bone1 : sk.slotBone[s]); };
+    const int lastPassFirst = ((B - 1) / kWave) * kWave; // first slot of the last pass
 
     sge_locomotion_state L = K.crowd.locomotion[e];
     sge_action_state A = K.crowd.actions[e];
@@ -221,6 +251,9 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
         if (active) A.flags |= SGE_ACTION_ACTIVE;
         if (exiting) A.flags |= SGE_ACTION_EXITING;
     }
+    // the per-character state is written back as soon as it is final (not at the end of the kernel): 32 dwords per lane that need
+    // not stay in registers across the bone loops
+    if (lane == 0 && (K.stages & SGE_STAGE_ACTION)) K.crowd.actions[e] = A;
 
     SGE_POSE_STAMP(1);
     if (K.stages & SGE_STAGE_POSE) {
@@ -228,6 +261,13 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
         const bool inPlace = (L.flags & SGE_MOTION_IN_PLACE) != 0;
         const Aff rootFix = loadAff12(sk.rootFix);
         float runLeanWeight = 0;
+        // a bone of a static last pass: no profile animates it, its local matrix is pre-rotation + rest translation
+        auto staticLocal = [&](int i) -> Aff {
+            Aff loc = loadAff12(sk.preRot + i * 12);
+            if (i == 0) loc = affMul(rootFix, loc);
+            loc.c3 = F3{sk.restT[i * 3], sk.restT[i * 3 + 1], sk.restT[i * 3 + 2]};
+            return loc;
+        };
 
         if (hasLoco && hasMotion) { // ProceduralPoseSystem.swift:36-223
             float cyc[4];
@@ -256,6 +296,7 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
 #pragma unroll
             for (int s = 0; s < 4; ++s) phase4[s] = smax(0.0f, smin(L.time[s] / cyc[s], 1.0f));
             L.posePhase = at4(phase4, L.state & 3);
+            if (lane == 0) K.crowd.locomotion[e] = L;
 
             const int fromState = (isBlending ? L.fromState : L.state) & 3;
             const int toState = L.state & 3;
@@ -280,27 +321,42 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
             runLeanWeight = runWeight;
 
             const int fromProf = at4(L.profile, fromState), toProf = at4(L.profile, toState);
-            Harmonics hTo, hFrom;
-            harmonics(at4(phase4, toState), pf.order[toProf], hTo);
+            Harmonics<KMAX> hTo, hFrom;
+            harmonics<KMAX>(at4(phase4, toState), pf.order[toProf], hTo);
             const bool sameEval = fromState == toState;
-            if (!sameEval) harmonics(at4(phase4, fromState), pf.order[fromProf], hFrom);
-            for (int i = lane; i < B; i += kWave) {
-                BoneEval to = evalBone(sk, pf, toProf, i, hTo, inPlace, rootFix);
+            if (!sameEval) harmonics<KMAX>(at4(phase4, fromState), pf.order[fromProf], hFrom);
+            for (int s = lane; s < B; s += kWave) {
+                const int i = boneOfSlot(s);
+                if (sk.lastPassStatic && s >= lastPassFirst) {
+                    // lerp(t, t) and slerp(q, q): the reference's matrix -> quaternion -> matrix round trip only re-rounds (~1e-7)
+                    storeAff12(sLocal + i * kRow, staticLocal(i));
+                    continue;
+                }
+                BoneEval to = evalBone<KMAX>(sk, pf, toProf, i, hTo, inPlace, rootFix);
                 if (sameEval && !isBlending) {
                     // one profile, no blend: lerp(t, t) = t and slerp(q, q) = q. The reference still goes matrix ->
                     // quaternion -> slerp -> matrix, which only re-rounds the rotation (~1e-7); skip the round trip.
                     Aff loc = to.rot;
                     loc.c3 = to.t;
-                    storeAff12(sLocal + i * 12, loc);
+                    storeAff12(sLocal + i * kRow, loc);
                     continue;
                 }
-                BoneEval from = sameEval ? to : evalBone(sk, pf, fromProf, i, hFrom, inPlace, rootFix);
-                F3 t = from.t + (to.t - from.t) * weightTo;
-                Quat fromQuat = quatFromRotation(from.rot);
-                Quat toQuat = quatFromRotation(to.rot);
+                // (the matrices die as soon as their quaternions exist: two bone evaluations never hold registers together)
+                const Quat toQuat = quatFromRotation(to.rot);
+                const F3 toT = to.t;
+                Quat fromQuat = toQuat;
+                F3 fromT = toT;
+                float yawX = to.rot.c2.x, yawZ = to.rot.c2.z; // of the FROM rotation (:210)
+                if (!sameEval) {
+                    BoneEval from = evalBone<KMAX>(sk, pf, fromProf, i, hFrom, inPlace, rootFix);
+                    fromQuat = quatFromRotation(from.rot);
+                    fromT = from.t;
+                    yawX = from.rot.c2.x; yawZ = from.rot.c2.z;
+                }
+                F3 t = fromT + (toT - fromT) * weightTo;
                 Quat rotQuat;
                 if (i == 0 && isBlending) { // yaw-stable root, :206-215
-                    float yaw = atan2f(from.rot.c2.x, from.rot.c2.z);
+                    const float yaw = atan2f(yawX, yawZ);
                     Quat yawQuat = quatAngleAxis(yaw, F3{0, 1, 0});
                     Quat fromPR = quatMul(quatInverse(yawQuat), fromQuat);
                     Quat toPR = quatMul(quatInverse(yawQuat), toQuat);
@@ -310,7 +366,7 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
                 }
                 Aff loc = rotationFromQuat(rotQuat);
                 loc.c3 = t;
-                storeAff12(sLocal + i * 12, loc);
+                storeAff12(sLocal + i * kRow, loc);
             }
         } else if (hasMotion) { // :224-276
             const int prof = L.motionProfile;
@@ -319,17 +375,23 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
             L.motionTime = loop ? fmodf(L.motionTime, cycle) : smin(L.motionTime, cycle);
             float phase = smax(0.0f, smin(L.motionTime / cycle, 1.0f));
             L.posePhase = phase;
-            Harmonics h;
-            harmonics(phase, pf.order[prof], h);
-            for (int i = lane; i < B; i += kWave) {
-                BoneEval ev = evalBone(sk, pf, prof, i, h, inPlace, rootFix);
+            if (lane == 0) K.crowd.locomotion[e] = L;
+            Harmonics<KMAX> h;
+            harmonics<KMAX>(phase, pf.order[prof], h);
+            for (int s = lane; s < B; s += kWave) {
+                const int i = boneOfSlot(s);
+                if (sk.lastPassStatic && s >= lastPassFirst) { // no entry in any profile: bindLocal (:265-270)
+                    storeAff12(sLocal + i * kRow, loadAff12(sk.bindLocal + i * 12));
+                    continue;
+                }
+                BoneEval ev = evalBone<KMAX>(sk, pf, prof, i, h, inPlace, rootFix);
                 Aff loc = ev.rot;
                 loc.c3 = ev.t;
                 if (!ev.present) loc = loadAff12(sk.bindLocal + i * 12);
-                storeAff12(sLocal + i * 12, loc);
+                storeAff12(sLocal + i * kRow, loc);
             }
         } else { // :277-284
-            for (int i = lane; i < B; i += kWave) storeAff12(sLocal + i * 12, loadAff12(sk.bindLocal + i * 12));
+            for (int i = lane; i < B; i += kWave) storeAff12(sLocal + i * kRow, loadAff12(sk.bindLocal + i * 12));
         }
         __syncthreads();
         SGE_POSE_STAMP(2);
@@ -339,23 +401,29 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
             const int prof = A.profile;
             float cycle = cycleOf(pf, prof);
             float phase = smax(0.0f, smin(A.time / cycle, 1.0f));
-            Harmonics h;
-            harmonics(phase, pf.order[prof], h);
+            Harmonics<KMAX> h;
+            harmonics<KMAX>(phase, pf.order[prof], h);
             float wgt = smax(0.0f, smin(A.weight, 1.0f));
             float iw = 1 - wgt;
             runLeanWeight *= iw;
             const bool actInPlace = (A.flags & SGE_ACTION_IN_PLACE) != 0;
-            for (int i = lane; i < B; i += kWave) {
-                BoneEval ev = evalBone(sk, pf, prof, i, h, actInPlace, rootFix);
-                Aff act = ev.rot;
-                act.c3 = ev.t;
-                if (!ev.present) act = loadAff12(sk.bindLocal + i * 12);
-                Aff base = loadAff12(sLocal + i * 12);
+            for (int s = lane; s < B; s += kWave) {
+                const int i = boneOfSlot(s);
+                Aff act;
+                if (sk.lastPassStatic && s >= lastPassFirst) {
+                    act = loadAff12(sk.bindLocal + i * 12);
+                } else {
+                    BoneEval ev = evalBone<KMAX>(sk, pf, prof, i, h, actInPlace, rootFix);
+                    act = ev.rot;
+                    act.c3 = ev.t;
+                    if (!ev.present) act = loadAff12(sk.bindLocal + i * 12);
+                }
+                Aff base = loadAff12(sLocal + i * kRow);
                 F3 t = base.c3 + (act.c3 - base.c3) * wgt;
                 Quat q = quatSlerp(quatFromRotation(base), quatFromRotation(act), wgt);
                 Aff loc = rotationFromQuat(q);
                 loc.c3 = t;
-                storeAff12(sLocal + i * 12, loc);
+                storeAff12(sLocal + i * kRow, loc);
             }
             __syncthreads();
         }
@@ -380,16 +448,16 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
                 alignQuat = quatAngleAxis(angle, right);
             }
             if (lane == 0) {
-                Aff p = affMul(rotationFromQuat(alignQuat), loadAff12(sLocal + sk.pelvisIndex * 12));
-                storeAff12(sLocal + sk.pelvisIndex * 12, p);
+                Aff p = affMul(rotationFromQuat(alignQuat), loadAff12(sLocal + sk.pelvisIndex * kRow));
+                storeAff12(sLocal + sk.pelvisIndex * kRow, p);
             }
             __syncthreads();
             if (runLeanWeight > 0.001f && sk.leanIndex >= 0) {
                 // model[leanIndex] needs only the ancestor chain of leanIndex (Skeleton.swift:189-203)
-                Aff m = loadAff12(sLocal + sk.leanChain[0] * 12), parentModel = m;
+                Aff m = loadAff12(sLocal + sk.leanChain[0] * kRow), parentModel = m;
                 for (int k = 1; k < sk.leanChainLen; ++k) {
                     parentModel = m;
-                    m = affMul(m, loadAff12(sLocal + sk.leanChain[k] * 12));
+                    m = affMul(m, loadAff12(sLocal + sk.leanChain[k] * kRow));
                 }
                 F3 rightWorld = normalize(m.c0);
                 F3 rightLocal = rightWorld;
@@ -401,8 +469,8 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
                 Quat leanQuat = quatAngleAxis(leanAngle, rightLocal);
                 __syncthreads();
                 if (lane == 0) {
-                    Aff l = affMul(rotationFromQuat(leanQuat), loadAff12(sLocal + sk.leanIndex * 12));
-                    storeAff12(sLocal + sk.leanIndex * 12, l);
+                    Aff l = affMul(rotationFromQuat(leanQuat), loadAff12(sLocal + sk.leanIndex * kRow));
+                    storeAff12(sLocal + sk.leanIndex * kRow, l);
                 }
                 __syncthreads();
             }
@@ -412,22 +480,32 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
         // ---- model transforms, then the palette :396-402 ----
         // model[i] = model[parent] * local[i] unrolls to local[root] * ... * local[i] multiplied left to right; every lane
         // walks its own bone's ancestor path in that order (the same sequence of products, hence the same bits, as the
-        // reference's parent-before-child loop) — no level-by-level barriers.
+        // reference's parent-before-child loop) — no level-by-level barriers. A bone of a later pass whose parent's model is
+        // finished (sk.extraParentReady) takes the reference's own form instead: one product with model[parent].
         {
             const int stride = sk.maxDepth + 1;
-            for (int i = lane; i < B; i += kWave) {
-                const int32_t* pth = sk.path + (size_t)i * stride;
-                const int dep = sk.depth[i];
-                Aff mod = loadAff12(sLocal + pth[0] * 12);
-                for (int k = 1; k <= dep; ++k) mod = affMul(mod, loadAff12(sLocal + pth[k] * 12));
-                storeAff12(sModel + i * 12, mod);
+            for (int s = lane; s - lane < B; s += kWave) { // (uniform trip count: the barrier below is inside the loop)
+                if (s < B) {
+                    const int i = boneOfSlot(s);
+                    Aff mod;
+                    if (s >= kWave && sk.extraParentReady) {
+                        mod = affMul(loadAff12(sModel + sk.parent[i] * kRow), loadAff12(sLocal + i * kRow));
+                    } else {
+                        const int32_t* pth = sk.path + (size_t)i * stride;
+                        const int dep = sk.depth[i];
+                        mod = loadAff12(sLocal + pth[0] * kRow);
+                        for (int k = 1; k <= dep; ++k) mod = affMul(mod, loadAff12(sLocal + pth[k] * kRow));
+                    }
+                    storeAff12(sModel + i * kRow, mod);
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
         SGE_POSE_STAMP(4);
         float* pal = K.crowd.palettes + ((size_t)e * B) * 16;
-        for (int i = lane; i < B; i += kWave) {
-            Aff M = loadAff12(sModel + i * 12);
+        for (int s = lane; s < B; s += kWave) {
+            const int i = boneOfSlot(s);
+            Aff M = loadAff12(sModel + i * kRow);
             const float* ib = sk.invBind + i * 16;
             float4* out = reinterpret_cast<float4*>(pal + i * 16);
 #pragma unroll
@@ -440,7 +518,7 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
             if (K.crowd.poseModel) {
                 float* dm = K.crowd.poseModel + ((size_t)e * B + i) * 16;
                 float* dl = K.crowd.poseLocal + ((size_t)e * B + i) * 16;
-                Aff Lc = loadAff12(sLocal + i * 12);
+                Aff Lc = loadAff12(sLocal + i * kRow);
                 const F3 mc[4] = {M.c0, M.c1, M.c2, M.c3}, lc[4] = {Lc.c0, Lc.c1, Lc.c2, Lc.c3};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -460,8 +538,9 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
     }
 #undef SGE_POSE_STAMP
     if (lane == 0) {
-        if (K.stages & (SGE_STAGE_LOCOMOTION | SGE_STAGE_POSE)) K.crowd.locomotion[e] = L;
-        if (K.stages & SGE_STAGE_ACTION) K.crowd.actions[e] = A;
+        // (a pose stage with a motion profile has already stored the state, at the point where the clocks were advanced)
+        const bool storedByPose = (K.stages & SGE_STAGE_POSE) && hasMotion;
+        if ((K.stages & (SGE_STAGE_LOCOMOTION | SGE_STAGE_POSE)) && !storedByPose) K.crowd.locomotion[e] = L;
         if (K.stages & SGE_STAGE_WRITEBACK) {
             sge_body_state& b = K.crowd.bodies[e];
 #pragma unroll
@@ -472,7 +551,9 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
 
 void launch_pose(const PoseLaunch& L, hipStream_t s) {
     if (L.count <= 0) return;
-    hipLaunchKernelGGL(pose_kernel, dim3(L.count), dim3(kWave), (size_t)L.sk.boneCount * 12 * 2 * sizeof(float), s, L);
+    const size_t lds = (size_t)L.sk.boneCount * kRow * 2 * sizeof(float);
+    if (L.prof.maxOrder <= 4) hipLaunchKernelGGL(pose_kernel<4>, dim3(L.count), dim3(kWave), lds, s, L);
+    else hipLaunchKernelGGL(pose_kernel<SGE_MAX_FOURIER_ORDER>, dim3(L.count), dim3(kWave), lds, s, L);
 }
 
 } // namespace sge

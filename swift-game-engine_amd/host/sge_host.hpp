@@ -207,6 +207,12 @@ public:
     }
     // the crowd path: one job per character over the shared source mesh, palettes from the pose stage
     void encodeCrowd(float dt = 0.0f) { world_->tick(dt, SGE_STAGE_SKIN); }
+    // What the reference gets from enqueueing on the same command buffer (RayTracingScene.swift:35-43): `consumer` (a hipStream_t;
+    // nullptr = the context's stream) sees the skinned streams of every encode / tick so far. Needed under SGE_OPT_OVERLAP_SKIN,
+    // where the skin stage runs on the context's second stream; harmless otherwise.
+    void waitForSkinning(void* consumer = nullptr) { check(sge_skin_wait(world_->context(), consumer), "sge_skin_wait"); }
+    // ... and the reverse: what `consumer` holds so far completes before the next skin launch overwrites the streams
+    void skinningConsumed(void* consumer = nullptr) { check(sge_skin_consumed(world_->context(), consumer), "sge_skin_consumed"); }
 
 private:
     explicit RTSkinningEncoder(World& w) : world_(&w) {}

@@ -37,8 +37,20 @@ public final class RTSkinningEncoder {
                                         outputStride16 ? Int32(SGE_LAYOUT_PADDED16) : Int32(SGE_LAYOUT_PACKED), &descs, Int32(descs.count)))
     }
 
+    /// What enqueueing behind `encode` on the same MTLCommandBuffer gives the reference (RayTracingScene.swift:35-43): `consumer` (a
+    /// hipStream_t, nil = the context's stream) is ordered behind every skin launch so far. Needed under SGE_OPT_OVERLAP_SKIN.
+    public func waitForSkinning(consumer: UnsafeMutableRawPointer? = nil) {
+        crowd.check(sge_skin_wait(crowd.ctx, consumer))
+    }
+
+    /// ... and the reverse: what `consumer` holds so far completes before the next skin launch overwrites the streams.
+    public func skinningConsumed(consumer: UnsafeMutableRawPointer? = nil) {
+        crowd.check(sge_skin_consumed(crowd.ctx, consumer))
+    }
+
     /// RTGeometryCache.makeSkinningJob (:492-576) for character `index` of the crowd over the context's own buffers: the source streams
-    /// uploaded once, the palette the pose stage wrote (no per-frame makeBuffer + memcpy, :556-566), destination = running vertex offset
+    /// uploaded once, the palette the pose stage wrote (no per-frame makeBuffer + memcpy, :556-566), destination = running vertex offset.
+    /// Build the jobs every frame, as the reference does: under SGE_OPT_OVERLAP_SKIN the palettes alternate between two buffers.
     public func makeSkinningJob(characterIndex index: Int, vertexCount: Int) -> RTSkinningJob? {
         var pal: UnsafeMutableRawPointer?, op: UnsafeMutableRawPointer?, on: UnsafeMutableRawPointer?, ot: UnsafeMutableRawPointer?
         var sp: UnsafeMutableRawPointer?, sn: UnsafeMutableRawPointer?, st: UnsafeMutableRawPointer?, si: UnsafeMutableRawPointer?, sw: UnsafeMutableRawPointer?

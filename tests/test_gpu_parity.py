@@ -1041,3 +1041,150 @@ def test_full_size_kernel_paths_agree_on_the_real_scene(sge):
     assert_struct_equal(base["controllers"][pick], c["controllers"], "controllers(subset vs oracle)")
     cpu.close()
 
+
+
+def _strided_checksums(eng, n, V, stride=97):
+    """Order-independent integer checksums over every `stride`-th character's three skinned streams (bit patterns summed)."""
+    sums = np.zeros(3, np.uint64)
+    for c in range(0, n, stride):
+        for k, a in enumerate(eng.skinned(first_vertex=c * V, vertex_count=V)):
+            sums[k] += np.ascontiguousarray(a).view(np.uint32).astype(np.uint64).sum()
+    return sums
+
+
+def test_bench_default_full_size(sge):
+    """The combination bench.py times, as one test: SGE_OPT_OVERLAP_SKIN on, every stage including skin, 10,000 characters x 14,080
+    vertices on the 17-Cheese mesh (BASELINE.json configs[2]) — the two-stream, two-palette-buffer schedule at full size. Checked
+    against (1) an oracle run over a subset (random characters + the expensive ones at the rim): bodies / controllers bit-exact,
+    palettes and the skinned vertices of three subset characters <= 1e-5; (2) the same crowd stepped in serial order
+    (overlap off): every state array and the strided checksums of the three output streams identical."""
+    abi = sge.abi
+    ybot = sge.assets.YBotAssets()
+    n, settle, steps = 10000, 40, 60
+
+    def run(overlap):
+        eng = sge.CharacterEngine(0)
+        eng.set_option(abi.OPT_OVERLAP_SKIN, 1 if overlap else 0)
+        sge.crowd.upload_character_assets(eng, ybot)
+        scene = sge.crowd.upload_asset_scene(eng, ("cheese",))
+        state0 = sge.crowd.spawn_crowd(eng, ybot, n, scene)
+        for _ in range(settle + steps):
+            eng.tick()
+        eng.synchronize()
+        return eng, state0
+
+    gpu, state0 = run(True)
+    V, B = gpu.vertex_count, gpu.bone_count
+    assert V == 14080
+    out = gpu.download()
+    assert gpu.move_stats().overflow == 0
+    sums = _strided_checksums(gpu, n, V)
+    rng = np.random.default_rng(5)
+    rim = np.argsort(-np.abs(out["bodies"]["position"][:, 0]))  # characters near the rim of the cheese are the expensive ones
+    pick = np.sort(np.unique(np.concatenate([rng.choice(n, 48, replace=False), rim[:24]])))
+    assert len(pick) >= 64
+    pal = np.stack([gpu.palettes(int(c), 1)[0][0] for c in pick])
+    skinned = {int(c): [a.copy() for a in gpu.skinned(first_vertex=int(c) * V, vertex_count=V)] for c in (pick[0], pick[len(pick) // 2], pick[-1])}
+    gpu.close()
+
+    # (2) serial order
+    ser, _ = run(False)
+    other = ser.download()
+    for k in ("bodies", "controllers", "locomotion", "actions"):
+        assert_struct_equal(out[k], other[k], "%s (overlap vs serial order)" % k)
+    assert np.array_equal(sums, _strided_checksums(ser, n, V))
+    ser.close()
+
+    # (1) oracle over the subset
+    cpu = ob.oracle_engine()
+    sge.crowd.upload_character_assets(cpu, ybot)
+    sge.crowd.upload_asset_scene(cpu, ("cheese",))
+    cpu.resize(len(pick))
+    cpu.upload(**{k: v[pick] for k, v in state0.items()})
+    for _ in range(settle + steps):
+        ob.tick_mt(cpu, 8)
+    c = cpu.download()
+    assert_struct_equal(out["bodies"][pick], c["bodies"], "bodies(subset vs oracle)")
+    assert_struct_equal(out["controllers"][pick], c["controllers"], "controllers(subset vs oracle)")
+    cpal = cpu.palettes(0, len(pick))[0]
+    assert np.abs(pal - cpal).max() <= REL * np.abs(cpal).max()
+    for j, cidx in ((0, int(pick[0])), (len(pick) // 2, int(pick[len(pick) // 2])), (len(pick) - 1, int(pick[-1]))):
+        cp, cn, ct = cpu.skinned(first_vertex=j * V, vertex_count=V)
+        gp, gn, gt = skinned[cidx]
+        assert np.abs(gp - cp).max() <= REL * np.abs(cp).max()
+        assert np.abs(gn - cn).max() <= 2e-5 and np.abs(gt - ct).max() <= 2e-5
+    cpu.close()
+
+
+def test_overlap_on_a_caller_stream_with_a_consumer(sge):
+    """SGE_OPT_OVERLAP_SKIN behind the reference's calling convention: RTSkinningEncoder.encode enqueues on the CALLER's command
+    buffer and the consumer enqueued right behind it sees the skinned vertices (RTSkinningEncoder.swift:27-56,
+    RayTracingScene.swift:35-43). Here the context runs on a caller-provided stream with the overlap option on; after every tick a
+    consumer on a SECOND caller stream orders itself with sge_skin_wait, copies the position stream (device to device) and hands
+    the streams back with sge_skin_consumed — no host synchronisation anywhere in the loop. Every copy must be exactly that step's positions as a serial-order context produces
+    them. Also: the palette pointer alternates between the two buffers sge_crowd_palette_buffers reports, and jobs built from
+    the freshly queried pointer after two more ticks re-skin the crowd to the same streams (advisor finding, round 2)."""
+    import torch
+
+    A = sge.abi
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    ybot = sge.assets.YBotAssets()
+    n, steps = 1500, 6
+
+    def make(overlap):
+        eng = sge.CharacterEngine(0)
+        eng.set_option(A.OPT_OVERLAP_SKIN, 1 if overlap else 0)
+        sge.crowd.upload_character_assets(eng, ybot)
+        terrain = sge.crowd.upload_terrain(eng)
+        sge.crowd.spawn_crowd(eng, ybot, n, terrain, seed=31, mode="ccd", mixed=True)
+        return eng
+
+    ser = make(False)
+    V, B = ser.vertex_count, ser.bone_count
+    expect = []
+    for _ in range(steps):
+        ser.tick()
+        expect.append(ser.skinned()[0].copy())
+    ser.close()
+
+    gpu = make(True)
+    lib, h = gpu.t.lib, gpu.h
+    dev = torch.device("cuda", 0)
+    main, consumer = torch.cuda.Stream(device=0), torch.cuda.Stream(device=0)
+    assert lib.sge_context_set_stream(h, C.c_void_p(main.cuda_stream)) == 0
+    snaps = [torch.zeros((n * V, 3), dtype=torch.float32, device=dev) for _ in range(steps)]
+    torch.cuda.synchronize()
+    bufs = (C.c_void_p * 2)()
+    latest = C.c_int32(-1)
+    seen = []
+    for k in range(steps):
+        gpu.tick()
+        pal, op = C.c_void_p(), C.c_void_p()
+        assert lib.sge_crowd_buffers(h, C.byref(pal), C.byref(op), None, None) == 0
+        assert lib.sge_crowd_palette_buffers(h, bufs, C.byref(latest)) == 0
+        assert pal.value == bufs[latest.value]
+        seen.append(latest.value)
+        assert lib.sge_skin_wait(h, C.c_void_p(consumer.cuda_stream)) == 0
+        assert hip.hipMemcpyAsync(C.c_void_p(snaps[k].data_ptr()), op, n * V * 12, 3, C.c_void_p(consumer.cuda_stream)) == 0
+        assert lib.sge_skin_consumed(h, C.c_void_p(consumer.cuda_stream)) == 0  # ... and the next skin launch behind the copy
+    assert seen == [(seen[0] + k) % 2 for k in range(steps)], seen  # a whole-crowd pose stage flips the buffer every tick
+    consumer.synchronize()
+    for k in range(steps):
+        assert np.array_equal(snaps[k].cpu().numpy(), expect[k]), "consumer copy of step %d" % k
+    # jobs from the freshly queried palette pointer: re-skin into scratch buffers on the caller's stream
+    src = [C.c_void_p() for _ in range(5)]
+    assert lib.sge_skinned_mesh_buffers(h, *[C.byref(p) for p in src]) == 0
+    pal = C.c_void_p()
+    assert lib.sge_crowd_buffers(h, C.byref(pal), None, None, None) == 0
+    with torch.cuda.stream(main):
+        scratch = [torch.zeros((n * V, 3), dtype=torch.float32, device=dev), torch.zeros((n * V, 3), dtype=torch.float32, device=dev),
+                   torch.zeros((n * V, 4), dtype=torch.float32, device=dev)]
+    jobs = [dict(sourcePositions=src[0].value, sourceNormals=src[1].value, sourceTangents=src[2].value, sourceBoneIndices=src[3].value,
+                 sourceBoneWeights=src[4].value, palette=pal.value + c * B * 64, paletteCount=B, vertexCount=V, dstBaseVertex=c * V)
+            for c in range(n)]
+    gpu.skinning_encode(scratch[0].data_ptr(), scratch[1].data_ptr(), scratch[2].data_ptr(), A.LAYOUT_PACKED, jobs)
+    main.synchronize()
+    assert np.abs(scratch[0].cpu().numpy() - expect[-1]).max() <= 1e-6 * np.abs(expect[-1]).max()
+    assert lib.sge_context_set_stream(h, None) == 0
+    gpu.close()
