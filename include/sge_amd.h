@@ -553,6 +553,11 @@ enum {
     SGE_STAGE_BLAS_REFIT = 1u << 9, /* RTAccelerationBuilder dynamic-slice refit, RTAccelerationBuilder.swift:113-145 (not in SGE_STAGE_ALL) */
     SGE_STAGE_SEPARATION = 1u << 10, /* AgentSeparationSystem, Systems.swift:1906-2210: between the move stage and the locomotion stage,
                                       * as in DemoScene.swift:66-68 (not in SGE_STAGE_ALL; whole crowd only: first = 0, count = all) */
+    SGE_STAGE_SIDE_CONTACT_CACHE = 1u << 11, /* modifier of SGE_STAGE_MOVE, not a stage: the system's contactCachePolicy
+                                      * (KinematicMoveStopSystem.init(gravity:contactCachePolicy:), Systems.swift:1402-1415) is
+                                      * SideContactOnlyCachePolicy (:1136-1157: the depenetration pass records only side contacts)
+                                      * instead of DefaultContactCachePolicy (:1102-1134). Any other ContactCachePolicy is host
+                                      * code the kernels cannot run: the Swift / C++ mirrors refuse it. */
     SGE_STAGE_ALL_FIXED = 0x7Fu,
     SGE_STAGE_ALL = 0xFFu
 };

@@ -115,6 +115,8 @@ struct World {
     // AgentSeparationSystem.init defaults (Systems.swift:2146-2152)
     int separationIterations = 2;
     float separationMargin = 0.2f, separationHeightMargin = 0.1f;
+    // contactCachePolicy of the move system for the current tick (SGE_STAGE_SIDE_CONTACT_CACHE): SideContactOnlyCachePolicy
+    bool sideContactCacheOnly = false;
 };
 
 // pose.cpp

@@ -320,6 +320,7 @@ static void run_range(sgeo_world* h, const sge_tick_desc& d, int first, int coun
     // order of the fixed lists in DemoScene.swift:57-75
     if (d.stages & SGE_STAGE_INTENT) intent_fixed_update(w, first, count, d.dt);
     if (d.stages & SGE_STAGE_GRAVITY) gravity_fixed_update(w, first, count, d.dt, g);
+    w.sideContactCacheOnly = (d.stages & SGE_STAGE_SIDE_CONTACT_CACHE) != 0;
     if (d.stages & SGE_STAGE_MOVE) kinematic_move_fixed_update(w, first, count, d.dt, g, agents, selfOffset);
     if (d.stages & SGE_STAGE_LOCOMOTION) locomotion_fixed_update(w, first, count);
     if (d.stages & SGE_STAGE_ACTION) action_fixed_update(w, first, count, d.dt);

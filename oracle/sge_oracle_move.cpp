@@ -133,7 +133,7 @@ static void cacheRecord(sge_controller_state& c, int triangleIndex, V3 normal, b
 
 // ---- DepenetrationResolver.resolve :734-808 ----
 static bool depenetrationResolve(V3& position, D3& velocity, const sge_controller_params& P, sge_controller_state& C,
-                                 const CollisionQuery& query, V3& outNormal) {
+                                 const CollisionQuery& query, V3& outNormal, bool sideContactCacheOnly) {
     const float radius = P.radius, halfHeight = P.halfHeight, skinWidth = P.skinWidth;
     float slop = fmax_s(skinWidth * 0.5f, 0.001f);
     bool didResolve = false;
@@ -156,7 +156,10 @@ static bool depenetrationResolve(V3& position, D3& velocity, const sge_controlle
             V3 cached;
             if (cachedNormal(C, hit.triangleIndex, cached)) nn = cached;
             frameNormal += nn * hit.depth;
-            cacheRecord(C, hit.triangleIndex, nn, hit.normal.y < P.minGroundDot);
+            const bool isSide = hit.normal.y < P.minGroundDot;
+            // contactCachePolicy.record: DefaultContactCachePolicy :1122-1133, or SideContactOnlyCachePolicy :1146-1156
+            // (`guard isSideContact else { return }`, then the same update + side-contact memory)
+            if (isSide || !sideContactCacheOnly) cacheRecord(C, hit.triangleIndex, nn, isSide);
         }
         float frameNormalLen = length(frameNormal);
         V3 depenNormal = frameNormalLen > 1e-6f ? frameNormal / frameNormalLen : frameNormal;
@@ -715,7 +718,7 @@ void kinematic_move_fixed_update(World& w, int first, int count, float dt, V3 gr
         V3 remaining = f3(remD);
         // applyPreSweepDepenetration :1635-1656
         V3 depenNormal;
-        if (depenetrationResolve(position, velocity, P, C, query, depenNormal)) {
+        if (depenetrationResolve(position, velocity, P, C, query, depenNormal, w.sideContactCacheOnly)) {
             float into = dot(remaining, depenNormal);
             if (into < 0) remaining -= depenNormal * into;
         }

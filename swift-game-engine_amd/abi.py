@@ -37,6 +37,7 @@ STAGE_INTENT, STAGE_GRAVITY, STAGE_MOVE, STAGE_LOCOMOTION = 1, 2, 4, 8
 STAGE_ACTION, STAGE_POSE, STAGE_WRITEBACK, STAGE_SKIN, STAGE_AGENTS = 16, 32, 64, 128, 256
 STAGE_BLAS_REFIT = 512
 STAGE_SEPARATION = 1024
+STAGE_SIDE_CONTACT_CACHE = 1 << 11  # modifier of STAGE_MOVE: SideContactOnlyCachePolicy (Systems.swift:1136-1157)
 STAGE_ALL_FIXED, STAGE_ALL = 0x7F, 0xFF
 # options
 OPT_STORE_POSE_DEBUG, OPT_SKIN_LAYOUT, OPT_PROFILE, OPT_OVERLAP_SKIN, OPT_HEAVY_THRESHOLD, OPT_PLACEMENT_PROBES = 1, 2, 3, 4, 5, 6

@@ -272,7 +272,7 @@ int allocCrowdOutputs(sge_context* c) {
     const float goodMs = (float)((double)verts * (stride == 16 ? 48.0 : 40.0) / 6.5e12 * 1e3); // 6.5 TB/s: a good placement
     const bool debug = getenv("SGE_DEBUG_PLACEMENT") != nullptr;
     float bestMs = 0;
-    if ((rc = probe(cur, bestMs)) != SGE_OK) return rc;
+    if ((rc = probe(cur, bestMs)) != SGE_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
     if (debug) fprintf(stderr, "[sge] output placement: first allocation %.3f ms (good <= %.3f)\n", bestMs, goodMs);
     const int order[3] = {2, 0, 1}; // tangents, positions, normals
     for (int oi = 0; oi < 3 && bestMs > goodMs; ++oi) {
@@ -299,12 +299,17 @@ int allocCrowdOutputs(sge_context* c) {
             void* trial[3] = {cur[0], cur[1], cur[2]};
             trial[s] = cand;
             float ms = 0;
-            if ((rc = probe(trial, ms)) != SGE_OK) return rc;
+            if ((rc = probe(trial, ms)) != SGE_OK) { // every candidate, the spacers and the events go back; the streams stay as they are
+                for (void* q : held) (void)hipFree(q);
+                for (void* q : spacers) (void)hipFree(q);
+                (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+                return rc;
+            }
             c->placementTried += 1;
             if (debug) fprintf(stderr, "[sge]   stream %d candidate %p: %.3f ms\n", s, cand, ms);
             if (ms < bestMs) { bestMs = ms; best = cand; }
         }
-        if (best != cur[s]) { (void)hipFree(cur[s]); cur[s] = best; }
+        if (best != cur[s]) { (void)hipFree(cur[s]); cur[s] = best; bufs[s]->p = best; } // (the DevBuf never holds a freed pointer)
         for (void* q : held) if (q != best) (void)hipFree(q);
         for (void* q : spacers) (void)hipFree(q);
     }
@@ -1264,7 +1269,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         MoveLaunch L{c->crowd, c->col, c->agents, d->dt, d->gravity[0], d->gravity[1], d->gravity[2], st, first, count,
                      c->dStats.as<unsigned long long>(), c->dMoveScratch.p, c->dPlatforms.as<sge_platform_state>(), c->platformCount,
                      c->dCost.as<int>(), getenv("SGE_NO_SPEC") ? nullptr : c->dHint.as<uint8_t>(), c->dLists.as<int>(), c->dListCounts.as<int>(), c->dHeavyFlags.as<uint8_t>(),
-                     c->heavyThreshold, c->heavyCap, c->heavyStream, c->evClassified, c->evHeavyDone, c->hHeavyDemand, nullptr, nullptr, nullptr, nullptr, c->dOrderHist.as<int>(), nullptr};
+                     c->heavyThreshold, c->heavyCap, c->heavyStream, c->evClassified, c->evHeavyDone, c->hHeavyDemand, nullptr, nullptr, nullptr, nullptr, c->dOrderHist.as<int>(), 0, nullptr};
         // Grid of the multi-wave launch: the characters that asked for it in the newest step whose count has reached the host
         // (+ 50 % + 8), not the cap — every workgroup of that grid, the ones beyond the list included, has to find a CU with two
         // free places per SIMD. The list is cut to the grid (classify_kernel); whoever does not fit stays with the grouped launch,
@@ -1554,10 +1559,18 @@ NcclAllGatherFn resolveAllGather() {
     static bool tried = false;
     if (!tried) {
         tried = true;
-        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (h) fn = reinterpret_cast<NcclAllGatherFn>(dlsym(h, "ncclAllGather"));
+        // The communicator the host hands in belongs to the RCCL copy that created it: use the copy already in the process (a torch
+        // wheel bundles its own librccl.so.1, not on the loader path) before loading one by name — two copies in one process and a
+        // foreign ncclComm_t passed across them is undefined behaviour.
+        fn = reinterpret_cast<NcclAllGatherFn>(dlsym(RTLD_DEFAULT, "ncclAllGather"));
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            if (fn) break;
+            if (void* h = dlopen(name, RTLD_NOW | RTLD_NOLOAD)) fn = reinterpret_cast<NcclAllGatherFn>(dlsym(h, "ncclAllGather"));
+        }
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) { // none resident: load by name
+            if (fn) break;
+            if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) fn = reinterpret_cast<NcclAllGatherFn>(dlsym(h, "ncclAllGather"));
+        }
     }
     return fn;
 }

@@ -1215,6 +1215,7 @@ struct MoveState {
     // constants of the launch + the agent sweep result of this slide iteration
     float dt; F3 gravity; const DevMaterial* materials;
     int aHave; float aToi; F3 aNormal;
+    int sideContactCacheOnly; // SGE_STAGE_SIDE_CONTACT_CACHE: SideContactOnlyCachePolicy (Systems.swift:1136-1157)
 };
 __shared__ MoveState msA[kGroup];
 
@@ -1255,7 +1256,8 @@ __device__ __noinline__ void consumeDepen(int g, int nOverlap) { // Depenetratio
             F3 nn = hit.normal, cached;
             if (cachedNormal(C, hit.triIndex, cached)) nn = cached;
             frameNormal = frameNormal + nn * hit.depth;
-            cacheRecord(C, hit.triIndex, nn, hit.normal.y < P.minGroundDot);
+            const bool isSide = hit.normal.y < P.minGroundDot;
+            if (isSide || !ms.sideContactCacheOnly) cacheRecord(C, hit.triIndex, nn, isSide); // (:1150 `guard isSideContact else { return }`)
         }
         float frameNormalLen = length(frameNormal);
         F3 depenNormal = frameNormalLen > 1e-6f ? frameNormal / frameNormalLen : frameNormal;
@@ -1636,6 +1638,7 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? (S
         ms.position = toF(D3{body.position[0], body.position[1], body.position[2]});
         ms.phase = MP_DONE;
         ms.dt = dt; ms.gravity = gravity; ms.materials = col.materials; ms.aHave = 0; ms.aToi = 0; ms.aNormal = F3{0, 0, 0};
+        ms.sideContactCacheOnly = (K.stages & SGE_STAGE_SIDE_CONTACT_CACHE) ? 1 : 0;
     }
     if (PART == 0 && doMove) {
         cacheDecay(C);
@@ -2168,11 +2171,15 @@ __global__ __launch_bounds__(kWave, SGE_CCD_EXCLUSIVE ? 2 : SGE_GROUP_WAVES) voi
     // the launch's first wavefronts hold the most expensive characters. Without a list: kGroup consecutive characters.
     unsigned actMask = 0;
     {
-        const int W = (int)gridDim.x, w = (int)blockIdx.x;
+        // The first K.solo wavefronts take ONE character each, the K.solo most expensive of the list: a character of 3,000-4,000
+        // evaluations is ~0.33 ms of dependent cast passes by itself, and three companions whose traversals it would have to wait
+        // for made the wavefront that held it the launch's last (0.94 M cycles against a median of 0.38 M).
+        const int S = K.order ? K.solo : 0, W = (int)gridDim.x - S, w = (int)blockIdx.x - S;
         // (agent-scope loads: the list was written by the kernels just before this one)
         const int n = K.order ? __hip_atomic_load(K.orderCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : K.count;
         for (int g = 0; g < kGroup; ++g) {
-            const int rank = (g & 1) ? (g + 1) * W - 1 - w : g * W + w;
+            int rank = w < 0 ? (g == 0 ? w + S : n) : S + ((g & 1) ? (g + 1) * W - 1 - w : g * W + w);
+            if (W <= 0) rank = g == 0 ? (int)blockIdx.x : n;
             int e = -1;
             if (rank < n) e = K.order ? __hip_atomic_load(K.order + rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : K.first + rank;
             if (e >= 0) actMask |= 1u << g;
@@ -2704,7 +2711,9 @@ void launch_move(const MoveLaunch& L, hipStream_t s) {
     const bool agents = (L.stages & SGE_STAGE_AGENTS) && L.agents.all;
     static const bool grouped = !(getenv("SGE_MOVE_GROUP") && atoi(getenv("SGE_MOVE_GROUP")) == 0);
     static const int ldsPad = getenv("SGE_MOVE_LDS_PAD") ? atoi(getenv("SGE_MOVE_LDS_PAD")) : 0; // experiments: caps workgroups per CU
-    const int groups = (L.count + kGroup - 1) / kGroup;
+    static const int soloSetting = getenv("SGE_GROUP_SOLO") ? atoi(getenv("SGE_GROUP_SOLO")) : 128; // experiments
+    const int solo = grouped ? std::max(0, std::min(soloSetting, L.count / 16)) : 0;
+    const int groups = solo + (L.count - solo + kGroup - 1) / kGroup;
     const int blocks = (L.count + 255) / 256;
     // last step's costs -> heavy list (multi-wave launch) + order list of everybody else (grouped launch)
     (void)hipMemsetAsync(L.listCounts, 0, 4 * sizeof(int), s);
@@ -2733,7 +2742,7 @@ void launch_move(const MoveLaunch& L, hipStream_t s) {
     if (grouped) {
         hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, gs, L.orderHist, L.listCounts);
         hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, gs, L.cost, L.first, L.count, L.heavyFlags, L.orderHist, L.lists);
-        G.order = L.lists; G.orderCount = L.listCounts;
+        G.order = L.lists; G.orderCount = L.listCounts; G.solo = solo;
         // kGroup characters per wavefront, members drawn from the order list
         if (agents) hipLaunchKernelGGL((move_group_kernel<true>), dim3(groups), dim3(kWave), ldsPad, gs, G);
         else hipLaunchKernelGGL((move_group_kernel<false>), dim3(groups), dim3(kWave), ldsPad, gs, G);

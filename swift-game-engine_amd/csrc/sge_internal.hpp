@@ -229,6 +229,7 @@ struct MoveLaunch {
     const int* list; const int* listCount; // what a part-1 launch iterates over (set by launch_move)
     const int* order; const int* orderCount; // grouped launch: characters sorted by last step's cost (device), its length
     int* orderHist;                        // [64] histogram / cursors of the order list (zero between steps)
+    int solo;                              // grouped launch: its first `solo` wavefronts take one character each (the most expensive)
     // diagnostics (SGE_WAVE_PROF=1), rows of 8 x u64 in three regions of crowd.count rows each: [0] one row per wavefront of
     // move_group_kernel, [1] one row per character of move_kernel<0>, [2] one row per character of pose_kernel
     unsigned long long* waveProf;

@@ -197,6 +197,140 @@ __device__ __forceinline__ void skinRange(const SkinLaunch& L, const int c, cons
     }
 }
 
+// CPW characters per work unit: every source vertex is loaded ONCE and skinned with CPW palettes (all CPW staged in LDS, the pair
+// layout of skinRange). Alone the kernel is as fast as the one-character form (it is bound by its stores); beside the next step's
+// collision kernels the per-CU memory pipeline is what the two sides share, and the one-character form puts 64 B of source loads per
+// vertex into it next to 40 B of stores — 9 GB of L2 reads per 10k-character launch. With CPW = 4 that is 16 B per vertex.
+// Same arithmetic as skinRange (shared through SGE_SKIN_ONE), so the three output streams are bit-identical.
+template <int DST_STRIDE, int CPW>
+__device__ __forceinline__ void skinRangeMulti(const SkinLaunch& L, const int c0, const int nChars, const int vBegin, const int vEnd, float4* pal) {
+    const int tid = threadIdx.x;
+    int gid = vBegin + tid;
+    VertexIn cur{};
+    if (gid < vEnd) cur = loadVertex<3>(L, gid);
+    const int rows = L.paletteCount * 3; // float4 rows of one staged palette
+    float* palf = reinterpret_cast<float*>(pal);
+    for (int k = 0; k < nChars; ++k) {
+        const float4* gp = reinterpret_cast<const float4*>(L.palettes + (size_t)(c0 + k) * L.paletteCount * 16);
+        for (int i = tid; i < L.paletteCount * 4; i += kSkinBlock) {
+            float4 col = gp[i];
+            int bone = i >> 2, cc = i & 3;
+            float* dst = palf + (size_t)k * rows * 4 + bone * 12;
+            dst[2 * cc + 0] = col.x;
+            dst[2 * cc + 1] = col.y;
+            dst[8 + cc] = col.z;
+        }
+    }
+    __syncthreads();
+    const size_t obase = (size_t)L.dstBaseVertex + (size_t)c0 * L.vertexCount;
+    float* const opBase = reinterpret_cast<float*>(L.outPos) + obase * DST_STRIDE;
+    float* const onBase = reinterpret_cast<float*>(L.outNrm) + obase * DST_STRIDE;
+    v4f* const otBase = reinterpret_cast<v4f*>(L.outTan) + obase;
+    const size_t charStride = (size_t)L.vertexCount;
+
+    auto skinAll = [&](const VertexIn& v, int g) {
+        const float w0 = fmaxf(v.w.x, 0.0f), w1 = fmaxf(v.w.y, 0.0f);
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) {
+            if (k >= nChars) break;
+            const v4f* P = reinterpret_cast<const v4f*>(pal) + (size_t)k * rows;
+            v2f A, B, C, D, E, F;
+            {
+                const v4f q0 = P[v.idx.x * 3 + 0], q1 = P[v.idx.x * 3 + 1], q2 = P[v.idx.x * 3 + 2];
+                A = q0.xy * w0; B = q0.zw * w0; C = q1.xy * w0; D = q1.zw * w0; E = q2.xy * w0; F = q2.zw * w0;
+            }
+#define SGE_BLEND(BONE, WGT)                                                                   \
+            {                                                                                  \
+                const v4f q0 = P[(BONE) * 3 + 0], q1 = P[(BONE) * 3 + 1], q2 = P[(BONE) * 3 + 2]; \
+                A += q0.xy * (WGT); B += q0.zw * (WGT); C += q1.xy * (WGT); D += q1.zw * (WGT); \
+                E += q2.xy * (WGT); F += q2.zw * (WGT);                                        \
+            }
+            SGE_BLEND(v.idx.y, w1)
+            if (v.w.z > 0.0f) SGE_BLEND(v.idx.z, v.w.z)
+            if (v.w.w > 0.0f) SGE_BLEND(v.idx.w, v.w.w)
+#undef SGE_BLEND
+            const v2f pxy = A * v.p.x + (B * v.p.y + (C * v.p.z + D));
+            const v2f pe = E * v2f{v.p.x, v.p.y};
+            const float pz = (pe.x + pe.y) + (F.x * v.p.z + F.y);
+            v2f nxy = A * v.n.x + (B * v.n.y + C * v.n.z);
+            const v2f ne = E * v2f{v.n.x, v.n.y};
+            float nz = (ne.x + ne.y) + F.x * v.n.z;
+            v2f txy = A * v.t.x + (B * v.t.y + C * v.t.z);
+            const v2f te = E * v2f{v.t.x, v.t.y};
+            float tz = (te.x + te.y) + F.x * v.t.z;
+            {
+                const v2f sq = nxy * nxy;
+                const float r = __builtin_amdgcn_rsqf((sq.x + sq.y) + nz * nz);
+                nxy *= r; nz *= r;
+            }
+            {
+                const v2f sq = txy * txy;
+                const float r = __builtin_amdgcn_rsqf((sq.x + sq.y) + tz * tz);
+                txy *= r; tz *= r;
+            }
+            float* op = opBase + (size_t)k * charStride * DST_STRIDE + (unsigned)g * DST_STRIDE;
+            float* on = onBase + (size_t)k * charStride * DST_STRIDE + (unsigned)g * DST_STRIDE;
+            if (DST_STRIDE == 4) {
+                __builtin_nontemporal_store(v4f{pxy.x, pxy.y, pz, 0.f}, reinterpret_cast<v4f*>(op));
+                __builtin_nontemporal_store(v4f{nxy.x, nxy.y, nz, 0.f}, reinterpret_cast<v4f*>(on));
+            } else {
+                __builtin_nontemporal_store(pxy.x, op); __builtin_nontemporal_store(pxy.y, op + 1); __builtin_nontemporal_store(pz, op + 2);
+                __builtin_nontemporal_store(nxy.x, on); __builtin_nontemporal_store(nxy.y, on + 1); __builtin_nontemporal_store(nz, on + 2);
+            }
+            __builtin_nontemporal_store(v4f{txy.x, txy.y, tz, v.t.w}, otBase + (size_t)k * charStride + (unsigned)g);
+        }
+    };
+
+    if (gid >= vEnd) return;
+    if (CPW >= 4) {
+        // four characters per loaded vertex: the loop body is ~1,200 instructions and 160 B of stores per lane, so the next chunk's
+        // source vertex is requested only when the current one is done with — one L2 latency per chunk, 16 registers fewer
+        // (the prefetching form needs 113, which leaves a SIMD room for one collision wavefront instead of two)
+        while (true) {
+            skinAll(cur, gid);
+            gid += kSkinBlock;
+            if (gid >= vEnd) break;
+            cur = loadVertex<3>(L, gid);
+        }
+        return;
+    }
+    VertexIn nxt{};
+    while (true) {
+        const int g1 = gid + kSkinBlock;
+        const bool has1 = g1 < vEnd;
+        if (has1) nxt = loadVertex<3>(L, g1);
+        skinAll(cur, gid);
+        if (!has1) break;
+        const int g2 = g1 + kSkinBlock;
+        const bool has2 = g2 < vEnd;
+        if (has2) cur = loadVertex<3>(L, g2);
+        skinAll(nxt, g1);
+        if (!has2) break;
+        gid = g2;
+    }
+}
+
+// The resident form with CPW characters per work unit (unit u = (group of CPW consecutive characters, vertex split)); dynamic LDS:
+// CPW palettes of L.paletteCount bones + the ticket slot behind them.
+template <int DST_STRIDE, int CPW>
+__global__ __launch_bounds__(kSkinBlock, SGE_SKIN_MIN_BLOCKS) void skin_ticket_multi_kernel(SkinLaunch L, int splits, int vertsPerSplit, int* __restrict__ queue) {
+    extern __shared__ float4 palDyn[];
+    int* const sNextUnit = reinterpret_cast<int*>(palDyn + (size_t)CPW * L.paletteCount * 3); // (behind the palettes: their 16-byte alignment stays)
+    const int groups = (L.chars + CPW - 1) / CPW;
+    for (int u = blockIdx.x; u < groups * splits;) {
+        const int gidx = u / splits;
+        const int sp = u - gidx * splits;
+        const int vBegin = sp * vertsPerSplit;
+        const int c0 = gidx * CPW;
+        int ticket = 0;
+        if (threadIdx.x == 0) ticket = atomicAdd(queue, 1);
+        skinRangeMulti<DST_STRIDE, CPW>(L, c0, min(CPW, L.chars - c0), vBegin, min(L.vertexCount, vBegin + vertsPerSplit), palDyn);
+        if (threadIdx.x == 0) *sNextUnit = (int)gridDim.x + ticket;
+        __syncthreads(); // also: every thread is done with the palettes
+        u = *sNextUnit;
+    }
+}
+
 template <int SRC_STRIDE, int DST_STRIDE>
 __global__ __launch_bounds__(kSkinBlock, SGE_SKIN_MIN_BLOCKS) void skin_kernel(SkinLaunch L, int splits, int vertsPerSplit, int wavePriority) {
     __shared__ float4 pal[SGE_MAX_BONES * 3];
@@ -301,6 +435,41 @@ void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU, int
         static const int totalOverride = getenv("SGE_SKIN_LDS_TOTAL") ? atoi(getenv("SGE_SKIN_LDS_TOTAL")) : 0; // experiments
         const int perWorkgroup = totalOverride > 0 ? totalOverride : 160 * 1024 / maxWorkgroupsPerCU, own = (int)sizeof(float4) * SGE_MAX_BONES * 3;
         ldsPad = perWorkgroup > own + 256 ? (perWorkgroup - own - 256) & ~255 : 0;
+    }
+    if (ldsPad + (int)sizeof(float4) * SGE_MAX_BONES * 3 > 64 * 1024) {
+        // a cap of one or two workgroups per CU pads beyond the 64 KB a kernel may ask for by default: raise the limit once per device
+        static bool attrSet[kMaxDevices] = {};
+        const int devSlot = currentDeviceSlot();
+        if (!attrSet[devSlot]) {
+            const void* fns[4] = {reinterpret_cast<const void*>(skin_kernel<3, 3>), reinterpret_cast<const void*>(skin_kernel<3, 4>),
+                                  reinterpret_cast<const void*>(skin_kernel<4, 3>), reinterpret_cast<const void*>(skin_kernel<4, 4>)};
+            bool ok = true;
+            for (const void* f : fns) ok &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(float4) * SGE_MAX_BONES * 3) == hipSuccess;
+            if (!ok) { (void)hipGetLastError(); ldsPad = 0; } // no cap rather than a launch that fails
+            else attrSet[devSlot] = true;
+        }
+    }
+    static const int cpwSetting = getenv("SGE_SKIN_CPW") ? atoi(getenv("SGE_SKIN_CPW")) : 1; // experiments: characters per work unit
+    if (residentQueue && residentQuarters > 0 && L.srcLayout != SGE_LAYOUT_PADDED16 && (cpwSetting == 2 || cpwSetting == 4 || cpwSetting == 8) && L.chars >= 64) {
+        const int cpw = cpwSetting, groups = (L.chars + cpw - 1) / cpw;
+        int sp2 = 1;
+        while ((long long)groups * sp2 < 8192 && sp2 < 64 && (L.vertexCount + sp2 - 1) / sp2 > 2 * kSkinBlock) sp2 *= 2;
+        int vps = ((L.vertexCount + sp2 - 1) / sp2 + kSkinBlock - 1) / kSkinBlock * kSkinBlock;
+        sp2 = (L.vertexCount + vps - 1) / vps;
+        const size_t lds = (size_t)cpw * L.paletteCount * 48 + 16;
+        (void)hipMemsetAsync(residentQueue, 0, sizeof(int), s);
+        dim3 pgrid((unsigned)std::min<size_t>((size_t)sp2 * groups, (size_t)currentDeviceCUs() * residentQuarters / 4));
+        if (cpw == 2) {
+            if (ds == 3) hipLaunchKernelGGL((skin_ticket_multi_kernel<3, 2>), pgrid, dim3(kSkinBlock), lds, s, L, sp2, vps, residentQueue);
+            else hipLaunchKernelGGL((skin_ticket_multi_kernel<4, 2>), pgrid, dim3(kSkinBlock), lds, s, L, sp2, vps, residentQueue);
+        } else if (cpw == 4) {
+            if (ds == 3) hipLaunchKernelGGL((skin_ticket_multi_kernel<3, 4>), pgrid, dim3(kSkinBlock), lds, s, L, sp2, vps, residentQueue);
+            else hipLaunchKernelGGL((skin_ticket_multi_kernel<4, 4>), pgrid, dim3(kSkinBlock), lds, s, L, sp2, vps, residentQueue);
+        } else {
+            if (ds == 3) hipLaunchKernelGGL((skin_ticket_multi_kernel<3, 8>), pgrid, dim3(kSkinBlock), lds, s, L, sp2, vps, residentQueue);
+            else hipLaunchKernelGGL((skin_ticket_multi_kernel<4, 8>), pgrid, dim3(kSkinBlock), lds, s, L, sp2, vps, residentQueue);
+        }
+        return;
     }
     if (residentQueue && residentQuarters > 0 && L.srcLayout != SGE_LAYOUT_PADDED16) { // resident workgroups + ticket counter
         (void)hipMemsetAsync(residentQueue, 0, sizeof(int), s);
@@ -446,9 +615,17 @@ static int launchSkinRefitTile(const SkinLaunch& L, const DevBlas& B, float* bou
     // persistent: exactly the workgroups that are resident together. Registers bind before the LDS does (112 VGPRs: four
     // wavefronts per SIMD, two workgroups per CU); a workgroup beyond that would start when the others leave and do its first
     // character, fixed by its index, as the tail of the launch.
-    int resident = 0;
-    if (L.dstLayout == SGE_LAYOUT_PADDED16) SGE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, skin_refit_kernel<3, 4, TILE>, kBlasRefitBlock, lds));
-    else SGE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, skin_refit_kernel<3, 3, TILE>, kBlasRefitBlock, lds));
+    static int residentCache[kMaxDevices][2] = {};
+    static size_t residentLds[kMaxDevices][2] = {};
+    const int form = L.dstLayout == SGE_LAYOUT_PADDED16 ? 1 : 0;
+    if (!residentCache[devSlot][form] || residentLds[devSlot][form] != lds) { // once per (device, layout, LDS size), not per tick
+        int r = 0;
+        if (form) SGE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, skin_refit_kernel<3, 4, TILE>, kBlasRefitBlock, lds));
+        else SGE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, skin_refit_kernel<3, 3, TILE>, kBlasRefitBlock, lds));
+        residentCache[devSlot][form] = r > 0 ? r : 1;
+        residentLds[devSlot][form] = lds;
+    }
+    const int resident = residentCache[devSlot][form];
     const int grid = std::min(L.chars, currentDeviceCUs() * std::max(1, std::min(perCU, resident)));
     if (L.dstLayout == SGE_LAYOUT_PADDED16) hipLaunchKernelGGL((skin_refit_kernel<3, 4, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, L, B, bounds, queue);
     else hipLaunchKernelGGL((skin_refit_kernel<3, 3, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, L, B, bounds, queue);

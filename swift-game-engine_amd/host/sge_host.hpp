@@ -77,12 +77,17 @@ struct FixedStepSystem {
 
 // PhysicsIntentSystem + GravitySystem + KinematicMoveStopSystem in the reference's order
 // (DemoScene.swift:62-68); init(gravity:) as Systems.swift:1407.
+// init(gravity:contactCachePolicy:) — the two policies the reference defines (Systems.swift:1102-1157); a ContactCachePolicy is host
+// code, so anything else cannot run inside the kernels and has no value here
+enum class ContactCachePolicy { Default, SideContactOnly };
 class KinematicMoveStopSystem : public FixedStepSystem {
 public:
-    explicit KinematicMoveStopSystem(float3 gravity = {0, -98.0f, 0}, bool applyIntentAndGravity = true)
-        : gravity_(gravity), pre_(applyIntentAndGravity) {}
+    explicit KinematicMoveStopSystem(float3 gravity = {0, -98.0f, 0}, bool applyIntentAndGravity = true,
+                                     ContactCachePolicy contactCachePolicy = ContactCachePolicy::Default)
+        : gravity_(gravity), pre_(applyIntentAndGravity), policy_(contactCachePolicy) {}
     void fixedUpdate(World& world, float dt) override {
-        world.tick(dt, (pre_ ? (SGE_STAGE_INTENT | SGE_STAGE_GRAVITY) : 0u) | SGE_STAGE_MOVE, gravity_);
+        world.tick(dt, (pre_ ? (SGE_STAGE_INTENT | SGE_STAGE_GRAVITY) : 0u) | SGE_STAGE_MOVE |
+                       (policy_ == ContactCachePolicy::SideContactOnly ? SGE_STAGE_SIDE_CONTACT_CACHE : 0u), gravity_);
     }
     // the platform entities of world.query(PhysicsBody, Transform, StaticMesh, KinematicPlatform) (Systems.swift:1832-1835)
     // as PlatformCarry reads them; call once per step after the platform motion system ran
@@ -92,6 +97,7 @@ public:
 private:
     float3 gravity_;
     bool pre_;
+    ContactCachePolicy policy_;
 };
 struct LocomotionProfileSystem : FixedStepSystem {
     void fixedUpdate(World& world, float dt) override { world.tick(dt, SGE_STAGE_LOCOMOTION); }

@@ -18,6 +18,19 @@ func sgeTick(_ crowd: GPUCrowd, dt: Float, gravity: SIMD3<Float> = SIMD3<Float>(
     crowd.check(sge_tick(crowd.ctx, &d))
 }
 
+/// Systems.swift:1136-1157 — `private` in the reference's file; a host that swaps this binding in names it here instead
+public struct SideContactOnlyCachePolicy: ContactCachePolicy {
+    public init() {}
+    public mutating func decay(controller: inout CharacterControllerComponent) { var p = DefaultContactCachePolicy(); p.decay(controller: &controller) }
+    public func cachedNormal(controller: CharacterControllerComponent, triangleIndex: Int) -> SIMD3<Float>? {
+        DefaultContactCachePolicy().cachedNormal(controller: controller, triangleIndex: triangleIndex)
+    }
+    public mutating func record(controller: inout CharacterControllerComponent, triangleIndex: Int, normal: SIMD3<Float>, isSideContact: Bool) {
+        guard isSideContact else { return }
+        var p = DefaultContactCachePolicy(); p.record(controller: &controller, triangleIndex: triangleIndex, normal: normal, isSideContact: true)
+    }
+}
+
 /// Systems.swift:1402-1415, :1823-1902
 public final class KinematicMoveStopSystem: FixedStepSystem {
     private let crowd: GPUCrowd
@@ -26,16 +39,21 @@ public final class KinematicMoveStopSystem: FixedStepSystem {
     /// kinematic platforms of this step (Systems.swift:1832-1835): entity, mesh positions, previous positionF
     public var platformEntities: [Entity] = []
 
+    /// The policy runs inside the kernels, so it must be one of the two the reference defines (:1102-1157); any other
+    /// ContactCachePolicy is host code that cannot be called per contact from the GPU and is refused, not silently dropped.
     public init(crowd: GPUCrowd, gravity: SIMD3<Float> = SIMD3<Float>(0, -98.0, 0), contactCachePolicy: ContactCachePolicy = DefaultContactCachePolicy()) {
         self.crowd = crowd; self.gravity = gravity
-        _ = contactCachePolicy                                     // the default policy is what the kernels implement (:1102-1205)
+        if contactCachePolicy is DefaultContactCachePolicy { policyBit = 0 }
+        else if contactCachePolicy is SideContactOnlyCachePolicy { policyBit = UInt32(SGE_STAGE_SIDE_CONTACT_CACHE) }
+        else { preconditionFailure("KinematicMoveStopSystem on the GPU supports DefaultContactCachePolicy and SideContactOnlyCachePolicy only") }
     }
+    private let policyBit: UInt32
     public func setQuery(_ query: CollisionQuery?) { self.query = query }   // kept for CollisionQueryRefreshSystem (:157-180); the world lives on the GPU
 
     public func fixedUpdate(world: World, dt: Float) {
         crowd.pushDirtyState(from: world)
         uploadPlatforms(world: world)
-        sgeTick(crowd, dt: dt, gravity: gravity, stages: UInt32(SGE_STAGE_MOVE))
+        sgeTick(crowd, dt: dt, gravity: gravity, stages: UInt32(SGE_STAGE_MOVE) | policyBit)
         crowd.pullBack(into: world)
     }
 

@@ -130,3 +130,43 @@ def test_assets_and_synthetic_meshes(sge, ybot):
     assert off[0] == 0 and np.all((off >= 0) & (off < 0.7))
     assert sge.parallel.shard_range(10, 0, 3) == (0, 3) and sge.parallel.shard_range(10, 2, 3) == (6, 4)
     assert sum(sge.parallel.shard_range(250000, r, 8)[1] for r in range(8)) == 250000
+
+
+def test_kernel_resources_match_what_the_schedule_counts_on(sge, lib):
+    """Build-time guard for the two GPU faults of round 2's scratch: read every gfx950 kernel's resources from the
+    code objects inside libsge_amd.so (no GPU needed) and hold them to what the step schedule and the kernels' own indexing assume.
+    - no kernel uses a dynamic stack, and the kernels that take their whole argument struct by value and index dynamic LDS
+      (pose_kernel: the variant with a non-inlined bone evaluation faulted at address nil through its scratch copy of the
+      arguments) use no scratch at all;
+    - register counts stay inside the residency the overlap schedule is built on: LBS <= 88 (two resident wavefronts leave a SIMD
+      336 registers), the multi-wave move kernel <= 168 (two per SIMD beside them), pose <= 168, the grouped kernel <= 168;
+    - static LDS of the collision kernels stays under the 10.5 KB five of them share in one vacated LBS slot."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    tab = kr.kernel_table(sge.abi.library_path())
+    assert len(tab) >= 40
+
+    def find(fragment):
+        hits = {k: v for k, v in tab.items() if fragment in k}
+        assert hits, fragment
+        return hits
+
+    for name, r in tab.items():
+        assert not r["dynamic_stack"], name
+    for name, r in find("pose_kernel").items():
+        assert r["scratch"] == 0 and r["vgpr_spill"] == 0, (name, r)
+    for name, r in find("pose_kernelILi4").items():
+        assert r["vgpr"] <= 168, (name, r)
+    for frag in ("skin_kernel", "skin_ticket_kernel"):
+        for name, r in find(frag).items():
+            assert r["vgpr"] <= 88 and r["scratch"] == 0, (name, r)
+    for name, r in find("move_group_kernel").items():
+        assert r["vgpr"] <= 168 and r["scratch"] == 0 and r["lds"] <= 10752, (name, r)
+    for name, r in find("move_kernelILi1E").items():
+        heavy = r["max_wg"] > 64
+        assert r["vgpr"] <= (168 if heavy else 128), (name, r)
+        assert r["scratch"] <= 16, (name, r)
+    for name, r in find("move_kernelILi0E").items():
+        assert r["vgpr"] <= 128 and r["scratch"] == 0 and r["lds"] <= 10752, (name, r)

@@ -1188,3 +1188,30 @@ def test_overlap_on_a_caller_stream_with_a_consumer(sge):
     assert np.abs(scratch[0].cpu().numpy() - expect[-1]).max() <= 1e-6 * np.abs(expect[-1]).max()
     assert lib.sge_context_set_stream(h, None) == 0
     gpu.close()
+
+
+def test_side_contact_cache_policy_parity(sge, engines):
+    """KinematicMoveStopSystem.init(gravity:contactCachePolicy:) with the reference's second policy, SideContactOnlyCachePolicy
+    (Systems.swift:1136-1157: the depenetration pass records only side contacts) = SGE_STAGE_SIDE_CONTACT_CACHE: bit-exact against
+    the oracle over 150 steps on the hilly terrain, and not the same as the default policy's trace (the flag does something)."""
+    gpu, cpu = engines
+    A = sge.abi
+    n = 96
+    for e in engines:
+        build_scene(sge, e, n, terrain_cells=(56, 40), seed=23, mixed=True)
+    st = A.STAGE_ALL | A.STAGE_SIDE_CONTACT_CACHE
+    for s in range(150):
+        for e in engines:
+            e.tick(stages=st)
+        if s in (0, 5, 60, 149):
+            gpu.synchronize()
+            compare_states(sge, gpu, cpu, n)
+    side_only = gpu.download()["controllers"].copy()
+    assert gpu.move_stats().overflow == 0
+    ref = sge.CharacterEngine(0)
+    build_scene(sge, ref, n, terrain_cells=(56, 40), seed=23, mixed=True)
+    for s in range(150):
+        ref.tick()
+    default = ref.download()["controllers"]
+    ref.close()
+    assert side_only.tobytes() != default.tobytes()

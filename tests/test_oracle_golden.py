@@ -364,3 +364,30 @@ def test_action_layer_matches_reference_tool_plus_slerp(sge, ybot, cpu, golden, 
     scale = np.abs(em).max()
     assert np.abs(loc[0] - el).max() <= 2e-5 * scale, np.abs(loc[0] - el).max()
     assert np.abs(mod[0] - em).max() <= 2e-5 * scale, np.abs(mod[0] - em).max()
+
+
+def test_side_contact_only_cache_policy_known_answer(sge):
+    """SideContactOnlyCachePolicy (Systems.swift:1136-1157) against DefaultContactCachePolicy (:1102-1134) on the oracle: a capsule
+    resting slightly inside the ground quad is depenetrated by a GROUND contact (normal.y = 1 >= minGroundDot). The default policy
+    records it in the contact manifold (ContactManifoldCache.update: one entry per overlapped triangle of the quad, 8 frames); the side-only policy returns at its
+    `guard isSideContact` and leaves the cache empty. Position and velocity are the same either way."""
+    import oracle_binding as ob
+    A = sge.abi
+    outs = []
+    for flag in (0, A.STAGE_SIDE_CONTACT_CACHE):
+        cpu = ob.oracle_engine()
+        quad = np.array([[-40, 0, -40], [40, 0, -40], [40, 0, 40], [-40, 0, 40]], np.float32)
+        cpu.rebuild_static([dict(positions=quad, indices=np.array([0, 1, 2, 0, 2, 3], np.uint32), modelMatrix=np.eye(4, dtype=np.float32).reshape(-1))])
+        cpu.resize(1)
+        params = sge.assets.default_controller_params(1)
+        bodies = sge.assets.default_bodies(1, np.array([[0.0, 2.5 - 0.2, 0.0]]))  # bottom of the capsule 0.2 under the quad
+        cpu.upload(bodies=bodies, params=params, controllers=sge.assets.default_controller_state(1),
+                   intents=sge.assets.default_intents(1), locomotion=None, actions=None)
+        cpu.tick(stages=A.STAGE_MOVE | flag)
+        d = cpu.download(what=("bodies", "controllers"))
+        outs.append((d["bodies"]["position"][0].copy(), int(d["controllers"]["manifoldCount"][0]), int(d["controllers"]["manifoldFrames"][0])))
+        cpu.close()
+    (p0, count0, frames0), (p1, count1, frames1) = outs
+    assert np.array_equal(p0, p1)
+    assert count0 == 2 and frames0 == 8  # both triangles of the quad overlap: a ground contact uses up to two hits (:764)
+    assert count1 == 0 and frames1 == 0

@@ -40,7 +40,7 @@ rc = eng.t.lib.sge_debug_wave_profile(eng.h, abi.ptr(prof), 3 * n)
 assert rc == 0, rc
 p = prof.astype(np.float64)
 waves = (n + G - 1) // G
-grp, mv0, pose = p[:waves], p[n:2 * n], p[2 * n:3 * n]
+grp, mv0, pose = p[:n], p[n:2 * n], p[2 * n:3 * n]  # (the grouped launch has fewer wavefronts than characters: unused rows stay zero)
 grp = grp[grp[:, 0] > 0]
 
 
@@ -50,7 +50,7 @@ def pct(a):
 
 print("== setting: %s, scene %s, %d characters; stage times per step (HIP events): %s" % (mode, "+".join(which), n, times))
 tot = grp[:, 0]
-print("move_group_kernel: %d wavefronts (4 characters each)" % len(grp))
+print("move_group_kernel: %d wavefronts (the first ones one character each, then 4 each)" % len(grp))
 print("  total cycles     %s" % pct(tot))
 print("  traverse (gather)%s  share %.3f" % (pct(grp[:, 1]), grp[:, 1].sum() / tot.sum()))
 print("  sweep            %s  share %.3f" % (pct(grp[:, 2]), grp[:, 2].sum() / tot.sum()))
