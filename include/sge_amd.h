@@ -619,11 +619,17 @@ typedef struct sge_move_stats {
 } sge_move_stats;
 /* AgentSeparationSystem.init(iterations:separationMargin:heightMargin:) (Systems.swift:2146-2152; defaults 2, 0.2, 0.1).
    The stage resolves overlaps between the context's solid agents in CHARACTER-INDEX order — the reference iterates a Swift
-   Dictionary, whose order is hash-seed dependent, so it has no canonical result of its own. The pair loop is
-   sequential by definition (every pair reads what the pairs before it wrote), so one wavefront walks it; the stage is meant for the
-   reference's scale of agents (at most SGE_MAX_SEPARATION_AGENTS solid agents per context, else SGE_ERR_CAPACITY). */
+   Dictionary, whose order is hash-seed dependent, so it has no canonical result of its own. Up to
+   SGE_MAX_SEPARATION_AGENTS characters (the reference's scale) one wavefront walks the pair loop with everything in LDS; larger
+   crowds run the same loop as a dataflow over agents — every agent carries a counter of the loops that have passed it, so loops
+   that share no agent run side by side and the result is the sequential loop's, bit for bit (sge_ccd.hip, "dataflow"). Capacity:
+   the context's character count. */
 #define SGE_MAX_SEPARATION_AGENTS 1024
 int sge_separation_params(sge_context* ctx, int32_t iterations, float separation_margin, float height_margin);
+/* Diagnostics of the crowd path, last pass of the last step: out[4] = listed agents, loops drawn, redo flags (bit 0: an agent had
+   more than 64 neighbours to track, bit 1: an agent was pushed further than a grid cell; either way the pass was redone by the
+   one-wavefront form, same result), cell size (float bits). */
+int sge_debug_separation(sge_context* ctx, int32_t* out);
 int sge_move_stats_read(sge_context* ctx, sge_move_stats* out, int reset);
 /* Per-character share of CollisionQueryStats.capsuleSweepIterations (CollisionQuery.swift:280-318) for the LAST fixed step:
    distance evaluations each of characters [first, first + count) spent in its casts (what the scheduler balances on). */

@@ -61,10 +61,14 @@ struct sge_context {
     int placementProbes = 8;   // candidate placements of the skinned output streams compared at allocation time
     float placementMs = 0; int placementTried = 0;
     int overlapSkinWorkgroups = 3; // LBS workgroups per CU while it shares the chip with the next step's collision kernels
-    // overlap mode, LBS as resident workgroups with a ticket counter (quarters of a workgroup per CU): -1 = by crowd size (8 from
-    // kResidentSkinCharacters characters on when the tick has a move stage: +3 ... +8 % per step at 16k-40k characters on both scenes,
-    // -0.5 % at 10k, -6 % at 2.5k and for LBS-only ticks at any size), 0 = never, q > 0 = always (SGE_SKIN_PERSISTENT)
+    // overlap mode, LBS as resident workgroups with a ticket counter (quarters of a workgroup per CU): -1 = by crowd size and by
+    // the move stage's weight (kResidentSkinQuarters from kResidentSkinCharacters characters on; round 3, with four characters per
+    // work unit: 10k cheese 1.087 -> 0.937 ms, configs[1] 0.927 -> 0.873, merged / mixed 1.086 -> 0.982, 35k-vertex Y-Bot 2.32 ->
+    // 2.24, agents 1.154 -> 1.109, 20k 1.975 -> 1.748; 2,500 characters 0.430 -> 0.459 and the collision-heavy synthetic terrain
+    // 1.307 -> 1.414, which is what the two conditions keep out), 0 = never, q > 0 = always (SGE_SKIN_PERSISTENT)
     int residentSkinQuarters = -1;
+    int residentSkinCharsPerUnit = kResidentSkinCharsPerUnit; // characters per work unit of the resident form (SGE_SKIN_CPW: 1, 2, 4, 8)
+    int lastMoveCount = 1;       // characters of the move stage whose cost sum sits in hHeavyDemand[1]
     int overlapFusedWorkgroups = 0; // cap for the persistent workgroups of the fused LBS + refit kernel (0: as many as the LDS holds; measured 1 / 2 / 3: 1.53 / 1.47 / 1.44 ms per step)
     int heavyThreshold = 4000; // distance evaluations in a character's last step above which it takes the multi-wave kernel; < 0: off
     int heavyCap = 2048;       // most characters the multi-wave launch takes per step (its grid is sized by demand, see sge_tick)
@@ -115,7 +119,7 @@ struct sge_context {
            dBlasIndices, dBlasBounds, dBlasInstances, dBlasRays, dBlasHits, dBlasTileStart, dBlasRoundLen, dBlasRoundCluster, dBlasRoundIds, dBlasWorldBoxes, dBlasUVs, dBlasQueue, dSkinQueue;
     bool blasHasUVs = false;
     // stats / profiling
-    DevBuf dStats, dWaveProf, dOrderHist, dSepAgents, dSepCounts;
+    DevBuf dStats, dWaveProf, dOrderHist, dSepAgents, dSepCounts, dSepFlow;
     int separationIterations = 2; float separationMargin = 0.2f, separationHeightMargin = 0.1f; // AgentSeparationSystem.init :2146-2152
     Events evMove, evPose, evSkin, evAgents, evBlas;
 };
@@ -483,6 +487,7 @@ sge_context* sge_context_create(int device_index) {
     if (getenv("SGE_PLACEMENT_PROBES")) c->placementProbes = std::max(1, atoi(getenv("SGE_PLACEMENT_PROBES")));
     if (getenv("SGE_OVERLAP_SKIN_WORKGROUPS")) c->overlapSkinWorkgroups = atoi(getenv("SGE_OVERLAP_SKIN_WORKGROUPS"));
     if (getenv("SGE_SKIN_PERSISTENT")) c->residentSkinQuarters = atoi(getenv("SGE_SKIN_PERSISTENT"));
+    if (getenv("SGE_SKIN_CPW")) c->residentSkinCharsPerUnit = atoi(getenv("SGE_SKIN_CPW"));
     if (getenv("SGE_OVERLAP_FUSED_WORKGROUPS")) c->overlapFusedWorkgroups = atoi(getenv("SGE_OVERLAP_FUSED_WORKGROUPS"));
     // the latency-bound collision / pose launches go first when they compete with a streaming skin launch (overlap option)
     int prLeast = 0, prGreatest = 0;
@@ -515,7 +520,7 @@ sge_context* sge_context_create(int device_index) {
         hipEventCreateWithFlags(&c->evHeavyDone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evTablesCopied, hipEventDisableTiming) != hipSuccess) { set_error("stream/event creation failed"); delete c; return nullptr; }
     if (c->dSkinQueue.alloc(256) != SGE_OK) { delete c; return nullptr; }
-    if (hipHostMalloc(reinterpret_cast<void**>(&c->hHeavyDemand), sizeof(int), hipHostMallocDefault) == hipSuccess) *c->hHeavyDemand = -1;
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->hHeavyDemand), 2 * sizeof(int), hipHostMallocDefault) == hipSuccess) { c->hHeavyDemand[0] = -1; c->hHeavyDemand[1] = -1; }
     else { (void)hipGetLastError(); c->hHeavyDemand = nullptr; }
     if (c->dStats.alloc((size_t)kStatShards * 64) != SGE_OK || hipMemsetAsync(c->dStats.p, 0, (size_t)kStatShards * 64, c->stream) != hipSuccess) { delete c; return nullptr; }
     return c;
@@ -528,7 +533,7 @@ void sge_context_destroy(sge_context* c) {
     drainEvents(c->evMove); drainEvents(c->evPose); drainEvents(c->evSkin); drainEvents(c->evAgents); drainEvents(c->evBlas);
     DevBuf* bufs[] = {&c->dSlotBone, &c->dParent, &c->dDepth, &c->dLeanChain, &c->dPath, &c->dBindLocal, &c->dInvBind, &c->dRestT, &c->dRawRestT, &c->dPreRot,
                       &c->dCoeffs, &c->dCoeffCount, &c->dBonePresent, &c->dMeshPos, &c->dMeshNrm, &c->dMeshTan, &c->dMeshIdx, &c->dMeshWgt,
-                      &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dSlotOfRank, &c->dCost, &c->dHint, &c->dHeavyFlags, &c->dJobTable, &c->dBlockJob, &c->dLists, &c->dListCounts, &c->dOrderHist, &c->dWaveProf, &c->dSepAgents, &c->dSepCounts, &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
+                      &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dSlotOfRank, &c->dCost, &c->dHint, &c->dHeavyFlags, &c->dJobTable, &c->dBlockJob, &c->dLists, &c->dListCounts, &c->dOrderHist, &c->dWaveProf, &c->dSepAgents, &c->dSepCounts, &c->dSepFlow, &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
                       &c->dPalettes[0], &c->dPalettes[1], &c->dPoseModel, &c->dPoseLocal, &c->dMoveScratch, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
                       &c->dCellCursor, &c->dAgentMinMax, &c->dAgentGrid, &c->dAgentsAll, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats,
                       &c->dBlasEntryLink, &c->dBlasWideFirst, &c->dBlasWideParent, &c->dBlasWideLevel, &c->dBlasSlotIdx, &c->dBlasSlotTri,
@@ -1274,6 +1279,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         // (+ 50 % + 8), not the cap — every workgroup of that grid, the ones beyond the list included, has to find a CU with two
         // free places per SIMD. The list is cut to the grid (classify_kernel); whoever does not fit stays with the grouped launch,
         // which gives the same result. -1: nothing has come back yet.
+        if (st & SGE_STAGE_MOVE) c->lastMoveCount = count;
         if (c->hHeavyDemand) {
             const int demand = *(volatile int*)c->hHeavyDemand;
             if (demand >= 0) L.heavyCap = std::min(c->heavyCap, demand + demand / 2 + 8);
@@ -1289,13 +1295,14 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
     }
     if (st & SGE_STAGE_SEPARATION) { // AgentSeparationSystem: after the move stage, before the animation stages (DemoScene.swift:66-71)
         if (first != 0 || count != c->crowd.count) { set_error("SGE_STAGE_SEPARATION works on the whole crowd (first = 0, count = all)"); return SGE_ERR_INVALID; }
-        if (c->crowd.count > SGE_MAX_SEPARATION_AGENTS) { set_error("SGE_STAGE_SEPARATION: more than SGE_MAX_SEPARATION_AGENTS characters in this context"); return SGE_ERR_CAPACITY; }
         if (c->col.root < 0 && c->col.triCount != 0) { set_error("collision world not built"); return SGE_ERR_STATE; }
         int rc;
-        if ((rc = c->dSepAgents.alloc((size_t)SGE_MAX_SEPARATION_AGENTS * kSeparationAgentBytes)) != SGE_OK) return rc;
+        const size_t sepAgents = (size_t)std::max(c->crowd.count, (int)SGE_MAX_SEPARATION_AGENTS);
+        if ((rc = c->dSepAgents.alloc(sepAgents * kSeparationAgentBytes)) != SGE_OK) return rc;
         if ((rc = c->dSepCounts.alloc(2 * sizeof(int))) != SGE_OK) return rc;
+        if ((rc = c->dSepFlow.alloc(separationFlowBytes(c->crowd.count))) != SGE_OK) return rc;
         launch_separation(c->crowd, c->col, c->separationIterations, c->separationMargin, c->separationHeightMargin, c->dSepAgents.p,
-                          c->dSepCounts.as<int>(), c->stream);
+                          c->dSepCounts.as<int>(), c->dSepFlow.p, c->stream);
     }
     if (st & (SGE_STAGE_LOCOMOTION | SGE_STAGE_ACTION | SGE_STAGE_POSE | SGE_STAGE_WRITEBACK)) {
         if ((st & SGE_STAGE_POSE) && (c->boneCount == 0 || c->prof.count == 0)) { set_error("pose stage needs a skeleton and motion profiles"); return SGE_ERR_STATE; }
@@ -1349,9 +1356,15 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         } else {
             {
                 Bracket br(c, &c->evSkin, ss);
-                const int quarters = !overlap ? 0 : c->residentSkinQuarters >= 0 ? c->residentSkinQuarters
-                                     : ((st & SGE_STAGE_MOVE) && count >= kResidentSkinCharacters ? 8 : 0);
-                launch_skin(L, ss, overlap ? c->overlapSkinWorkgroups : 0, c->dSkinQueue.as<int>(), quarters);
+                // resident workgroups or workgroups that hand their places over (see kResidentSkinCharacters)
+                int quarters = 0;
+                if (overlap && c->residentSkinQuarters >= 0) quarters = c->residentSkinQuarters;
+                else if (overlap && count >= kResidentSkinCharacters) {
+                    const long long evals = c->hHeavyDemand ? (long long)*(volatile int*)(c->hHeavyDemand + 1) : -1;
+                    const bool moveHeavy = (st & SGE_STAGE_MOVE) && evals > (long long)kMoveHeavyEvaluations * c->lastMoveCount;
+                    quarters = moveHeavy ? 0 : kResidentSkinQuarters;
+                }
+                launch_skin(L, ss, overlap ? c->overlapSkinWorkgroups : 0, c->dSkinQueue.as<int>(), quarters, c->residentSkinCharsPerUnit);
             }
             if (refit) { // RTAccelerationBuilder.build is enqueued right behind the skinning encoder (RayTracingScene.swift:35-43)
                 Bracket br(c, &c->evBlas, ss);
@@ -1621,6 +1634,18 @@ int sge_separation_params(sge_context* c, int32_t iterations, float separation_m
     c->separationIterations = iterations < 1 ? 1 : iterations; // max(1, iterations) :2146
     c->separationMargin = separation_margin;
     c->separationHeightMargin = height_margin;
+    return SGE_OK;
+}
+
+// diagnostics of the crowd path of the separation stage, last pass: out[0] listed agents, out[1] loops drawn, out[2] redo flags
+// (bit 0: an agent had more than 64 candidates, bit 1: an agent was pushed further than a cell; either: the pass ran serially)
+int sge_debug_separation(sge_context* c, int32_t* out) {
+    if (!c || !out) return SGE_ERR_INVALID;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!c->dSepFlow.p || c->crowd.count <= 0) return SGE_OK;
+    (void)hipSetDevice(c->device);
+    { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; }
+    SGE_HIP(hipMemcpy(out, reinterpret_cast<const char*>(c->dSepFlow.p) + separationFlowControlOffset(c->crowd.count), 16, hipMemcpyDeviceToHost));
     return SGE_OK;
 }
 

@@ -1546,61 +1546,19 @@ __device__ __forceinline__ int xcdRemap(int b, int n) {
 #endif
 }
 
-template <int PART, bool AGENTS, bool HEAVY = false>
-#ifndef SGE_MOVE_WAVES1
-#define SGE_MOVE_WAVES1 4
-#endif
-// (the multi-wave form: three waves per SIMD = at most 168 VGPRs, so that its 2 waves per SIMD fit into the 336 registers two resident
-// LBS wavefronts leave of a SIMD's 512; at the 176 the compiler takes when asked for less, the workgroup found no CU beside a resident
-// LBS launch and ran only after it: DESIGN.md 3.5)
-#ifndef SGE_HEAVY_WAVES_EU
-#define SGE_HEAVY_WAVES_EU 3
-#endif
-__global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? (SGE_CCD_EXCLUSIVE ? 2 : 4) : (HEAVY ? SGE_HEAVY_WAVES_EU : SGE_MOVE_WAVES1)) void move_kernel(MoveLaunch K) {
-    if (PART == 0) SGE_PAD_VGPRS();
-    if (HEAVY) SGE_HEAVY_PRIO();
-    // PART 1 may run over an index list (light / heavy characters of this step, see classify_kernel)
-    if (PART == 1 && K.list && (int)blockIdx.x >= *K.listCount) return;
-    const int e = (PART == 1 && K.list) ? K.list[blockIdx.x] : K.first + xcdRemap((int)blockIdx.x, K.count);
-    if (PART == 1 && !K.list && K.heavyFlags && K.heavyFlags[e]) return; // this character runs in the multi-wave launch
-    const int lane = laneId();
-    WaveStats st{0, 0, 0, 0, 0, 0, 0};
+// PART 0 of one character's step on LDS slot g (body / params / controller already there): intent, gravity, VelocityGate, contact-cache
+// decay, platform carry and the pre-sweep depenetration. Leaves the step's working set in msA[g] (phase MP_SLIDE, or MP_DONE when the
+// body does not move). Shared by move_kernel<0> (slot 0; the result crosses to part 1 through K.scratch) and by move_group_kernel,
+// which runs it for its own members at its head: the grouped launch then needs no launch in front of it.
+__device__ __forceinline__ void movePart0(const MoveLaunch& K, const int g, const int e, WaveStats& st, long long& pQuery) {
     const DevCollision& col = K.col;
-    const long long pT0 = (PART == 0 && K.waveProf) ? (long long)__builtin_amdgcn_s_memtime() : 0; // diagnostics (SGE_WAVE_PROF)
-    long long pQuery = 0;
-    if (HEAVY) {
-        if (threadIdx.x == 0) { hv.cmd = HCMD_NONE; hv.evalSum = 0; }
-        __syncthreads();
-        if (threadIdx.x >= kWave) { // helper waves
-            heavyHelperLoop(col, st);
-            if (K.stats && lane == 0 && st.trips) atomicAdd(&statShard(K.stats)[5], (unsigned long long)st.trips);
-            return;
-        }
-    }
-#ifdef SGE_CCD_TIMING
-    const long long tStart = (long long)__builtin_amdgcn_s_memtime();
-#endif
-    {   // 288 B of state: lanes copy dwords
-        const uint32_t* gb = reinterpret_cast<const uint32_t*>(K.crowd.bodies + e);
-        const uint32_t* gp = reinterpret_cast<const uint32_t*>(K.crowd.params + e);
-        const uint32_t* gc = reinterpret_cast<const uint32_t*>(K.crowd.controllers + e);
-        if (lane < 24) reinterpret_cast<uint32_t*>(&sBodyA[0])[lane] = gb[lane];
-        if (lane < 16) reinterpret_cast<uint32_t*>(&sParamsA[0])[lane] = gp[lane];
-        if (lane < 32) reinterpret_cast<uint32_t*>(&sCtrlA[0])[lane] = gc[lane];
-        __syncthreads();
-    }
-    sge_body_state& body = sBodyA[0];
-    const sge_controller_params& P = sParamsA[0];
-    sge_controller_state& C = sCtrlA[0];
-    MoveState& ms = msA[0];
+    sge_body_state& body = sBodyA[g];
+    const sge_controller_params& P = sParamsA[g];
+    sge_controller_state& C = sCtrlA[g];
+    MoveState& ms = msA[g];
     const float dt = K.dt;
     const F3 gravity{K.gx, K.gy, K.gz};
-    uint32_t* const scratch = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(K.scratch) + (size_t)e * kMoveScratchBytes);
-    if (PART == 1) {
-        if (lane < (int)(sizeof(MoveState) / 4)) reinterpret_cast<uint32_t*>(&ms)[lane] = scratch[lane];
-        __syncthreads();
-    }
-    if (PART == 0) {
+    {
         D3 velocity{body.linearVelocity[0], body.linearVelocity[1], body.linearVelocity[2]};
         // ---- PhysicsIntentSystem, controller branch (Systems.swift:217-247) ----
         if (K.stages & SGE_STAGE_INTENT) {
@@ -1631,16 +1589,11 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? (S
         ms.velocity = velocity;
     }
     const bool doMove = (K.stages & SGE_STAGE_MOVE) && body.bodyType != SGE_BODY_STATIC;
-    const bool hasAgent = (P.agentFlags & SGE_AGENT_PRESENT) != 0;
-    const bool selfSolid = hasAgent && (P.agentFlags & SGE_AGENT_SOLID);
-    const bool useAgents = AGENTS && (K.stages & SGE_STAGE_AGENTS) && selfSolid && K.agents.all != nullptr;
-    if (PART == 0) {
-        ms.position = toF(D3{body.position[0], body.position[1], body.position[2]});
-        ms.phase = MP_DONE;
-        ms.dt = dt; ms.gravity = gravity; ms.materials = col.materials; ms.aHave = 0; ms.aToi = 0; ms.aNormal = F3{0, 0, 0};
-        ms.sideContactCacheOnly = (K.stages & SGE_STAGE_SIDE_CONTACT_CACHE) ? 1 : 0;
-    }
-    if (PART == 0 && doMove) {
+    ms.position = toF(D3{body.position[0], body.position[1], body.position[2]});
+    ms.phase = MP_DONE;
+    ms.dt = dt; ms.gravity = gravity; ms.materials = col.materials; ms.aHave = 0; ms.aToi = 0; ms.aNormal = F3{0, 0, 0};
+    ms.sideContactCacheOnly = (K.stages & SGE_STAGE_SIDE_CONTACT_CACHE) ? 1 : 0;
+    if (doMove) {
         cacheDecay(C);
         if (K.platformCount > 0) { // applyPlatformDelta :1619-1633
             F3 platformDelta = platformCarryDelta(ms.position, P, K.platforms, K.platformCount);
@@ -1664,15 +1617,84 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? (S
         ms.nearGround = 0; ms.canSnap = 0; ms.gGrounded = 0; ms.gNear = 0;
     }
     __syncthreads();
+    // applyPreSweepDepenetration :1635-1656 — one overlap query per trip
+    while (ms.phase == MP_DEPEN) {
+        __syncthreads();
+        const long long pq = K.waveProf ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        const int nOverlap = waveCapsuleOverlapAll(col, ms.position, P.radius, P.halfHeight, 8, P.collisionMask, st);
+        if (K.waveProf) pQuery += (long long)__builtin_amdgcn_s_memtime() - pq;
+        consumeDepen(g, nOverlap);
+        __syncthreads();
+    }
+}
+
+template <int PART, bool AGENTS, bool HEAVY = false>
+#ifndef SGE_MOVE_WAVES1
+#define SGE_MOVE_WAVES1 4
+#endif
+// (the multi-wave form: three waves per SIMD = at most 168 VGPRs, so that its 2 waves per SIMD fit into the 336 registers two resident
+// LBS wavefronts leave of a SIMD's 512; at the 176 the compiler takes when asked for less, the workgroup found no CU beside a resident
+// LBS launch and ran only after it: DESIGN.md 3.5)
+#ifndef SGE_HEAVY_WAVES_EU
+#define SGE_HEAVY_WAVES_EU 3
+#endif
+__global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? (SGE_CCD_EXCLUSIVE ? 2 : 4) : (HEAVY ? SGE_HEAVY_WAVES_EU : SGE_MOVE_WAVES1)) void move_kernel(MoveLaunch K) {
+    if (PART == 0) SGE_PAD_VGPRS();
+    if (HEAVY) SGE_HEAVY_PRIO();
+    // PART 1 may run over an index list (light / heavy characters of this step, see classify_kernel)
+    // (so may PART 0: the multi-wave launch's characters take their part 0 in a launch of their own, see launch_move)
+    if (K.list && (int)blockIdx.x >= *K.listCount) return;
+    const int e = K.list ? K.list[blockIdx.x] : K.first + xcdRemap((int)blockIdx.x, K.count);
+    if (PART == 1 && !K.list && K.heavyFlags && K.heavyFlags[e]) return; // this character runs in the multi-wave launch
+    const int lane = laneId();
+    WaveStats st{0, 0, 0, 0, 0, 0, 0};
+    const DevCollision& col = K.col;
+    const long long pT0 = (PART == 0 && K.waveProf) ? (long long)__builtin_amdgcn_s_memtime() : 0; // diagnostics (SGE_WAVE_PROF)
+    long long pQuery = 0;
+    if (HEAVY) {
+        if (threadIdx.x == 0) { hv.cmd = HCMD_NONE; hv.evalSum = 0; }
+        __syncthreads();
+        if (threadIdx.x >= kWave) { // helper waves
+            heavyHelperLoop(col, st);
+            if (K.stats && lane == 0 && st.trips) atomicAdd(&statShard(K.stats)[5], (unsigned long long)st.trips);
+            return;
+        }
+    }
+#ifdef SGE_CCD_TIMING
+    const long long tStart = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    {   // 288 B of state: lanes copy dwords
+        const uint32_t* gb = reinterpret_cast<const uint32_t*>(K.crowd.bodies + e);
+        const uint32_t* gp = reinterpret_cast<const uint32_t*>(K.crowd.params + e);
+        const uint32_t* gc = reinterpret_cast<const uint32_t*>(K.crowd.controllers + e);
+        if (lane < 24) reinterpret_cast<uint32_t*>(&sBodyA[0])[lane] = gb[lane];
+        if (lane < 16) reinterpret_cast<uint32_t*>(&sParamsA[0])[lane] = gp[lane];
+        if (lane < 32) reinterpret_cast<uint32_t*>(&sCtrlA[0])[lane] = gc[lane];
+        __syncthreads();
+    }
+    sge_body_state& body = sBodyA[0];
+    const sge_controller_params& P = sParamsA[0];
+    sge_controller_state& C = sCtrlA[0]; (void)C;
+    MoveState& ms = msA[0];
+    const float dt = K.dt;
+    const F3 gravity{K.gx, K.gy, K.gz}; (void)gravity;
+    uint32_t* const scratch = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(K.scratch) + (size_t)e * kMoveScratchBytes);
+    if (PART == 1) {
+        if (lane < (int)(sizeof(MoveState) / 4)) reinterpret_cast<uint32_t*>(&ms)[lane] = scratch[lane];
+        __syncthreads();
+    }
+    if (PART == 0) movePart0(K, 0, e, st, pQuery);
+    const bool hasAgent = (P.agentFlags & SGE_AGENT_PRESENT) != 0;
+    const bool selfSolid = hasAgent && (P.agentFlags & SGE_AGENT_SOLID);
+    const bool useAgents = AGENTS && (K.stages & SGE_STAGE_AGENTS) && selfSolid && K.agents.all != nullptr;
+    __syncthreads();
 
     // Each trip issues at most one BVH query; each query routine is inlined exactly once (one per PART).
-    while (ms.phase != MP_DONE && (PART == 1 || ms.phase == MP_DEPEN)) {
+    while (PART == 1 && ms.phase != MP_DONE) {
         const int phase = ms.phase;
         // ---------------- 1. which query does this phase need? ----------------
-        bool doOverlap = false, doCast = false, blocking = false;
-        if (PART == 0) {
-            doOverlap = true;
-        } else if (phase == MP_SLIDE) {
+        bool doCast = false, blocking = false;
+        if (phase == MP_SLIDE) {
             // head of the slide loop :1674-1676
             float len = length(ms.remaining);
             if (ms.it >= P.maxSlideIterations || len < 1e-6f) { ms.phase = MP_GROUND_CENTER; __syncthreads(); continue; }
@@ -1719,17 +1741,10 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? (S
         }
         __syncthreads();
         // ---------------- 2. the query ----------------
-        int nOverlap = 0;
-        if (PART == 0 && doOverlap) {
-            const long long pq = K.waveProf ? (long long)__builtin_amdgcn_s_memtime() : 0;
-            nOverlap = waveCapsuleOverlapAll(col, ms.position, P.radius, P.halfHeight, 8, P.collisionMask, st);
-            if (K.waveProf) pQuery += (long long)__builtin_amdgcn_s_memtime() - pq;
-        }
         if (PART == 1 && doCast) waveCastRays<HEAVY>(col, P.radius, P.halfHeight, blocking, !blocking, P.minGroundDot, P.collisionMask, st,
                                                      HEAVY && phase == MP_GROUND_CENTER ? 1 : -1);
         // ---------------- 3. consume ----------------
-        if (PART == 0) consumeDepen(0, nOverlap);
-        else if (phase == MP_SLIDE) {
+        if (phase == MP_SLIDE) {
             if (AGENTS && useAgents) { // AgentSweepSolver.bestHit :1053-1091 (independent of the static hit)
                 const F3 remaining = ms.remaining;
                 const float selfRadius = (hasAgent && (P.agentFlags & SGE_AGENT_RADIUS_OVERRIDE)) ? P.agentRadiusOverride : P.radius;
@@ -1830,8 +1845,20 @@ __shared__ F3 sNearMin[kGroup], sNearMax[kGroup];
 #define SGE_BISECT_SPEC 1
 #endif
 // (at most 31 items are served per trip: every served item has at least two of the <= 63 idle lanes)
-__shared__ unsigned char sSpecOwner[kWave / 2];
-__shared__ unsigned sSpecBits[kWave / 2];
+constexpr int kSpecSlots = kWave / 2;
+__shared__ unsigned char sSpecOwner[kSpecSlots];
+__shared__ unsigned sSpecBits[kSpecSlots];
+// The bounds these LDS arrays rest on, checked where they are declared (an out-of-allocation LDS access aborts the queue; one working-tree
+// build of round 2 did): a served item's rank is < nServe <= nHelp / per with per >= 2 and nHelp <= kWave - 1 idle lanes
+// (the refining owner is not idle); a helper's node number is <= 14 + 1, a bit of one 32-bit word; a lane index fits the owner byte.
+static_assert((kWave - 1) / 2 <= kSpecSlots, "speculative bisection: ranks of served items");
+static_assert(14 + 2 <= 32, "speculative bisection: one bit per tree node in sSpecBits");
+static_assert(kWave <= 256, "speculative bisection: owner lane stored in a byte");
+// a traversal expands only while fewer than kWave candidates are pending and one expansion adds at most kWave: kWave - 1 + kWave;
+// the item queue is swept before a batch of kWave candidates x kMaxRays rays might not fit
+static_assert(kCandCap >= 2 * kWave - 1 && kRangeCap >= 2 * kWave - 1, "candidate / range lists");
+static_assert(kItemCap >= kWave + kWave * kMaxRays, "item queue: one gathered batch always fits an empty queue");
+static_assert(kRaySlots <= (1 << (32 - kItemRayShift)), "work item word: the ray slot has 32 - kItemRayShift bits");
 
 // One cast pass of character g, rays rb .. rb + R - 1 already in sh.rayFrom / sh.rayDelta: the per-ray setup of waveCastRays
 // (CollisionQuery.swift:1021-1035). Returns the number of valid rays and their union box.
@@ -2633,13 +2660,438 @@ __global__ __launch_bounds__(kWave, 3) void separation_post_kernel(SepLaunch K) 
     if (lane < 32) gc[lane] = reinterpret_cast<const uint32_t*>(&sCtrlA[0])[lane];
 }
 
+
+// ---------------------------------------------------------------------------
+// AgentSeparationSystem for crowds (more solid agents than one wavefront's LDS holds): the pair loop as a dataflow over agents
+// ---------------------------------------------------------------------------
+// What the reference's loop fixes is, per agent, the ORDER in which the loops of other agents read and write it:
+//   - loop i takes its copy `a` of agent i when every loop i' < i that can pair with i has done so (:1954), and after that nobody
+//     touches agent i but loop i itself (pairs are (i, j > i));
+//   - pair (i, j) reads and writes agent j after every pair (i', j) with i' < i (:1961, :1999-2000, :2040).
+// Loops that share no agent commute. So every agent c carries a counter ver[c] of the earlier loops that have PASSED it, and every
+// loop k knows, for each agent c it may touch, its rank among c's passers: it waits for ver[c] == rank, pairs with c (or not),
+// and stores ver[c] = rank + 1; loop c starts at ver[c] == need[c]. Who "may touch" whom is decided from the cells at the head of
+// the pass (the grid is fixed for the pass, :2187): loop k pairs with the agents in the 3 x 3 cells around its LIVE cell (:1955-1960),
+// which is at most one cell away from its cell at the head of the pass unless it has been pushed further than a cell (checked; the
+// pass is then redone serially) — so the agents c > k in the 5 x 5 cells around k's pass-start cell are its candidates, and it passes
+// all of them: the ones it pairs with in the reference's order, the others afterwards. (Ordering only agents that start the pass
+// close enough to meet — one cell + what two agents may move — shortens the chains but needs a bound on every agent's movement
+// in the pass; a quarter cell and half a cell were both exceeded in crowded scenes, 3 of 45 and 1 of 45 steps of the 192-agent
+// test, every step of an 8,192-agent crowd without character-vs-character sweeps, and each miss costs a serial pass.) Wavefronts draw loops from a ticket counter in index order, so the lowest
+// unfinished loop never waits for an unfinished one: no deadlock, whatever the number of resident wavefronts.
+// Positions and velocities cross CUs (and XCDs) through agent-scope atomic loads / stores; a release is the data stores, a wait for
+// them, then the counter store (MI355X_MICROARCH.md, "Valid forms"). The result is the reference's, bit for bit, for any crowd;
+// what varies is the depth of the dependency graph (tools/separation_depth.py prints it).
+constexpr int kSepMaxCand = 256; // candidates a loop tracks (agents of higher index in its 5 x 5 cells); more: the pass runs serially
+struct SepFlow {
+    int* cell;          // [n][2] cell of every agent at the head of the pass (:1940-1944)
+    int* bucketStart;   // [H + 1] hashed cells: agents sorted by (bucket, index)
+    int* bucketCursor;  // [H]
+    int* bucketItems;   // [n]
+    int* need;          // [n] agents of lower index in the 5 x 5 cells around the agent
+    int* ver;           // [n] how many of them have passed it
+    int* candCount;     // [n]
+    int2* cand;         // [n][kSepMaxCand] (agent of higher index in the 5 x 5 cells, this loop's rank among that agent's passers)
+    int* control;       // [0] listed agents, [1] ticket, [2] redo flag of the pass, [3] cell size (float bits), [4] depth diagnostics
+    float* backup;      // [n][6] position, velocity at the head of the pass
+    int H;
+};
+__device__ __forceinline__ unsigned sepHash(int cx, int cz, int H) { return ((unsigned)cx * 73856093u ^ (unsigned)cz * 19349663u) & (unsigned)(H - 1); }
+__device__ __forceinline__ float sepLoad(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sepStore(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ F3 sepLoad3(const float* p) { return F3{sepLoad(p), sepLoad(p + 1), sepLoad(p + 2)}; }
+__device__ __forceinline__ void sepStore3(float* p, F3 v) { sepStore(p, v.x); sepStore(p + 1, v.y); sepStore(p + 2, v.z); }
+__device__ __forceinline__ void sepWait(const int* counter, int value) {
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != value) __builtin_amdgcn_s_sleep(2);
+}
+__device__ __forceinline__ void sepRelease(int* counter, int value) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the data stores of this wavefront have left it
+    __hip_atomic_store(counter, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the agent list (:2166-2187) in character order, its size and the cell size: one workgroup, ordered compaction
+__global__ __launch_bounds__(1024) void sep_list_kernel(SepLaunch K, SepFlow F) {
+    __shared__ int sWaveCount[16];
+    __shared__ float sWaveMax[16];
+    __shared__ int sBase;
+    const int N = K.crowd.count, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) sBase = 0;
+    float maxRadius = 0;
+    __syncthreads();
+    for (int base = 0; base < N; base += 1024) {
+        const int e = base + tid;
+        bool solid = false;
+        float radius = 0, invWeight = 0;
+        if (e < N) {
+            const sge_controller_params& P = K.crowd.params[e];
+            const bool present = (P.agentFlags & SGE_AGENT_PRESENT) != 0;
+            solid = present ? (P.agentFlags & SGE_AGENT_SOLID) != 0 : true; // aStore[e] ?? AgentCollisionComponent()
+            radius = (present && (P.agentFlags & SGE_AGENT_RADIUS_OVERRIDE)) ? P.agentRadiusOverride : P.radius;
+            const float massWeight = present ? P.agentMassWeight : 1.0f;
+            invWeight = massWeight > 0 ? 1.0f / massWeight : 0.0f;
+        }
+        const unsigned long long m = __ballot(solid);
+        if (lane == 0) sWaveCount[wv] = __popcll(m);
+        __syncthreads();
+        int off = sBase;
+        for (int w = 0; w < wv; ++w) off += sWaveCount[w];
+        if (solid) {
+            const int idx = off + prefixCount(m);
+            const sge_body_state& b = K.crowd.bodies[e];
+            SepAgentDev a;
+            for (int k = 0; k < 3; ++k) { a.position[k] = (float)b.position[k]; a.velocity[k] = (float)b.linearVelocity[k]; a.start[k] = a.position[k]; }
+            a.radius = radius; a.halfHeight = K.crowd.params[e].halfHeight; a.invWeight = invWeight; a.entity = e; a.pad = 0;
+            K.agents[idx] = a;
+            maxRadius = smax(maxRadius, radius);
+        }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += sWaveCount[w]; sBase += t; }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxRadius = smax(maxRadius, __shfl_xor(maxRadius, o, kWave));
+    if (lane == 0) sWaveMax[wv] = maxRadius;
+    __syncthreads();
+    if (tid == 0) {
+        float r = 0;
+        for (int w = 0; w < 16; ++w) r = smax(r, sWaveMax[w]);
+        const int n = sBase;
+        const bool run = !(N <= 1 || n <= 1); // guards :2153, :2189
+        F.control[0] = run ? n : 0;
+        F.control[3] = __float_as_int(smax(r * 2 + K.separationMargin, 0.001f));
+        K.count[0] = run ? n : 0;
+    }
+}
+
+// head of a pass: grid.rebuild (:1930-1936) as hashed buckets; counters back to zero; the pass's start state kept for a serial redo
+__global__ void sep_cells_kernel(SepLaunch K, SepFlow F) {
+    const int n = F.control[0], i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { F.control[1] = 0; F.control[2] = 0; }
+    if (i >= n) return;
+    const float cellSize = __int_as_float(F.control[3]);
+    const SepAgentDev& a = K.agents[i];
+    const int cx = (int)floorf(a.position[0] / cellSize), cz = (int)floorf(a.position[2] / cellSize);
+    F.cell[2 * i] = cx; F.cell[2 * i + 1] = cz;
+    atomicAdd(&F.bucketCursor[sepHash(cx, cz, F.H)], 1);
+    F.ver[i] = 0;
+    for (int k = 0; k < 3; ++k) { F.backup[i * 6 + k] = a.position[k]; F.backup[i * 6 + 3 + k] = a.velocity[k]; }
+}
+// exclusive scan of the bucket counts (one workgroup; every thread a contiguous run), counts -> zero (they become the scatter cursors)
+__global__ __launch_bounds__(1024) void sep_scan_kernel(SepFlow F) {
+    __shared__ int sPart[1024];
+    const int tid = threadIdx.x, per = (F.H + 1023) / 1024, lo = tid * per, hi = min(F.H, lo + per);
+    int s = 0;
+    for (int b = lo; b < hi; ++b) s += F.bucketCursor[b];
+    sPart[tid] = s;
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int t = 0; t < 1024; ++t) { const int c = sPart[t]; sPart[t] = run; run += c; } F.bucketStart[F.H] = run; }
+    __syncthreads();
+    int run = sPart[tid];
+    for (int b = lo; b < hi; ++b) { const int c = F.bucketCursor[b]; F.bucketStart[b] = run; F.bucketCursor[b] = 0; run += c; }
+}
+__global__ void sep_scatter_kernel(SepFlow F) {
+    const int n = F.control[0], i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned b = sepHash(F.cell[2 * i], F.cell[2 * i + 1], F.H);
+    F.bucketItems[F.bucketStart[b] + atomicAdd(&F.bucketCursor[b], 1)] = i;
+}
+// a cell's list is in agent order (:1934-1937): sort every bucket by index (a handful of entries each)
+__global__ void sep_sort_kernel(SepFlow F) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= F.H) return;
+    const int lo = F.bucketStart[b], hi = F.bucketStart[b + 1];
+    for (int p = lo + 1; p < hi; ++p) {
+        const int v = F.bucketItems[p];
+        int q = p - 1;
+        while (q >= lo && F.bucketItems[q] > v) { F.bucketItems[q + 1] = F.bucketItems[q]; --q; }
+        F.bucketItems[q + 1] = v;
+    }
+}
+// agents in the 5 x 5 cells around (cx, cz) with index below `limit`
+__device__ __forceinline__ int sepCountBelow(const SepFlow& F, int cx, int cz, int limit) {
+    int cnt = 0;
+    for (int dz = -2; dz <= 2; ++dz)
+        for (int dx = -2; dx <= 2; ++dx) {
+            const int tx = cx + dx, tz = cz + dz;
+            const unsigned b = sepHash(tx, tz, F.H);
+            for (int p = F.bucketStart[b]; p < F.bucketStart[b + 1]; ++p) {
+                const int x = F.bucketItems[p];
+                if (x >= limit) break; // sorted by index
+                if (F.cell[2 * x] == tx && F.cell[2 * x + 1] == tz) cnt += 1;
+            }
+        }
+    return cnt;
+}
+// per agent k (one wavefront): need[k], its candidates (agents c > k in the 5 x 5 cells) and k's rank among each candidate's passers
+__global__ __launch_bounds__(kWave) void sep_cand_kernel(SepFlow F) {
+    __shared__ int sCount;
+    __shared__ int sList[kSepMaxCand];
+    const int n = F.control[0], k = blockIdx.x, lane = laneId();
+    if (k >= n) return;
+    if (lane == 0) sCount = 0;
+    __syncthreads();
+    const int cx = F.cell[2 * k], cz = F.cell[2 * k + 1];
+    int below = 0;
+    if (lane < 25) { // one cell of the 5 x 5 per lane
+        const int tx = cx + lane % 5 - 2, tz = cz + lane / 5 - 2;
+        const unsigned b = sepHash(tx, tz, F.H);
+        for (int p = F.bucketStart[b]; p < F.bucketStart[b + 1]; ++p) {
+            const int x = F.bucketItems[p];
+            if (F.cell[2 * x] != tx || F.cell[2 * x + 1] != tz) continue;
+            if (x < k) below += 1;
+            else if (x > k) { const int pos = atomicAdd(&sCount, 1); if (pos < kSepMaxCand) sList[pos] = x; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o, kWave);
+    __syncthreads();
+    const int total = sCount, nc = total < kSepMaxCand ? total : kSepMaxCand;
+    if (lane == 0) {
+        F.need[k] = below;
+        F.candCount[k] = nc;
+        if (total > kSepMaxCand) atomicOr(&F.control[2], 1); // more neighbours than a loop tracks: the pass runs serially
+    }
+    for (int l = lane; l < nc; l += kWave) {
+        const int c = sList[l];
+        F.cand[(size_t)k * kSepMaxCand + l] = make_int2(c, sepCountBelow(F, F.cell[2 * c], F.cell[2 * c + 1], k));
+    }
+}
+
+struct SepPairAgent { float radius, halfHeight, invWeight, skinWidth, minGroundDot; uint32_t mask; };
+// One pair of AgentSeparationResolver.resolve (:1961-2040): `aPos` / `aVel` are loop i's copy of agent i, posI / velI its live entry,
+// bPos / bVel agent j's (live). Returns true when agent j's entry changed.
+__device__ __forceinline__ bool sepPair(const DevCollision& col, const SepPairAgent& A, const SepPairAgent& B, F3 aPos, F3 aVel, F3& posI, F3& velI,
+                                        F3& bPos, F3& bVel, float separationMargin, float heightMargin, WaveStats& st) {
+    const float aMin = aPos.y - A.halfHeight, aMax = aPos.y + A.halfHeight;
+    const float bMin = bPos.y - B.halfHeight, bMax = bPos.y + B.halfHeight;
+    const float ddx = aPos.x - bPos.x, ddz = aPos.z - bPos.z;
+    const float distSq = ddx * ddx + ddz * ddz;
+    const float skinAllowance = smin(A.skinWidth, B.skinWidth);
+    const float margin = smin(separationMargin, skinAllowance);
+    const float minDist = A.radius + B.radius + margin;
+    const bool heightSeparated = aMax < bMin - heightMargin || aMin > bMax + heightMargin;
+    if (heightSeparated) return false;
+    if (distSq >= minDist * minDist) return false;
+    const float dist = sqrtf(smax(distSq, 1e-8f));
+    const float nx = ddx / dist, nz = ddz / dist;
+    const float penetration = minDist - dist;
+    const float wSum = A.invWeight + B.invWeight;
+    if (wSum <= 0) return false;
+    const float corr = penetration / wSum;
+    F3 moveA{nx * corr * A.invWeight, 0, nz * corr * A.invWeight};
+    F3 moveB{-nx * corr * B.invWeight, 0, -nz * corr * B.invWeight};
+    const F3 relV = aVel - bVel;
+    const float vn = relV.x * nx + relV.z * nz;
+    if (vn < 0) {
+        const float impulse = -vn;
+        const float scaleA = A.invWeight / wSum, scaleB = B.invWeight / wSum;
+        velI.x += nx * impulse * scaleA; velI.z += nz * impulse * scaleA;
+        bVel.x -= nx * impulse * scaleB; bVel.z -= nz * impulse * scaleB;
+    }
+    // the two blocking casts of :2004-2027 as one pass: ray 0 = agent i along moveA, ray 1 = agent j along moveB
+    const float eps = 1e-6f;
+    const bool castA = length(moveA) > eps, castB = length(moveB) > eps;
+    bool blockedA = false, blockedB = false;
+    if (castA || castB) {
+        __syncthreads();
+        sh.rayFrom[0] = posI; sh.rayDelta[0] = castA ? moveA : F3{0, 0, 0};
+        sh.rayFrom[1] = bPos; sh.rayDelta[1] = castB ? moveB : F3{0, 0, 0};
+        __syncthreads();
+        int itemCount = 0;
+        F3 minP, maxP;
+        if (groupSetupRays(col, 0, 1, A.radius, A.halfHeight, true, false, 0.0f, minP, maxP) > 0)
+            groupGather(col, 0, 1, minP, maxP, A.radius, false, 0.0f, A.mask, itemCount, st);
+        if (groupSetupRays(col, 1, 1, B.radius, B.halfHeight, true, false, 0.0f, minP, maxP) > 0)
+            groupGather(col, 1, 1, minP, maxP, B.radius, false, 0.0f, B.mask, itemCount, st);
+        groupSweep(col, itemCount, st);
+        blockedA = castA && rayHit(0) && sh.rayRec[0].toi <= A.skinWidth && sh.rayRec[0].normal.y < A.minGroundDot;
+        blockedB = castB && rayHit(1) && sh.rayRec[1].toi <= B.skinWidth && sh.rayRec[1].normal.y < B.minGroundDot;
+        __syncthreads();
+    }
+    if (blockedA && !blockedB) {
+        moveA = F3{0, 0, 0};
+        moveB = F3{-nx * penetration, 0, -nz * penetration};
+    } else if (blockedB && !blockedA) {
+        moveB = F3{0, 0, 0};
+        moveA = F3{nx * penetration, 0, nz * penetration};
+    } else if (blockedA && blockedB) {
+        return vn < 0; // (:2035 `continue` comes after the velocity update)
+    }
+    posI = posI + moveA;
+    bPos = bPos + moveB;
+    return true;
+}
+__device__ __forceinline__ SepPairAgent sepPairAgent(const SepLaunch& K, const SepAgentDev& a) {
+    const sge_controller_params& P = K.crowd.params[a.entity];
+    return SepPairAgent{a.radius, a.halfHeight, a.invWeight, P.skinWidth, P.minGroundDot, P.collisionMask};
+}
+
+// the pair loops of one pass, one wavefront per loop, loops drawn in index order
+__global__ __launch_bounds__(kWave, 2) void sep_flow_kernel(SepLaunch K, SepFlow F) {
+    __shared__ int2 sCand[kSepMaxCand];
+    __shared__ unsigned long long sPassed[kSepMaxCand / 64]; // candidates this loop has passed already
+    __shared__ int sTicket;
+    const int lane = laneId();
+    const DevCollision& col = K.col;
+    WaveStats st{0, 0, 0, 0, 0, 0, 0};
+    const int n = F.control[0];
+    if (n <= 1) return;
+    if (__hip_atomic_load(&F.control[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) return; // the candidate lists overflowed: serial pass
+    const float cellSize = __int_as_float(F.control[3]);
+    while (true) {
+        __syncthreads();
+        if (lane == 0) sTicket = atomicAdd(&F.control[1], 1);
+        __syncthreads();
+        const int i = sTicket;
+        if (i >= n) break;
+        const int nc = F.candCount[i];
+        for (int l = lane; l < nc; l += kWave) sCand[l] = F.cand[(size_t)i * kSepMaxCand + l];
+        if (lane < kSepMaxCand / 64) sPassed[lane] = 0;
+        __syncthreads();
+        sepWait(&F.ver[i], F.need[i]); // every earlier loop that can pair with agent i has passed it
+        SepAgentDev* Ai = K.agents + i;
+        const F3 aPos = sepLoad3(Ai->position), aVel = sepLoad3(Ai->velocity); // the copy `a` (:1954)
+        const SepPairAgent A = sepPairAgent(K, *Ai);
+        F3 posI = aPos, velI = aVel;
+        const int cx = (int)floorf(aPos.x / cellSize), cz = (int)floorf(aPos.z / cellSize);
+        {   // the pair list of :1955-1960 hangs on the LIVE cell: its 3 x 3 cells lie inside the 5 x 5 the candidates were taken from
+            // as long as the agent has not been pushed further than one cell since the head of the pass
+            const int d0 = cx - F.cell[2 * i], d1 = cz - F.cell[2 * i + 1];
+            if ((d0 < -1 || d0 > 1 || d1 < -1 || d1 > 1) && lane == 0) atomicOr(&F.control[2], 2); // redo serially
+        }
+        for (int dz = -1; dz <= 1; ++dz) {
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int tx = cx + dx, tz = cz + dz;
+                const unsigned b = sepHash(tx, tz, F.H);
+                const int pEnd = F.bucketStart[b + 1];
+                for (int p = F.bucketStart[b]; p < pEnd; ++p) {
+                    const int j = F.bucketItems[p];
+                    if (j <= i || F.cell[2 * j] != tx || F.cell[2 * j + 1] != tz) continue;
+                    int slot = -1;
+                    for (int base = 0; base < nc && slot < 0; base += kWave) {
+                        const int l = base + lane;
+                        const unsigned long long hit = __ballot(l < nc && sCand[l < nc ? l : 0].x == j);
+                        if (hit) slot = base + __ffsll((long long)hit) - 1;
+                    }
+                    if (slot < 0) { if (lane == 0) atomicOr(&F.control[2], 2); continue; } // (only after the cell check above has fired)
+                    const int rank = sCand[slot].y;
+                    sepWait(&F.ver[j], rank);
+                    SepAgentDev* Aj = K.agents + j;
+                    F3 bPos = sepLoad3(Aj->position), bVel = sepLoad3(Aj->velocity);
+                    const SepPairAgent B = sepPairAgent(K, *Aj);
+                    if (sepPair(col, A, B, aPos, aVel, posI, velI, bPos, bVel, K.separationMargin, K.heightMargin, st)) {
+                        if (lane == 0) { sepStore3(Aj->position, bPos); sepStore3(Aj->velocity, bVel); }
+                    }
+                    if (lane == 0) { sepRelease(&F.ver[j], rank + 1); sPassed[slot >> 6] |= 1ull << (slot & 63); }
+                }
+            }
+        }
+        __syncthreads();
+        for (int slot = 0; slot < nc; ++slot) { // the candidates this loop does not pair with, in their turn
+            if ((sPassed[slot >> 6] >> (slot & 63)) & 1) continue;
+            const int c = sCand[slot].x, rank = sCand[slot].y;
+            sepWait(&F.ver[c], rank);
+            if (lane == 0) __hip_atomic_store(&F.ver[c], rank + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) { sepStore3(Ai->position, posI); sepStore3(Ai->velocity, velI); } // nobody reads it before the pass ends
+    }
+}
+
+// the same pass by ONE wavefront in the reference's own order, from the state at the head of the pass: runs only when the dataflow
+// pass gave up (more than kSepMaxCand candidates for some agent, or an agent pushed further than a cell)
+__global__ __launch_bounds__(kWave) void sep_serial_kernel(SepLaunch K, SepFlow F) {
+    const int lane = laneId();
+    const DevCollision& col = K.col;
+    WaveStats st{0, 0, 0, 0, 0, 0, 0};
+    const int n = F.control[0];
+    if (n <= 1 || F.control[2] == 0) return;
+    const float cellSize = __int_as_float(F.control[3]);
+    for (int i = lane; i < n; i += kWave)
+        for (int k = 0; k < 3; ++k) { sepStore(&K.agents[i].position[k], F.backup[i * 6 + k]); sepStore(&K.agents[i].velocity[k], F.backup[i * 6 + 3 + k]); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        SepAgentDev* Ai = K.agents + i;
+        const F3 aPos = sepLoad3(Ai->position), aVel = sepLoad3(Ai->velocity);
+        const SepPairAgent A = sepPairAgent(K, *Ai);
+        F3 posI = aPos, velI = aVel;
+        const int cx = (int)floorf(aPos.x / cellSize), cz = (int)floorf(aPos.z / cellSize);
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int tx = cx + dx, tz = cz + dz;
+                const unsigned b = sepHash(tx, tz, F.H);
+                const int pEnd = F.bucketStart[b + 1];
+                for (int p = F.bucketStart[b]; p < pEnd; ++p) {
+                    const int j = F.bucketItems[p];
+                    if (j <= i || F.cell[2 * j] != tx || F.cell[2 * j + 1] != tz) continue;
+                    SepAgentDev* Aj = K.agents + j;
+                    F3 bPos = sepLoad3(Aj->position), bVel = sepLoad3(Aj->velocity);
+                    const SepPairAgent B = sepPairAgent(K, *Aj);
+                    if (sepPair(col, A, B, aPos, aVel, posI, velI, bPos, bVel, K.separationMargin, K.heightMargin, st)) {
+                        if (lane == 0) { sepStore3(Aj->position, bPos); sepStore3(Aj->velocity, bVel); }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                }
+            }
+        if (lane == 0) { sepStore3(Ai->position, posI); sepStore3(Ai->velocity, velI); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+int separationFlowBuckets(int count);
+// byte offset of SepFlow::control inside the scratch buffer (diagnostics: sge_debug_separation)
+size_t separationFlowControlOffset(int count) {
+    const size_t n = (size_t)count, H = (size_t)separationFlowBuckets(count);
+    auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    return up(8 * n) + up(4 * (H + 1)) + up(4 * H) + up(4 * n) * 4 + up(sizeof(int2) * kSepMaxCand * n);
+}
+size_t separationFlowBytes(int count) {
+    const size_t n = (size_t)count, H = (size_t)separationFlowBuckets(count);
+    return 8 * n + 4 * (H + 1) + 4 * H + 4 * n * 4 + sizeof(int2) * kSepMaxCand * n + 64 + 24 * n + 256;
+}
+int separationFlowBuckets(int count) { int H = 64; while (H < 2 * count) H <<= 1; return H; }
+
 void launch_separation(const DevCrowd& crowd, const DevCollision& col, int iterations, float separationMargin, float heightMargin,
-                       void* agentScratch, int* counts, hipStream_t s) {
+                       void* agentScratch, int* counts, void* flowScratch, hipStream_t s) {
     if (crowd.count <= 1) return;
     SepLaunch K{crowd, col, iterations < 1 ? 1 : iterations, separationMargin, heightMargin, reinterpret_cast<SepAgentDev*>(agentScratch), counts};
-    hipLaunchKernelGGL(separation_resolve_kernel, dim3(1), dim3(kWave), 0, s, K);
-    const int grid = crowd.count < SGE_MAX_SEPARATION_AGENTS ? crowd.count : SGE_MAX_SEPARATION_AGENTS;
-    hipLaunchKernelGGL(separation_post_kernel, dim3(grid), dim3(kWave), 0, s, K);
+    const bool forceFlow = getenv("SGE_SEPARATION_FLOW") && atoi(getenv("SGE_SEPARATION_FLOW")) != 0; // tests: the crowd path on a small crowd
+    if (crowd.count <= SGE_MAX_SEPARATION_AGENTS && !forceFlow) { // the reference's scale: one wavefront, everything in LDS
+        hipLaunchKernelGGL(separation_resolve_kernel, dim3(1), dim3(kWave), 0, s, K);
+        hipLaunchKernelGGL(separation_post_kernel, dim3(crowd.count), dim3(kWave), 0, s, K);
+        return;
+    }
+    const int n = crowd.count, H = separationFlowBuckets(n);
+    SepFlow F;
+    char* p = reinterpret_cast<char*>(flowScratch);
+    auto carve = [&](size_t bytes) { char* q = p; p += (bytes + 15) & ~(size_t)15; return q; };
+    F.cell = reinterpret_cast<int*>(carve(8 * (size_t)n));
+    F.bucketStart = reinterpret_cast<int*>(carve(4 * ((size_t)H + 1)));
+    F.bucketCursor = reinterpret_cast<int*>(carve(4 * (size_t)H));
+    F.bucketItems = reinterpret_cast<int*>(carve(4 * (size_t)n));
+    F.need = reinterpret_cast<int*>(carve(4 * (size_t)n));
+    F.ver = reinterpret_cast<int*>(carve(4 * (size_t)n));
+    F.candCount = reinterpret_cast<int*>(carve(4 * (size_t)n));
+    F.cand = reinterpret_cast<int2*>(carve(sizeof(int2) * kSepMaxCand * (size_t)n));
+    F.control = reinterpret_cast<int*>(carve(64));
+    F.backup = reinterpret_cast<float*>(carve(24 * (size_t)n));
+    F.H = H;
+    const int blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(sep_list_kernel, dim3(1), dim3(1024), 0, s, K, F);
+    for (int it = 0; it < K.iterations; ++it) {
+        (void)hipMemsetAsync(F.bucketCursor, 0, 4 * (size_t)H, s);
+        hipLaunchKernelGGL(sep_cells_kernel, dim3(blocks), dim3(256), 0, s, K, F);
+        hipLaunchKernelGGL(sep_scan_kernel, dim3(1), dim3(1024), 0, s, F);
+        hipLaunchKernelGGL(sep_scatter_kernel, dim3(blocks), dim3(256), 0, s, F);
+        hipLaunchKernelGGL(sep_sort_kernel, dim3((H + 255) / 256), dim3(256), 0, s, F);
+        hipLaunchKernelGGL(sep_cand_kernel, dim3(n), dim3(kWave), 0, s, F);
+        // as many wavefronts as stay resident together do useful work; more would only queue behind them
+        const int waves = std::min(n, currentDeviceCUs() * 8);
+        hipLaunchKernelGGL(sep_flow_kernel, dim3(waves), dim3(kWave), 0, s, K, F);
+        hipLaunchKernelGGL(sep_serial_kernel, dim3(1), dim3(kWave), 0, s, K, F);
+    }
+    hipLaunchKernelGGL(separation_post_kernel, dim3(n), dim3(kWave), 0, s, K);
 }
 
 // Picks this step's heavy characters by last step's sweep cost: flags[e] = 1 and an entry in the heavy list (at most
@@ -2650,7 +3102,9 @@ __device__ __forceinline__ int costBucket(int cost) { const int b = cost >> 7; r
 __global__ void classify_kernel(const int* cost, int first, int count, int threshold, int heavyCap, int* lists, int* counts,
                                 uint8_t* flags, int* hist) {
     __shared__ int h[kCostBuckets];
+    __shared__ int hTotal;
     if (threadIdx.x < kCostBuckets) h[threadIdx.x] = 0;
+    if (threadIdx.x == 0) hTotal = 0;
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) {
@@ -2664,8 +3118,10 @@ __global__ void classify_kernel(const int* cost, int first, int count, int thres
         }
         flags[e] = heavy;
         if (!heavy) atomicAdd(&h[costBucket(cost[e])], 1);
+        atomicAdd(&hTotal, cost[e] < 0 ? 0 : cost[e]);
     }
     __syncthreads();
+    if (threadIdx.x == 0 && hTotal) atomicAdd(&counts[3], hTotal); // the crowd's distance evaluations of the last step (schedule choice, sge_tick)
     if (threadIdx.x < kCostBuckets && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
 // hist[0..32) -> start of every class in the order list, most expensive class first (hist[32..64) = scatter cursors); zeroes the
@@ -2706,10 +3162,13 @@ __global__ void order_scatter_kernel(const int* cost, int first, int count, cons
 
 void launch_move(const MoveLaunch& L, hipStream_t s) {
     if (L.count <= 0) return;
+    static const bool grouped = !(getenv("SGE_MOVE_GROUP") && atoi(getenv("SGE_MOVE_GROUP")) == 0);
+    // (part 0 at the head of the grouped launch instead — no launch in front of the stage, no round trip of the working set — was
+    // built and measured: the grouped kernel then needs 166 registers instead of 155, one wavefront fewer fits beside two resident
+    // LBS wavefronts, and the step is 1-6 % slower: 0.998 against 0.987 ms, against 0.937 with 155)
     hipLaunchKernelGGL((move_kernel<0, false>), dim3(L.count), dim3(kWave), 0, s, L);
     if (!(L.stages & SGE_STAGE_MOVE)) return;
     const bool agents = (L.stages & SGE_STAGE_AGENTS) && L.agents.all;
-    static const bool grouped = !(getenv("SGE_MOVE_GROUP") && atoi(getenv("SGE_MOVE_GROUP")) == 0);
     static const int ldsPad = getenv("SGE_MOVE_LDS_PAD") ? atoi(getenv("SGE_MOVE_LDS_PAD")) : 0; // experiments: caps workgroups per CU
     static const int soloSetting = getenv("SGE_GROUP_SOLO") ? atoi(getenv("SGE_GROUP_SOLO")) : 128; // experiments
     const int solo = grouped ? std::max(0, std::min(soloSetting, L.count / 16)) : 0;
@@ -2737,7 +3196,7 @@ void launch_move(const MoveLaunch& L, hipStream_t s) {
         else hipLaunchKernelGGL((move_kernel<1, false, true>), dim3(heavyGrid), dim3(kWave * kHeavyWaves), 0, s, H);
         (void)hipStreamWaitEvent(gs, L.evClassified, 0);
         // how many characters asked for the multi-wave launch: read by the host when it enqueues a later step (pinned memory)
-        if (L.heavyDemandHost) (void)hipMemcpyAsync(L.heavyDemandHost, L.listCounts + 2, sizeof(int), hipMemcpyDeviceToHost, gs);
+        if (L.heavyDemandHost) (void)hipMemcpyAsync(L.heavyDemandHost, L.listCounts + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, gs);
     }
     if (grouped) {
         hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, gs, L.orderHist, L.listCounts);

@@ -225,7 +225,7 @@ struct MoveLaunch {
     uint8_t* heavyFlags;         // [crowd.count] 1: taken by the multi-wave launch this step
     int heavyThreshold, heavyCap;
     hipStream_t heavyStream; hipEvent_t evClassified, evHeavyDone; // second stream of the move stage (the grouped launch runs there)
-    int* heavyDemandHost;      // pinned: characters above the threshold in the step last copied back, or null
+    int* heavyDemandHost;      // pinned int[2]: characters above the threshold, and the sum of all costs, of the step last copied back; or null
     const int* list; const int* listCount; // what a part-1 launch iterates over (set by launch_move)
     const int* order; const int* orderCount; // grouped launch: characters sorted by last step's cost (device), its length
     int* orderHist;                        // [64] histogram / cursors of the order list (zero between steps)
@@ -255,11 +255,21 @@ inline int currentDeviceCUs() {
 constexpr int kMoveScratchBytes = 256;
 constexpr int kTraversalStackCap = 256; // LDS stack of pending wide nodes per query (sge_ccd.hip)
 constexpr int kStatShards = 256; // device counters: kStatShards lines of 8 x u64
-constexpr int kResidentSkinCharacters = 16384; // overlap mode: crowds from this size on skin with resident workgroups (sge_api.hip)
+// Overlap mode: crowds from this size on skin with RESIDENT workgroups (kResidentSkinQuarters / 4 per CU, drawing work
+// units of kResidentSkinCharsPerUnit characters from a ticket counter) — unless the move stage is the longer side of the step anyway
+// (more than kMoveHeavyEvaluations distance evaluations per character in the last step that reported back), where LBS workgroups
+// that come and go slow the collision chain less than resident ones.
+constexpr int kResidentSkinCharacters = 4096;
+constexpr int kResidentSkinQuarters = 6;
+constexpr int kResidentSkinCharsPerUnit = 4;
+constexpr int kMoveHeavyEvaluations = 300;
 void launch_move(const MoveLaunch& L, hipStream_t s);
 constexpr size_t kSeparationAgentBytes = 56; // SepAgentDev (sge_ccd.hip)
+// agentScratch: crowd.count x kSeparationAgentBytes; flowScratch: separationFlowBytes(crowd.count) (used above SGE_MAX_SEPARATION_AGENTS)
+size_t separationFlowBytes(int count);
+size_t separationFlowControlOffset(int count);
 void launch_separation(const DevCrowd& crowd, const DevCollision& col, int iterations, float separationMargin, float heightMargin,
-                       void* agentScratch, int* counts, hipStream_t s);
+                       void* agentScratch, int* counts, void* flowScratch, hipStream_t s);
 void launch_cast_queries(const DevCollision& col, const sge_capsule_query* d_q, int n, sge_capsule_cast_hit* d_out,
                          unsigned long long* stats, hipStream_t s);
 void launch_overlap_queries(const DevCollision& col, const sge_capsule_query* d_q, int n, int maxHits,
@@ -284,7 +294,8 @@ struct SkinLaunch {
     void* outPos; void* outNrm; void* outTan;
 };
 // residentQueue + residentQuarters > 0: the resident form (quarters of a workgroup per CU, one device int as the ticket counter)
-void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU = 0, int* residentQueue = nullptr, int residentQuarters = 0);
+// charsPerUnit: 1, 2, 4 or 8 characters share every loaded source vertex in the resident form
+void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU = 0, int* residentQueue = nullptr, int residentQuarters = 0, int charsPerUnit = 1);
 // one record per RTSkinningJob of a batched encode (device copy)
 struct SkinJobDev {
     const void* srcPos; const void* srcNrm; const void* srcTan; const void* srcIdx; const void* srcWgt;

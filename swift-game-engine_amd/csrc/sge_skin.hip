@@ -229,11 +229,11 @@ __device__ __forceinline__ void skinRangeMulti(const SkinLaunch& L, const int c0
     const size_t charStride = (size_t)L.vertexCount;
 
     auto skinAll = [&](const VertexIn& v, int g) {
-        const float w0 = fmaxf(v.w.x, 0.0f), w1 = fmaxf(v.w.y, 0.0f);
 #pragma unroll
         for (int k = 0; k < CPW; ++k) {
             if (k >= nChars) break;
             const v4f* P = reinterpret_cast<const v4f*>(pal) + (size_t)k * rows;
+            const float w0 = fmaxf(v.w.x, 0.0f), w1 = fmaxf(v.w.y, 0.0f); // (per character: two registers fewer across the loop than two clamps kept)
             v2f A, B, C, D, E, F;
             {
                 const v4f q0 = P[v.idx.x * 3 + 0], q1 = P[v.idx.x * 3 + 1], q2 = P[v.idx.x * 3 + 2];
@@ -313,7 +313,10 @@ __device__ __forceinline__ void skinRangeMulti(const SkinLaunch& L, const int c0
 // The resident form with CPW characters per work unit (unit u = (group of CPW consecutive characters, vertex split)); dynamic LDS:
 // CPW palettes of L.paletteCount bones + the ticket slot behind them.
 template <int DST_STRIDE, int CPW>
-__global__ __launch_bounds__(kSkinBlock, SGE_SKIN_MIN_BLOCKS) void skin_ticket_multi_kernel(SkinLaunch L, int splits, int vertsPerSplit, int* __restrict__ queue) {
+#ifndef SGE_SKIN_MULTI_MIN_BLOCKS
+#define SGE_SKIN_MULTI_MIN_BLOCKS SGE_SKIN_MIN_BLOCKS
+#endif
+__global__ __launch_bounds__(kSkinBlock, SGE_SKIN_MULTI_MIN_BLOCKS) void skin_ticket_multi_kernel(SkinLaunch L, int splits, int vertsPerSplit, int* __restrict__ queue) {
     extern __shared__ float4 palDyn[];
     int* const sNextUnit = reinterpret_cast<int*>(palDyn + (size_t)CPW * L.paletteCount * 3); // (behind the palettes: their 16-byte alignment stays)
     const int groups = (L.chars + CPW - 1) / CPW;
@@ -421,7 +424,7 @@ void launch_store_probe(void* outPos, void* outNrm, void* outTan, int chars, int
 // maxWorkgroupsPerCU > 0 caps the kernel's residency with dynamic-LDS padding: beside the next step's collision kernels
 // (SGE_OPT_OVERLAP_SKIN) three workgroups per CU stream as fast as five do alone, and the rest of the register file goes to the
 // latency-bound side (measured: 1.50 ms per step uncapped, 1.31 ms capped at three, 1.74 ms without overlap).
-void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU, int* residentQueue, int residentQuarters) {
+void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU, int* residentQueue, int residentQuarters, int charsPerUnit) {
     if (L.chars <= 0 || L.vertexCount <= 0) return;
     // enough workgroups to fill 256 CUs x 8 resident blocks several times over; small crowds split characters
     int splits = 1;
@@ -449,7 +452,7 @@ void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU, int
             else attrSet[devSlot] = true;
         }
     }
-    static const int cpwSetting = getenv("SGE_SKIN_CPW") ? atoi(getenv("SGE_SKIN_CPW")) : 1; // experiments: characters per work unit
+    const int cpwSetting = charsPerUnit;
     if (residentQueue && residentQuarters > 0 && L.srcLayout != SGE_LAYOUT_PADDED16 && (cpwSetting == 2 || cpwSetting == 4 || cpwSetting == 8) && L.chars >= 64) {
         const int cpw = cpwSetting, groups = (L.chars + cpw - 1) / cpw;
         int sp2 = 1;

@@ -130,3 +130,64 @@ def test_separation_stage_gpu_parity(sge):
         gpu.tick(stages=sge.abi.STAGE_SEPARATION, first=1, count=5)
     for e in (gpu, cpu, free):
         e.close()
+
+
+@pytest.mark.gpu
+def test_separation_dataflow_path_on_a_small_crowd(sge, monkeypatch):
+    """The crowd path of the stage (agents as a dataflow: per-agent pass counters, loops drawn from a ticket counter, sge_ccd.hip)
+    forced onto the 192-agent scene of the test above (SGE_SEPARATION_FLOW=1): bit-exact with the oracle's sequential loop, and
+    without the serial redo (the flags stay clear), so what is compared IS the dataflow's result."""
+    import torch
+
+    monkeypatch.setenv("SGE_SEPARATION_FLOW", "1")
+    gpu = sge.CharacterEngine(0)
+    cpu = ob.oracle_engine()
+    n = 192
+    for e in (gpu, cpu):
+        _, _, st0 = build_scene(sge, e, n, seed=41, mixed=True, agents=True, rings=3, segments=3, asset_scene=("cheese", "mirror"), footprint=60.0)
+        p = st0["params"].copy()
+        p["agentFlags"][::9] = 0
+        p["agentFlags"][4::13] = sge.abi.AGENT_PRESENT
+        p["agentMassWeight"][::5] = 2.5
+        p["agentMassWeight"][7::31] = 0.0
+        p["agentFlags"][3::17] |= sge.abi.AGENT_RADIUS_OVERRIDE
+        p["agentRadiusOverride"][:] = 1.2
+        e.upload(params=p)
+    ex = sge.parallel.AgentExchange(gpu, n, 0, 1, torch.device("cuda", 0), None)
+    st = (sge.abi.STAGE_ALL & ~sge.abi.STAGE_SKIN) | sge.abi.STAGE_SEPARATION
+    info = np.zeros(4, np.int32)
+    redone = 0
+    for s in range(45):
+        ex.step(stages=st)
+        ob.tick_mt(cpu, 8, stages=st | sge.abi.STAGE_AGENTS)
+        assert gpu.t.lib.sge_debug_separation(gpu.h, sge.abi.ptr(info)) == 0
+        redone += int(info[2] != 0)
+        if s % 5 == 0 or s == 44:
+            compare_states(sge, gpu, cpu, n)
+    assert info[0] > 100 and info[1] >= info[0]
+    assert redone == 0, "the dataflow pass fell back to the serial form in %d steps" % redone
+    gpu.close()
+    cpu.close()
+
+
+@pytest.mark.gpu
+def test_separation_crowd_of_8192(sge):
+    """Eight times the old capacity, on the real cheese + mirror scene at a density where most agents overlap a neighbour
+    (spacing ~2.2 units, capsule diameter 3): move-and-slide + AgentSeparationSystem, bodies and controllers bit-exact with the
+    oracle's sequential loop after every step."""
+    gpu = sge.CharacterEngine(0)
+    cpu = ob.oracle_engine()
+    n = 8192
+    for e in (gpu, cpu):
+        build_scene(sge, e, n, seed=43, mixed=True, agents=True, rings=3, segments=3, asset_scene=("cheese", "mirror"))
+    st = (sge.abi.STAGE_ALL & ~sge.abi.STAGE_SKIN) | sge.abi.STAGE_SEPARATION
+    info = np.zeros(4, np.int32)
+    for s in range(3):
+        gpu.tick(stages=st)
+        ob.tick_mt(cpu, 8, stages=st)
+        compare_states(sge, gpu, cpu, n)
+        assert gpu.t.lib.sge_debug_separation(gpu.h, sge.abi.ptr(info)) == 0
+        assert info[0] == n
+    assert gpu.move_stats().overflow == 0
+    gpu.close()
+    cpu.close()
