@@ -158,6 +158,12 @@ def main():
 
     prof = eng.profile_read(reset=True)
     stats = eng.move_stats(reset=True)
+    import ctypes as _C
+    _q, _cpw = _C.c_int32(0), _C.c_int32(1)
+    eng.t.lib.sge_debug_skin_form(eng.h, _C.byref(_q), _C.byref(_cpw))
+    lbs_kernel = ("skin_ticket_multi_kernel (4-weight LBS: %.2f resident workgroups per CU, %d characters per loaded source vertex)" % (_q.value / 4.0, _cpw.value)
+                  if _q.value > 0 and _cpw.value > 1 else
+                  "skin_ticket_kernel (4-weight LBS: %.2f resident workgroups per CU)" % (_q.value / 4.0) if _q.value > 0 else "skin_kernel (4-weight LBS, one workgroup per character)")
     # the LBS kernel alone on the idle chip (outside the timed region): with --overlap its launches inside the timed region share
     # the SIMDs with the next step's collision kernels and stretch; this is the kernel's own rate
     # on an idle chip: a pause before every launch (back to back the kernel goes through a ~10-launch transient of 1.0-1.2 ms and
@@ -188,7 +194,7 @@ def main():
     achieved = lbs_bytes / (lbs_ms * 1e-3) / 1e9 if lbs_ms > 0 else 0.0
     alone_ms = alone.skin_ms / max(alone.skin_launches, 1)
     alone_gbs = lbs_bytes / (alone_ms * 1e-3) / 1e9 if alone_ms > 0 else 0.0
-    traffic = _recorded_traffic(count, V)
+    traffic = _recorded_traffic(count, V, "skin_ticket_multi_kernel" if (_q.value > 0 and _cpw.value > 1) else "skin_ticket_kernel" if _q.value > 0 else "skin_kernel<")
     value = n_total * args.steps / elapsed
     out = {
         "metric": "characters/sec (skin+CCD)" if mode == "ccd" else "characters/sec (pose+skin, no CCD)",
@@ -217,13 +223,13 @@ def main():
             "static_triangles": tris, "dt": 1.0 / 60.0, "sharding": f"by-character x{world}",
             "skin_layout": args.layout, "overlap_skin_with_next_move": bool(args.overlap), "settle_steps": SETTLE_STEPS if mode == "ccd" else 0, "seed": 1234,
         },
-        "roofline": {"bound": "hbm", "kernel": "skin_kernel (4-weight LBS)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": lbs_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "bytes_per_launch": lbs_bytes, "ms_per_launch": lbs_ms,
                      "note": "HIP events on the skin stream over the timed region" + (
                          "; the launches overlap the next step's collision + pose kernels (see lbs_alone for the kernel by itself)" if args.overlap and mode == "ccd" else "")},
         "lbs_alone": {"ms_per_launch": alone_ms, "achieved": alone_gbs, "frac": alone_gbs / HBM_PEAK_GBS, "unit": "GB/s", "launches": alone_launches,
-                      "note": "the same kernel by itself after the timed region: no other kernel beside it, no residency cap, a 1 ms pause before every launch (back to back it sustains ~0.86 ms: profiles/r2_lbs_sustained_vs_burst.txt)"},
+                      "note": "the LBS launch of the serial schedule (skin_kernel, one workgroup per character) by itself after the timed region: no other kernel beside it, a 1 ms pause before every launch (back to back it sustains ~0.86 ms: profiles/r2_lbs_sustained_vs_burst.txt)"},
         "whole_path_hbm_frac": (value / world) * (40.0 * V + 64.0 * V / count + 2 * B * 64.0 + 640.0) / (HBM_PEAK_GBS * 1e9),
         "kernels_ms_per_step": {"move_ccd": prof.move_ms / args.steps, "pose": prof.pose_ms / args.steps,
                                 "lbs": prof.skin_ms / args.steps, "agents_grid": prof.agents_ms / args.steps},
@@ -310,14 +316,16 @@ def skin_source_hash():
     return h.hexdigest()[:16]
 
 
-def _recorded_traffic(count, V):
-    """HBM bytes per LBS launch from the committed rocprofv3 --pmc passes (tools/collect_profiles.sh writes the record).
-    Only a record taken from THIS kernel source and this shape counts; anything else reports null."""
+def _recorded_traffic(count, V, kernel):
+    """HBM bytes per LBS launch from the committed rocprofv3 --pmc passes (tools/collect_r3.sh writes the record).
+    Only a record taken from THIS kernel source, this shape and the LBS kernel form that ran counts; anything else reports null."""
     path = os.path.join(ROOT, "profiles", "lbs_traffic.json")
     try:
         rec = json.load(open(path))
         if rec.get("characters") == count and rec.get("vertices") == V and rec.get("skin_source_hash") == skin_source_hash():
-            return rec["hbm_bytes_per_launch"]
+            for name, b in rec.get("hbm_bytes_per_launch_by_kernel", {}).items():
+                if kernel in name:
+                    return b
     except Exception:
         pass
     return None

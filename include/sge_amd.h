@@ -630,6 +630,9 @@ int sge_separation_params(sge_context* ctx, int32_t iterations, float separation
    more than 64 neighbours to track, bit 1: an agent was pushed further than a grid cell; either way the pass was redone by the
    one-wavefront form, same result), cell size (float bits). */
 int sge_debug_separation(sge_context* ctx, int32_t* out);
+/* Which form the newest skin stage of sge_tick took (the rule is in DESIGN.md 3.5): quarters of a RESIDENT workgroup per CU (0: one
+   workgroup per character, coming and going) and characters per work unit. bench.py names the kernel it prices from this. */
+int sge_debug_skin_form(sge_context* ctx, int32_t* quarters, int32_t* chars_per_unit);
 int sge_move_stats_read(sge_context* ctx, sge_move_stats* out, int reset);
 /* Per-character share of CollisionQueryStats.capsuleSweepIterations (CollisionQuery.swift:280-318) for the LAST fixed step:
    distance evaluations each of characters [first, first + count) spent in its casts (what the scheduler balances on). */

@@ -296,6 +296,7 @@ PROTOTYPES = {
     "sge_debug_wave_profile": (C.c_int, [VP, VP, C.c_int32]),
     "sge_debug_move_lists": (C.c_int, [VP, VP, VP]),
     "sge_debug_separation": (C.c_int, [VP, VP]),
+    "sge_debug_skin_form": (C.c_int, [VP, P(i32), P(i32)]),
     "sge_blas_topology": (C.c_int, [VP, i32, VP, i32, P(BlasInfo), VP, VP, VP, VP, VP, VP]),
     "sge_blas_build": (C.c_int, [VP, VP, i32]),
     "sge_blas_info_get": (C.c_int, [VP, P(BlasInfo)]),

@@ -69,6 +69,7 @@ struct sge_context {
     int residentSkinQuarters = -1;
     int residentSkinCharsPerUnit = kResidentSkinCharsPerUnit; // characters per work unit of the resident form (SGE_SKIN_CPW: 1, 2, 4, 8)
     int lastMoveCount = 1;       // characters of the move stage whose cost sum sits in hHeavyDemand[1]
+    int lastSkinQuarters = 0, lastSkinCharsPerUnit = 1; // the form the newest skin stage took (sge_debug_skin_form)
     int overlapFusedWorkgroups = 0; // cap for the persistent workgroups of the fused LBS + refit kernel (0: as many as the LDS holds; measured 1 / 2 / 3: 1.53 / 1.47 / 1.44 ms per step)
     int heavyThreshold = 4000; // distance evaluations in a character's last step above which it takes the multi-wave kernel; < 0: off
     int heavyCap = 2048;       // most characters the multi-wave launch takes per step (its grid is sized by demand, see sge_tick)
@@ -1365,6 +1366,8 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
                     quarters = moveHeavy ? 0 : kResidentSkinQuarters;
                 }
                 launch_skin(L, ss, overlap ? c->overlapSkinWorkgroups : 0, c->dSkinQueue.as<int>(), quarters, c->residentSkinCharsPerUnit);
+                c->lastSkinQuarters = quarters;
+                c->lastSkinCharsPerUnit = quarters > 0 && count >= 64 ? c->residentSkinCharsPerUnit : 1;
             }
             if (refit) { // RTAccelerationBuilder.build is enqueued right behind the skinning encoder (RayTracingScene.swift:35-43)
                 Bracket br(c, &c->evBlas, ss);
@@ -1634,6 +1637,15 @@ int sge_separation_params(sge_context* c, int32_t iterations, float separation_m
     c->separationIterations = iterations < 1 ? 1 : iterations; // max(1, iterations) :2146
     c->separationMargin = separation_margin;
     c->separationHeightMargin = height_margin;
+    return SGE_OK;
+}
+
+// which form the newest skin stage of sge_tick took: quarters of a resident workgroup per CU (0: workgroups that come and go) and
+// characters per work unit
+int sge_debug_skin_form(sge_context* c, int32_t* quarters, int32_t* chars_per_unit) {
+    if (!c) return SGE_ERR_INVALID;
+    if (quarters) *quarters = c->lastSkinQuarters;
+    if (chars_per_unit) *chars_per_unit = c->lastSkinCharsPerUnit;
     return SGE_OK;
 }
 

@@ -46,6 +46,9 @@ class AgentExchange:
         self.product = bool(getattr(engine.t, "is_product", False))
         self.stream = None
         self.staged = False
+        import os
+        self.force_sync = os.environ.get("SGE_EXCHANGE_SYNC", "0") not in ("", "0")  # host synchronisation around the collective
+        self.checked = False
         if self.product and world == 1:
             return  # sge_agents_allgather keeps its own buffers
         self.staged = self.product and dist is not None and dist.get_backend() != "nccl"  # rehearsal: gloo moves host memory
@@ -69,7 +72,28 @@ class AgentExchange:
         elif self.product and not self.staged:
             with self.torch.cuda.stream(self.stream):
                 eng.agents_export(self.local.data_ptr())
+                if self.force_sync:
+                    eng.synchronize()
                 self.dist.all_gather_into_tensor(self.all, self.local)
+                if self.force_sync:
+                    self.torch.cuda.synchronize()
+            if not self.checked:
+                # The stream-ordered path (no host synchronisation between export, collective and import) has never run on more than
+                # one GPU before the first multi-GPU job does: the first exchange is repeated with host synchronisation on both
+                # sides and compared. A mismatch switches this exchange to the synchronising form for good and says so.
+                self.checked = True
+                eng.synchronize()
+                self.torch.cuda.synchronize()
+                check = self.torch.empty_like(self.all)
+                self.dist.all_gather_into_tensor(check, self.local)
+                self.torch.cuda.synchronize()
+                if not self.torch.equal(check, self.all):
+                    import sys
+                    print("[sge] rank %d: the stream-ordered agent exchange disagrees with the synchronised one; "
+                          "using host synchronisation from here on" % self.rank, file=sys.stderr, flush=True)
+                    self.force_sync = True
+                    self.all.copy_(check)
+                    self.torch.cuda.synchronize()
             eng.agents_import(self.all.data_ptr(), self.all.shape[0], self.self_offset)
         else:
             eng.agents_export(self.local.data_ptr())

@@ -26,7 +26,7 @@ res = defaultdict(lambda: defaultdict(list))
 for path in glob.glob(os.path.join(out, "p*/**/*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"]
-        if "move_" not in k and "pose_kernel" not in k and "skin_kernel" not in k and "order_" not in k and "classify" not in k:
+        if "move_" not in k and "pose_kernel" not in k and "skin_" not in k and "order_" not in k and "classify" not in k:
             continue
         res[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summ = {k: {c: {"mean": sum(v) / len(v), "n": len(v)} for c, v in cs.items()} for k, cs in res.items()}

@@ -5,7 +5,7 @@ import csv, sys
 rows = []
 for r in csv.DictReader(open(sys.argv[1])):
     name = r["Kernel_Name"]
-    key = "skin" if ("skin_kernel" in name or "skin_ticket_kernel" in name) else "group" if "move_group_kernel" in name else "heavy" if "move_kernel<1" in name else \
+    key = "skin" if ("skin_kernel" in name or "skin_ticket" in name) else "group" if "move_group_kernel" in name else "heavy" if "move_kernel<1" in name else \
         "move0" if "move_kernel<0" in name else "pose" if "pose_kernel" in name else None
     if key:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), key))
