@@ -74,6 +74,9 @@ struct sge_context {
     int heavyThreshold = 4000; // distance evaluations in a character's last step above which it takes the multi-wave kernel; < 0: off
     int heavyCap = 2048;       // most characters the multi-wave launch takes per step (its grid is sized by demand, see sge_tick)
     int* hHeavyDemand = nullptr; // pinned host word the move stage copies its demand count to
+    // the heavy / order lists of the next move stage, built behind the last one (launch_move): valid for exactly this range / threshold
+    bool listsValid = false; int listsFirst = 0, listsCount = 0, listsThreshold = 0, listsCap = 0;
+    hipEvent_t evListsReady = nullptr;
     bool skinPending[2] = {false, false}, overlapSkin = false, customStream = false;
     // options
     bool storePoseDebug = false, profile = false;
@@ -516,6 +519,7 @@ sge_context* sge_context_create(int device_index) {
         hipEventCreateWithFlags(&c->evSkinDone[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evMainMark, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evConsumed, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evListsReady, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithPriority(&c->heavyStream, hipStreamNonBlocking, prGreatest) != hipSuccess ||
         hipEventCreateWithFlags(&c->evClassified, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evHeavyDone, hipEventDisableTiming) != hipSuccess ||
@@ -545,6 +549,7 @@ void sge_context_destroy(sge_context* c) {
     if (c->hHeavyDemand) (void)hipHostFree(c->hHeavyDemand);
     if (c->evMainMark) (void)hipEventDestroy(c->evMainMark);
     if (c->evConsumed) (void)hipEventDestroy(c->evConsumed);
+    if (c->evListsReady) (void)hipEventDestroy(c->evListsReady);
     for (hipEvent_t e : c->evSkinDone) if (e) (void)hipEventDestroy(e);
     if (c->skinStream) (void)hipStreamDestroy(c->skinStream);
     if (c->evClassified) (void)hipEventDestroy(c->evClassified);
@@ -1162,6 +1167,7 @@ int sge_characters_resize(sge_context* c, int32_t count) {
     SGE_ZALLOC(c->dPalettes[0], N * B * 64);
     SGE_ZALLOC(c->dPalettes[1], N * B * 64);
     c->palRead = 0;
+    c->listsValid = false;
     SGE_ZALLOC(c->dMoveScratch, N * (size_t)kMoveScratchBytes);
     SGE_ZALLOC(c->dCost, N * sizeof(int));
     SGE_ZALLOC(c->dHint, N);
@@ -1275,16 +1281,22 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         MoveLaunch L{c->crowd, c->col, c->agents, d->dt, d->gravity[0], d->gravity[1], d->gravity[2], st, first, count,
                      c->dStats.as<unsigned long long>(), c->dMoveScratch.p, c->dPlatforms.as<sge_platform_state>(), c->platformCount,
                      c->dCost.as<int>(), getenv("SGE_NO_SPEC") ? nullptr : c->dHint.as<uint8_t>(), c->dLists.as<int>(), c->dListCounts.as<int>(), c->dHeavyFlags.as<uint8_t>(),
-                     c->heavyThreshold, c->heavyCap, c->heavyStream, c->evClassified, c->evHeavyDone, c->hHeavyDemand, nullptr, nullptr, nullptr, nullptr, c->dOrderHist.as<int>(), 0, nullptr};
+                     c->heavyThreshold, c->heavyCap, c->heavyStream, c->evClassified, c->evHeavyDone, c->hHeavyDemand, nullptr, nullptr, nullptr, nullptr, c->dOrderHist.as<int>(), 0, 0, 0, c->evListsReady, nullptr};
         // Grid of the multi-wave launch: the characters that asked for it in the newest step whose count has reached the host
         // (+ 50 % + 8), not the cap — every workgroup of that grid, the ones beyond the list included, has to find a CU with two
         // free places per SIMD. The list is cut to the grid (classify_kernel); whoever does not fit stays with the grouped launch,
         // which gives the same result. -1: nothing has come back yet.
         if (st & SGE_STAGE_MOVE) c->lastMoveCount = count;
+        int capNow = c->heavyCap;
         if (c->hHeavyDemand) {
             const int demand = *(volatile int*)c->hHeavyDemand;
-            if (demand >= 0) L.heavyCap = std::min(c->heavyCap, demand + demand / 2 + 8);
+            if (demand >= 0) capNow = std::min(c->heavyCap, demand + demand / 2 + 8);
         }
+        // lists built behind the previous step's move stage serve this one if nothing they depend on has changed; their cap is the grid
+        const bool listsReady = c->listsValid && c->listsFirst == first && c->listsCount == count && c->listsThreshold == c->heavyThreshold;
+        L.listsReady = listsReady ? 1 : 0;
+        L.heavyCap = listsReady ? c->listsCap : capNow;
+        L.nextHeavyCap = capNow;
         if (c->waveProfOn) {
             if (c->dWaveProf.alloc((size_t)c->crowd.count * 3 * 64) != SGE_OK) return SGE_ERR_DEVICE;
             SGE_HIP(hipMemsetAsync(c->dWaveProf.p, 0, (size_t)c->crowd.count * 3 * 64, c->stream));
@@ -1292,7 +1304,11 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         }
         if (!(st & SGE_STAGE_AGENTS) || !c->agents.grid) L.agents.all = nullptr;
         Bracket br(c, &c->evMove);
-        launch_move(L, c->stream);
+        const bool built = launch_move(L, c->stream);
+        if (st & SGE_STAGE_MOVE) {
+            c->listsValid = built;
+            c->listsFirst = first; c->listsCount = count; c->listsThreshold = c->heavyThreshold; c->listsCap = capNow;
+        }
     }
     if (st & SGE_STAGE_SEPARATION) { // AgentSeparationSystem: after the move stage, before the animation stages (DemoScene.swift:66-71)
         if (first != 0 || count != c->crowd.count) { set_error("SGE_STAGE_SEPARATION works on the whole crowd (first = 0, count = all)"); return SGE_ERR_INVALID; }

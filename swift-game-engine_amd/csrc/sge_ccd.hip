@@ -2927,9 +2927,25 @@ __device__ __forceinline__ SepPairAgent sepPairAgent(const SepLaunch& K, const S
 }
 
 // the pair loops of one pass, one wavefront per loop, loops drawn in index order
+// does the pair change anything? The early exits of :1972-1986 (sepPair repeats them, same expressions)
+__device__ __forceinline__ bool sepInteracts(const SepPairAgent& A, const SepPairAgent& B, F3 aPos, F3 bPos, float separationMargin, float heightMargin) {
+    const float aMin = aPos.y - A.halfHeight, aMax = aPos.y + A.halfHeight;
+    const float bMin = bPos.y - B.halfHeight, bMax = bPos.y + B.halfHeight;
+    const float ddx = aPos.x - bPos.x, ddz = aPos.z - bPos.z;
+    const float distSq = ddx * ddx + ddz * ddz;
+    const float skinAllowance = smin(A.skinWidth, B.skinWidth);
+    const float margin = smin(separationMargin, skinAllowance);
+    const float minDist = A.radius + B.radius + margin;
+    const bool heightSeparated = aMax < bMin - heightMargin || aMin > bMax + heightMargin;
+    if (heightSeparated) return false;
+    if (distSq >= minDist * minDist) return false;
+    return A.invWeight + B.invWeight > 0;
+}
+
+// the pair loops of one pass, one wavefront per loop, loops drawn in index order
 __global__ __launch_bounds__(kWave, 2) void sep_flow_kernel(SepLaunch K, SepFlow F) {
     __shared__ int2 sCand[kSepMaxCand];
-    __shared__ unsigned long long sPassed[kSepMaxCand / 64]; // candidates this loop has passed already
+    __shared__ unsigned long long sKey[kSepMaxCand]; // pairs that change something, by their place in the reference's order (~0: none)
     __shared__ int sTicket;
     const int lane = laneId();
     const DevCollision& col = K.col;
@@ -2945,8 +2961,7 @@ __global__ __launch_bounds__(kWave, 2) void sep_flow_kernel(SepLaunch K, SepFlow
         const int i = sTicket;
         if (i >= n) break;
         const int nc = F.candCount[i];
-        for (int l = lane; l < nc; l += kWave) sCand[l] = F.cand[(size_t)i * kSepMaxCand + l];
-        if (lane < kSepMaxCand / 64) sPassed[lane] = 0;
+        for (int l = lane; l < nc; l += kWave) { sCand[l] = F.cand[(size_t)i * kSepMaxCand + l]; sKey[l] = ~0ull; }
         __syncthreads();
         sepWait(&F.ver[i], F.need[i]); // every earlier loop that can pair with agent i has passed it
         SepAgentDev* Ai = K.agents + i;
@@ -2959,39 +2974,53 @@ __global__ __launch_bounds__(kWave, 2) void sep_flow_kernel(SepLaunch K, SepFlow
             const int d0 = cx - F.cell[2 * i], d1 = cz - F.cell[2 * i + 1];
             if ((d0 < -1 || d0 > 1 || d1 < -1 || d1 > 1) && lane == 0) atomicOr(&F.control[2], 2); // redo serially
         }
-        for (int dz = -1; dz <= 1; ++dz) {
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int tx = cx + dx, tz = cz + dz;
-                const unsigned b = sepHash(tx, tz, F.H);
-                const int pEnd = F.bucketStart[b + 1];
-                for (int p = F.bucketStart[b]; p < pEnd; ++p) {
-                    const int j = F.bucketItems[p];
-                    if (j <= i || F.cell[2 * j] != tx || F.cell[2 * j + 1] != tz) continue;
-                    int slot = -1;
-                    for (int base = 0; base < nc && slot < 0; base += kWave) {
-                        const int l = base + lane;
-                        const unsigned long long hit = __ballot(l < nc && sCand[l < nc ? l : 0].x == j);
-                        if (hit) slot = base + __ffsll((long long)hit) - 1;
+        // 1. every candidate in its turn, a lane each: the ones outside the 3 x 3 cells around the live cell, and the pairs that fail
+        //    the tests of :1972-1986 (they read agent j at their turn and change nothing: they commute with everything), are passed
+        //    at once; the pairs that DO change something keep their turn and are queued by their place in the reference's order
+        //    (cell dz, dx, then index). A loop no longer makes its successors wait for ~30 passes one after the other.
+        for (int base = 0; base < nc; base += kWave) {
+            const int l = base + lane;
+            bool waiting = l < nc;
+            const int c = waiting ? sCand[l].x : 0, rank = waiting ? sCand[l].y : 0;
+            const int ddx = waiting ? F.cell[2 * c] - cx : 9, ddz = waiting ? F.cell[2 * c + 1] - cz : 9;
+            const bool inList = ddx >= -1 && ddx <= 1 && ddz >= -1 && ddz <= 1;
+            while (__any(waiting)) {
+                if (waiting && __hip_atomic_load(&F.ver[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == rank) {
+                    waiting = false;
+                    bool hold = false;
+                    if (inList) {
+                        const SepAgentDev* Aj = K.agents + c;
+                        const F3 bPos = sepLoad3(Aj->position);
+                        hold = sepInteracts(A, sepPairAgent(K, *Aj), aPos, bPos, K.separationMargin, K.heightMargin);
                     }
-                    if (slot < 0) { if (lane == 0) atomicOr(&F.control[2], 2); continue; } // (only after the cell check above has fired)
-                    const int rank = sCand[slot].y;
-                    sepWait(&F.ver[j], rank);
-                    SepAgentDev* Aj = K.agents + j;
-                    F3 bPos = sepLoad3(Aj->position), bVel = sepLoad3(Aj->velocity);
-                    const SepPairAgent B = sepPairAgent(K, *Aj);
-                    if (sepPair(col, A, B, aPos, aVel, posI, velI, bPos, bVel, K.separationMargin, K.heightMargin, st)) {
-                        if (lane == 0) { sepStore3(Aj->position, bPos); sepStore3(Aj->velocity, bVel); }
-                    }
-                    if (lane == 0) { sepRelease(&F.ver[j], rank + 1); sPassed[slot >> 6] |= 1ull << (slot & 63); }
+                    if (hold) sKey[l] = ((unsigned long long)((ddz + 1) * 3 + (ddx + 1)) << 32) | (unsigned)c;
+                    else __hip_atomic_store(&F.ver[c], rank + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                if (__any(waiting)) __builtin_amdgcn_s_sleep(2);
             }
         }
         __syncthreads();
-        for (int slot = 0; slot < nc; ++slot) { // the candidates this loop does not pair with, in their turn
-            if ((sPassed[slot >> 6] >> (slot & 63)) & 1) continue;
-            const int c = sCand[slot].x, rank = sCand[slot].y;
-            sepWait(&F.ver[c], rank);
-            if (lane == 0) __hip_atomic_store(&F.ver[c], rank + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // 2. the pairs that change something, one after the other in the reference's order (the casts start from agent i's live position)
+        while (true) {
+            unsigned long long best = ~0ull;
+            int bestSlot = -1;
+            for (int base = 0; base < nc; base += kWave) {
+                const int l = base + lane;
+                const unsigned long long k = l < nc ? sKey[l] : ~0ull;
+                const unsigned long long m = waveMinU64(k);
+                if (m < best) { best = m; const unsigned long long who = __ballot(k == m); bestSlot = base + __ffsll((long long)who) - 1; }
+            }
+            if (bestSlot < 0) break;
+            const int j = sCand[bestSlot].x, rank = sCand[bestSlot].y;
+            SepAgentDev* Aj = K.agents + j;
+            F3 bPos = sepLoad3(Aj->position), bVel = sepLoad3(Aj->velocity);
+            const SepPairAgent B = sepPairAgent(K, *Aj);
+            if (sepPair(col, A, B, aPos, aVel, posI, velI, bPos, bVel, K.separationMargin, K.heightMargin, st)) {
+                if (lane == 0) { sepStore3(Aj->position, bPos); sepStore3(Aj->velocity, bVel); }
+            }
+            __syncthreads();
+            if (lane == 0) { sepRelease(&F.ver[j], rank + 1); sKey[bestSlot] = ~0ull; }
+            __syncthreads();
         }
         if (lane == 0) { sepStore3(Ai->position, posI); sepStore3(Ai->velocity, velI); } // nobody reads it before the pass ends
     }
@@ -3160,31 +3189,50 @@ __global__ void order_scatter_kernel(const int* cost, int first, int count, cons
     if (e >= 0) order[base[b] + local] = e;
 }
 
-void launch_move(const MoveLaunch& L, hipStream_t s) {
-    if (L.count <= 0) return;
+bool launch_move(const MoveLaunch& L, hipStream_t s) {
+    if (L.count <= 0) return false;
     static const bool grouped = !(getenv("SGE_MOVE_GROUP") && atoi(getenv("SGE_MOVE_GROUP")) == 0);
-    // (part 0 at the head of the grouped launch instead — no launch in front of the stage, no round trip of the working set — was
-    // built and measured: the grouped kernel then needs 166 registers instead of 155, one wavefront fewer fits beside two resident
-    // LBS wavefronts, and the step is 1-6 % slower: 0.998 against 0.987 ms, against 0.937 with 155)
-    hipLaunchKernelGGL((move_kernel<0, false>), dim3(L.count), dim3(kWave), 0, s, L);
-    if (!(L.stages & SGE_STAGE_MOVE)) return;
+    static const bool pipelineSetting = !(getenv("SGE_MOVE_PIPELINE_LISTS") && atoi(getenv("SGE_MOVE_PIPELINE_LISTS")) == 0); // experiments
+    const bool move = (L.stages & SGE_STAGE_MOVE) != 0;
     const bool agents = (L.stages & SGE_STAGE_AGENTS) && L.agents.all;
+    const bool heavy = L.heavyThreshold >= 0;
     static const int ldsPad = getenv("SGE_MOVE_LDS_PAD") ? atoi(getenv("SGE_MOVE_LDS_PAD")) : 0; // experiments: caps workgroups per CU
     static const int soloSetting = getenv("SGE_GROUP_SOLO") ? atoi(getenv("SGE_GROUP_SOLO")) : 128; // experiments
     const int solo = grouped ? std::max(0, std::min(soloSetting, L.count / 16)) : 0;
     const int groups = solo + (L.count - solo + kGroup - 1) / kGroup;
     const int blocks = (L.count + 255) / 256;
-    // last step's costs -> heavy list (multi-wave launch) + order list of everybody else (grouped launch)
-    (void)hipMemsetAsync(L.listCounts, 0, 4 * sizeof(int), s);
-    hipLaunchKernelGGL(classify_kernel, dim3(blocks), dim3(256), 0, s, L.cost, L.first, L.count, L.heavyThreshold, L.heavyCap, L.lists,
-                       L.listCounts, L.heavyFlags, L.orderHist);
-    const bool heavy = L.heavyThreshold >= 0;
+    // The scheduling lists — last step's costs -> heavy list (multi-wave launch) + order list of everybody else (grouped launch) —
+    // depend on nothing of the step they schedule, so they are built BEHIND the move stage of the step before, on the second stream,
+    // while that step's pose kernel runs: the memset and three small kernels (and the cross-stream event in front of the grouped
+    // launch) were 50 us between the end of move_kernel<0> and the start of the grouped launch, on the step's critical chain.
+    const bool pipelined = move && grouped && heavy && pipelineSetting;
+    auto buildLists = [&](hipStream_t q, int cap) {
+        (void)hipMemsetAsync(L.listCounts, 0, 4 * sizeof(int), q);
+        hipLaunchKernelGGL(classify_kernel, dim3(blocks), dim3(256), 0, q, L.cost, L.first, L.count, L.heavyThreshold, cap, L.lists,
+                           L.listCounts, L.heavyFlags, L.orderHist);
+        if (grouped) {
+            hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, q, L.orderHist, L.listCounts);
+            hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, q, L.cost, L.first, L.count, L.heavyFlags, L.orderHist, L.lists);
+        }
+        // how many characters asked for the multi-wave launch, and the crowd's evaluations: read by the host when it enqueues a
+        // later step (pinned memory)
+        if (heavy && L.heavyDemandHost) (void)hipMemcpyAsync(L.heavyDemandHost, L.listCounts + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, q);
+    };
+    if (move) {
+        if (pipelined && L.listsReady) (void)hipStreamWaitEvent(s, L.evListsReady, 0); // built behind the previous step, on the second stream
+        else buildLists(s, L.heavyCap);                                                 // first step, or something changed
+    }
+    // (part 0 at the head of the grouped launch instead — no launch in front of the stage, no round trip of the working set — was
+    // built and measured: the grouped kernel then needs 166 registers instead of 155, one wavefront fewer fits beside two resident
+    // LBS wavefronts, and the step is 1-6 % slower: 0.998 against 0.987 ms, against 0.937 with 155)
+    hipLaunchKernelGGL((move_kernel<0, false>), dim3(L.count), dim3(kWave), 0, s, L);
+    if (!move) return false;
     MoveLaunch G = L;
-    // The multi-wave launch goes FIRST and stays on the main stream, right behind the classification: its 512-thread workgroups need
+    // The multi-wave launch goes FIRST and stays on the main stream, right behind part 0: its 512-thread workgroups need
     // two free wavefront places on every SIMD of one CU at the same moment, which they find while the chip holds nothing but the
     // skin launch of the previous step — and do not find for several hundred microseconds once the one-wave workgroups of the
     // grouped launch have taken every place that comes free (beside resident LBS workgroups the move stage took 0.94 ms instead of
-    // 0.52 for exactly this reason). So the grouped launch and its two ordering kernels run on the second stream,
+    // 0.52 for exactly this reason). So the grouped launch runs on the second stream,
     // behind an event: the cross-stream hand-over is what gives the multi-wave workgroups their head start.
     hipStream_t gs = heavy ? L.heavyStream : s;
     if (heavy) {
@@ -3195,12 +3243,8 @@ void launch_move(const MoveLaunch& L, hipStream_t s) {
         if (agents) hipLaunchKernelGGL((move_kernel<1, true, true>), dim3(heavyGrid), dim3(kWave * kHeavyWaves), 0, s, H);
         else hipLaunchKernelGGL((move_kernel<1, false, true>), dim3(heavyGrid), dim3(kWave * kHeavyWaves), 0, s, H);
         (void)hipStreamWaitEvent(gs, L.evClassified, 0);
-        // how many characters asked for the multi-wave launch: read by the host when it enqueues a later step (pinned memory)
-        if (L.heavyDemandHost) (void)hipMemcpyAsync(L.heavyDemandHost, L.listCounts + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, gs);
     }
     if (grouped) {
-        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, gs, L.orderHist, L.listCounts);
-        hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, gs, L.cost, L.first, L.count, L.heavyFlags, L.orderHist, L.lists);
         G.order = L.lists; G.orderCount = L.listCounts; G.solo = solo;
         // kGroup characters per wavefront, members drawn from the order list
         if (agents) hipLaunchKernelGGL((move_group_kernel<true>), dim3(groups), dim3(kWave), ldsPad, gs, G);
@@ -3211,6 +3255,13 @@ void launch_move(const MoveLaunch& L, hipStream_t s) {
         (void)hipEventRecord(L.evHeavyDone, gs);
         (void)hipStreamWaitEvent(s, L.evHeavyDone, 0);
     }
+    if (pipelined) { // the NEXT step's lists, behind both launches of this one, beside whatever the main stream does next
+        (void)hipEventRecord(L.evClassified, s);
+        (void)hipStreamWaitEvent(gs, L.evClassified, 0);
+        buildLists(gs, L.nextHeavyCap);
+        (void)hipEventRecord(L.evListsReady, gs);
+    }
+    return pipelined;
 }
 
 // ---- batched single queries (the CollisionQuery facade) ---------------------

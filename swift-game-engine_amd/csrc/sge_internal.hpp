@@ -230,6 +230,8 @@ struct MoveLaunch {
     const int* order; const int* orderCount; // grouped launch: characters sorted by last step's cost (device), its length
     int* orderHist;                        // [64] histogram / cursors of the order list (zero between steps)
     int solo;                              // grouped launch: its first `solo` wavefronts take one character each (the most expensive)
+    int listsReady, nextHeavyCap;          // the heavy / order lists of this step were built behind the previous one; cap for the next
+    hipEvent_t evListsReady;
     // diagnostics (SGE_WAVE_PROF=1), rows of 8 x u64 in three regions of crowd.count rows each: [0] one row per wavefront of
     // move_group_kernel, [1] one row per character of move_kernel<0>, [2] one row per character of pose_kernel
     unsigned long long* waveProf;
@@ -263,7 +265,8 @@ constexpr int kResidentSkinCharacters = 4096;
 constexpr int kResidentSkinQuarters = 6;
 constexpr int kResidentSkinCharsPerUnit = 4;
 constexpr int kMoveHeavyEvaluations = 300;
-void launch_move(const MoveLaunch& L, hipStream_t s);
+// returns true when the lists of the NEXT step (same range, threshold, cap = nextHeavyCap) have been enqueued behind this stage
+bool launch_move(const MoveLaunch& L, hipStream_t s);
 constexpr size_t kSeparationAgentBytes = 56; // SepAgentDev (sge_ccd.hip)
 // agentScratch: crowd.count x kSeparationAgentBytes; flowScratch: separationFlowBytes(crowd.count) (used above SGE_MAX_SEPARATION_AGENTS)
 size_t separationFlowBytes(int count);
