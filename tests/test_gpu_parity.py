@@ -1215,3 +1215,83 @@ def test_side_contact_cache_policy_parity(sge, engines):
     default = ref.download()["controllers"]
     ref.close()
     assert side_only.tobytes() != default.tobytes()
+
+
+class _SyntheticRig:
+    """A rig shaped like assets.YBotAssets (same attributes), with a random hierarchy and random Fourier profiles: what the pose
+    kernel's generic paths need that the Y-Bot never shows — bone counts other than 65, orders above 4, translation channels on
+    bones other than the root, a last pass whose bones ARE animated, bones whose parent sits in the same pass."""
+
+    def __init__(self, bones, order, seed, animate_all, translate_some, chain=False):
+        rng = np.random.default_rng(seed)
+        self.names = ["mixamorig:Hips"] + ["bone%03d" % i for i in range(1, bones)]
+        if bones > 12:
+            self.names[5] = "mixamorig:Spine2"
+        self.parent = np.full(bones, -1, np.int32)
+        for i in range(1, bones):
+            self.parent[i] = i - 1 if (chain and i % 3) else int(rng.integers(max(0, i - 9), i))
+        self.translations = rng.uniform(-8, 8, (bones, 3)).astype(np.float32)
+        self.pre_rotation_degrees = rng.uniform(-40, 40, (bones, 3)).astype(np.float32)
+        self.unit_scale = 0.026
+        self.root_fix_degrees = np.array([0, 180, 0], np.float32)
+        self.zero_root = True
+        self.pelvis_index = 0
+        self.lean_index = 5 if bones > 12 else -1
+        self.profile_names = ["Idle", "Walking", "Running", "FallingIdle", "StandingDodgeBackward"]
+        self.profiles = []
+        ncoef = 1 + 2 * order
+        for k, name in enumerate(self.profile_names):
+            present = np.ones(bones, np.uint8) if animate_all else (rng.uniform(size=bones) < 0.8).astype(np.uint8)
+            present[0] = 1
+            count = np.full((bones, 6), 255, np.uint8)
+            coeffs = np.zeros((bones, 6, 17), np.float32)
+            for b in range(bones):
+                if not present[b]:
+                    continue
+                axes = [3, 4, 5] + ([0, 1, 2] if (b == 0 or (translate_some and b % 7 == 3)) else [])
+                for a in axes:
+                    if rng.uniform() < 0.1:
+                        continue                                        # a nil axis
+                    c = ncoef if rng.uniform() < 0.8 else int(rng.integers(0, ncoef + 1))   # ragged and empty rows too
+                    count[b, a] = c
+                    amp = 25.0 if a >= 3 else 3.0
+                    coeffs[b, a, :c] = rng.normal(0, amp, c) / (1 + np.arange(c))
+            self.profiles.append({"name": name, "order": order if k != 1 else max(1, order - 2), "cycleDuration": float(rng.uniform(0.6, 1.6)),
+                                  "sampleFps": 30, "bonePresent": present, "coeffCount": count, "coeffs": coeffs})
+
+    @property
+    def bone_count(self):
+        return len(self.names)
+
+    def profile_index(self, name):
+        return self.profile_names.index(name)
+
+
+@pytest.mark.parametrize("bones,order,animate_all,translate_some,chain", [(64, 8, True, True, False), (130, 6, True, True, False),
+                                                                        (100, 4, False, False, True), (33, 8, False, True, False)])
+def test_pose_kernel_generic_rigs(sge, engines, bones, order, animate_all, translate_some, chain):
+    """pose_kernel beyond the Y-Bot (round 3's kernel visits bones by slots, has a static-last-pass shortcut, a one-product model
+    path for later passes and an instantiation for orders up to 8): random rigs of 33 / 64 / 100 / 130 bones (one, two, three
+    passes), orders 4 / 6 / 8 with ragged and nil axes, translation on non-root bones, an animated or a partly static last pass,
+    long parent chains — locomotion blends, the action layer, ground align and run lean on top. Palettes within 1e-5 of the
+    oracle, CCD state bit-exact, over 40 steps of a mixed crowd."""
+    gpu, cpu = engines
+    rig = _SyntheticRig(bones, order, seed=100 + bones, animate_all=animate_all, translate_some=translate_some, chain=chain)
+    n = 48
+    for e in engines:
+        e.set_option(sge.abi.OPT_STORE_POSE_DEBUG, 1)
+        sge.crowd.upload_character_assets(e, rig, rings=2, segments=3)
+        terrain = sge.crowd.upload_terrain(e, cells=(24, 16))
+        st0 = sge.crowd.spawn_crowd(e, rig, n, terrain, seed=9, mode="ccd", mixed=True)
+        a = st0["actions"].copy()
+        a["flags"][::3] |= sge.abi.ACTION_ACTIVE                      # every third character starts its action layer
+        a["weight"][::3] = 0.4
+        e.upload(actions=a)
+    for s in range(40):
+        for e in engines:
+            e.tick()
+        if s in (0, 1, 7, 39):
+            compare_states(sge, gpu, cpu, n)
+    gp, gn, gt = gpu.skinned()
+    cp, cn, ct = cpu.skinned()
+    assert np.abs(gp - cp).max() <= REL * max(np.abs(cp).max(), 1.0)
