@@ -163,7 +163,11 @@ def test_kernel_resources_match_what_the_schedule_counts_on(sge, lib):
         for name, r in find(frag).items():
             assert r["vgpr"] <= 88 and r["scratch"] == 0, (name, r)
     for name, r in find("move_group_kernel").items():
-        assert r["vgpr"] <= 168 and r["scratch"] == 0 and r["lds"] <= 10752, (name, r)
+        # 160, not the 168 three wavefronts per SIMD would allow: two of these beside two resident LBS wavefronts of 96 registers fill a
+        # SIMD's 512 exactly; at 166 (part 0 fused into the kernel, round 3) the step was 1-6 % slower
+        assert r["vgpr"] <= 160 and r["scratch"] == 0 and r["lds"] <= 10752, (name, r)
+    for name, r in find("skin_ticket_multi_kernelILi3ELi4").items():
+        assert r["vgpr"] <= 96 and r["scratch"] == 0, (name, r)
     for name, r in find("move_kernelILi1E").items():
         heavy = r["max_wg"] > 64
         assert r["vgpr"] <= (168 if heavy else 128), (name, r)
