@@ -53,6 +53,13 @@ struct sge_context {
     hipStream_t skinStream = nullptr;
     hipEvent_t evPoseDone = nullptr, evSkinDone[2] = {nullptr, nullptr}, evMainMark = nullptr, evConsumed = nullptr;
     int lastSkin = 0;            // palette buffer (= event slot) of the newest overlapped skin launch
+    // overlap mode, whole-crowd ticks with move + pose + skin: pose(n) on a stream of its own, beside move(n+1) — it reads the move
+    // stage's results from a copy the move kernels write with their write-back (PoseInput, two buffers), so the step's dependent chain
+    // on the main stream is the move stage alone
+    hipStream_t poseStream = nullptr;
+    hipEvent_t evMoveDone = nullptr, evPosePiped[2] = {nullptr, nullptr};
+    bool posePending[2] = {false, false}, pipelinePose = true;
+    int poseSlot = 0;            // PoseInput buffer (= event slot) of the newest pipelined pose launch
     // two palette buffers: with the overlap option pose(n+1) writes one while skin(n) still reads the other, so that only
     // skin(n+1) -> skin(n) and skin(n+1) -> pose(n+1) remain as dependencies (a single buffer chains pose(n+1) behind skin(n))
     int palRead = 0;             // buffer holding the latest palettes
@@ -61,11 +68,8 @@ struct sge_context {
     int placementProbes = 8;   // candidate placements of the skinned output streams compared at allocation time
     float placementMs = 0; int placementTried = 0;
     int overlapSkinWorkgroups = 3; // LBS workgroups per CU while it shares the chip with the next step's collision kernels
-    // overlap mode, LBS as resident workgroups with a ticket counter (quarters of a workgroup per CU): -1 = by crowd size and by
-    // the move stage's weight (kResidentSkinQuarters from kResidentSkinCharacters characters on; round 3, with four characters per
-    // work unit: 10k cheese 1.087 -> 0.937 ms, configs[1] 0.927 -> 0.873, merged / mixed 1.086 -> 0.982, 35k-vertex Y-Bot 2.32 ->
-    // 2.24, agents 1.154 -> 1.109, 20k 1.975 -> 1.748; 2,500 characters 0.430 -> 0.459 and the collision-heavy synthetic terrain
-    // 1.307 -> 1.414, which is what the two conditions keep out), 0 = never, q > 0 = always (SGE_SKIN_PERSISTENT)
+    // overlap mode, LBS as resident workgroups with a ticket counter (quarters of a workgroup per CU): -1 = by crowd size
+    // (kResidentSkinQuarters from kResidentSkinCharacters characters on, see there), 0 = never, q > 0 = always (SGE_SKIN_PERSISTENT)
     int residentSkinQuarters = -1;
     int residentSkinCharsPerUnit = kResidentSkinCharsPerUnit; // characters per work unit of the resident form (SGE_SKIN_CPW: 1, 2, 4, 8)
     int lastMoveCount = 1;       // characters of the move stage whose cost sum sits in hHeavyDemand[1]
@@ -102,7 +106,7 @@ struct sge_context {
     int platformCount = 0;
     // crowd
     DevCrowd crowd{};
-    DevBuf dBodies, dParams, dCtrl, dIntents, dLoco, dActions, dPalettes[2], dPoseModel, dPoseLocal, dMoveScratch;
+    DevBuf dBodies, dParams, dCtrl, dIntents, dLoco, dActions, dPalettes[2], dPoseModel, dPoseLocal, dMoveScratch, dPoseIn[2];
     DevBuf dOutPos, dOutNrm, dOutTan;
     int outLayoutAllocated = -1;
     // agents
@@ -171,11 +175,21 @@ int syncAll(sge_context* c) {
     SGE_HIP(hipStreamSynchronize(c->stream));
     if (c->skinStream) SGE_HIP(hipStreamSynchronize(c->skinStream));
     if (c->heavyStream) SGE_HIP(hipStreamSynchronize(c->heavyStream));
+    if (c->poseStream) SGE_HIP(hipStreamSynchronize(c->poseStream));
     c->skinPending[0] = c->skinPending[1] = false;
+    c->posePending[0] = c->posePending[1] = false;
+    return SGE_OK;
+}
+// The main stream must not touch what the animation stages own (locomotion / action states, transformRotation, palettes) while a
+// pose launch on the pose stream is in flight.
+int joinPose(sge_context* c) {
+    for (int f = 0; f < 2; ++f)
+        if (c->posePending[f]) { SGE_HIP(hipStreamWaitEvent(c->stream, c->evPosePiped[f], 0)); c->posePending[f] = false; }
     return SGE_OK;
 }
 // The main stream must not touch palettes / skinned outputs while a skin launch is in flight.
 int joinSkin(sge_context* c) {
+    { int rcp = joinPose(c); if (rcp != SGE_OK) return rcp; }
     for (int f = 0; f < 2; ++f)
         if (c->skinPending[f]) { SGE_HIP(hipStreamWaitEvent(c->stream, c->evSkinDone[f], 0)); c->skinPending[f] = false; }
     return SGE_OK;
@@ -493,10 +507,19 @@ sge_context* sge_context_create(int device_index) {
     if (getenv("SGE_SKIN_PERSISTENT")) c->residentSkinQuarters = atoi(getenv("SGE_SKIN_PERSISTENT"));
     if (getenv("SGE_SKIN_CPW")) c->residentSkinCharsPerUnit = atoi(getenv("SGE_SKIN_CPW"));
     if (getenv("SGE_OVERLAP_FUSED_WORKGROUPS")) c->overlapFusedWorkgroups = atoi(getenv("SGE_OVERLAP_FUSED_WORKGROUPS"));
+    if (getenv("SGE_POSE_PIPELINE")) c->pipelinePose = atoi(getenv("SGE_POSE_PIPELINE")) != 0; // experiments: 0 = pose stays on the main stream
     // the latency-bound collision / pose launches go first when they compete with a streaming skin launch (overlap option)
     int prLeast = 0, prGreatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest);
-    if (hipStreamCreateWithPriority(&c->ownStream, hipStreamNonBlocking, prGreatest) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
+    // experiments (SGE_STREAM_PRIO=main:heavy:pose:skin; 0 = greatest, 1 = one below it, ...)
+    int prMain = prGreatest, prHeavy = prGreatest, prPose = prGreatest, prSkin = prLeast;
+    if (getenv("SGE_STREAM_PRIO")) {
+        int a = 0, b = 0, p = 0, k = 99;
+        sscanf(getenv("SGE_STREAM_PRIO"), "%d:%d:%d:%d", &a, &b, &p, &k);
+        auto lvl = [&](int v) { return std::min(prLeast, prGreatest + v); };
+        prMain = lvl(a); prHeavy = lvl(b); prPose = lvl(p); prSkin = lvl(k);
+    }
+    if (hipStreamCreateWithPriority(&c->ownStream, hipStreamNonBlocking, prMain) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
     c->stream = c->ownStream;
     // experiment (SGE_SKIN_CUS=n[:pattern]): the skin stream on a subset of the CUs, the rest left to the collision side alone
     hipError_t skinRc;
@@ -511,23 +534,28 @@ sge_context* sge_context_create(int device_index) {
         }
         skinRc = hipExtStreamCreateWithCUMask(&c->skinStream, 8, mask);
     } else {
-        skinRc = hipStreamCreateWithPriority(&c->skinStream, hipStreamNonBlocking, prLeast);
+        skinRc = hipStreamCreateWithPriority(&c->skinStream, hipStreamNonBlocking, prSkin);
     }
     if (skinRc != hipSuccess ||
         hipEventCreateWithFlags(&c->evPoseDone, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->poseStream, hipStreamNonBlocking, prPose) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evMoveDone, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evPosePiped[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evPosePiped[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evSkinDone[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evSkinDone[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evMainMark, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evConsumed, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evListsReady, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->heavyStream, hipStreamNonBlocking, prGreatest) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->heavyStream, hipStreamNonBlocking, prHeavy) != hipSuccess ||
         hipEventCreateWithFlags(&c->evClassified, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evHeavyDone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evTablesCopied, hipEventDisableTiming) != hipSuccess) { set_error("stream/event creation failed"); delete c; return nullptr; }
-    if (c->dSkinQueue.alloc(256) != SGE_OK) { delete c; return nullptr; }
+    if (c->dSkinQueue.alloc(256) != SGE_OK || hipMemsetAsync(c->dSkinQueue.p, 0, 256, c->stream) != hipSuccess) { delete c; return nullptr; } // the resident LBS forms leave their ticket words at zero
     if (hipHostMalloc(reinterpret_cast<void**>(&c->hHeavyDemand), 2 * sizeof(int), hipHostMallocDefault) == hipSuccess) { c->hHeavyDemand[0] = -1; c->hHeavyDemand[1] = -1; }
     else { (void)hipGetLastError(); c->hHeavyDemand = nullptr; }
     if (c->dStats.alloc((size_t)kStatShards * 64) != SGE_OK || hipMemsetAsync(c->dStats.p, 0, (size_t)kStatShards * 64, c->stream) != hipSuccess) { delete c; return nullptr; }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { set_error("context creation: device synchronisation failed"); delete c; return nullptr; } // the zeroed words are read from other streams
     return c;
 }
 
@@ -539,13 +567,16 @@ void sge_context_destroy(sge_context* c) {
     DevBuf* bufs[] = {&c->dSlotBone, &c->dParent, &c->dDepth, &c->dLeanChain, &c->dPath, &c->dBindLocal, &c->dInvBind, &c->dRestT, &c->dRawRestT, &c->dPreRot,
                       &c->dCoeffs, &c->dCoeffCount, &c->dBonePresent, &c->dMeshPos, &c->dMeshNrm, &c->dMeshTan, &c->dMeshIdx, &c->dMeshWgt,
                       &c->dWide, &c->dTris, &c->dMaterials, &c->dBinNodes[0], &c->dBinNodes[1], &c->dSlotOfRank, &c->dCost, &c->dHint, &c->dHeavyFlags, &c->dJobTable, &c->dBlockJob, &c->dLists, &c->dListCounts, &c->dOrderHist, &c->dWaveProf, &c->dSepAgents, &c->dSepCounts, &c->dSepFlow, &c->dPlatforms, &c->dRayQueries, &c->dRayOut, &c->dBodies, &c->dParams, &c->dCtrl, &c->dIntents, &c->dLoco, &c->dActions,
-                      &c->dPalettes[0], &c->dPalettes[1], &c->dPoseModel, &c->dPoseLocal, &c->dMoveScratch, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
+                      &c->dPalettes[0], &c->dPalettes[1], &c->dPoseIn[0], &c->dPoseIn[1], &c->dPoseModel, &c->dPoseLocal, &c->dMoveScratch, &c->dOutPos, &c->dOutNrm, &c->dOutTan, &c->dCellStart, &c->dCellItems,
                       &c->dCellCursor, &c->dAgentMinMax, &c->dAgentGrid, &c->dAgentsAll, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats,
                       &c->dBlasEntryLink, &c->dBlasWideFirst, &c->dBlasWideParent, &c->dBlasWideLevel, &c->dBlasSlotIdx, &c->dBlasSlotTri,
                       &c->dBlasIndices, &c->dBlasBounds, &c->dBlasInstances, &c->dBlasRays, &c->dBlasHits, &c->dBlasTileStart,
                       &c->dBlasRoundLen, &c->dBlasRoundCluster, &c->dBlasRoundIds, &c->dBlasWorldBoxes, &c->dBlasUVs, &c->dBlasQueue, &c->dSkinQueue};
     for (DevBuf* b : bufs) b->release();
     if (c->evPoseDone) (void)hipEventDestroy(c->evPoseDone);
+    if (c->evMoveDone) (void)hipEventDestroy(c->evMoveDone);
+    for (hipEvent_t e : c->evPosePiped) if (e) (void)hipEventDestroy(e);
+    if (c->poseStream) (void)hipStreamDestroy(c->poseStream);
     if (c->hHeavyDemand) (void)hipHostFree(c->hHeavyDemand);
     if (c->evMainMark) (void)hipEventDestroy(c->evMainMark);
     if (c->evConsumed) (void)hipEventDestroy(c->evConsumed);
@@ -816,6 +847,8 @@ int sge_skin_wait(sge_context* c, void* consumer_stream) {
     if (s == c->stream) return joinSkin(c);
     // launches on the skin stream complete in order: the newest one's event covers them all
     if (c->skinPending[0] || c->skinPending[1]) SGE_HIP(hipStreamWaitEvent(s, c->evSkinDone[c->lastSkin], 0));
+    // a pose launch on the pose stream (they complete in order too)
+    if (c->posePending[0] || c->posePending[1]) SGE_HIP(hipStreamWaitEvent(s, c->evPosePiped[c->poseSlot], 0));
     // and whatever the context has enqueued on its main stream so far (a serial skin stage, pose, move)
     SGE_HIP(hipEventRecord(c->evMainMark, c->stream));
     SGE_HIP(hipStreamWaitEvent(s, c->evMainMark, 0));
@@ -1166,6 +1199,8 @@ int sge_characters_resize(sge_context* c, int32_t count) {
     SGE_ZALLOC(c->dActions, N * sizeof(sge_action_state));
     SGE_ZALLOC(c->dPalettes[0], N * B * 64);
     SGE_ZALLOC(c->dPalettes[1], N * B * 64);
+    SGE_ZALLOC(c->dPoseIn[0], N * sizeof(PoseInput));
+    SGE_ZALLOC(c->dPoseIn[1], N * sizeof(PoseInput));
     c->palRead = 0;
     c->listsValid = false;
     SGE_ZALLOC(c->dMoveScratch, N * (size_t)kMoveScratchBytes);
@@ -1180,7 +1215,8 @@ int sge_characters_resize(sge_context* c, int32_t count) {
     c->crowd = DevCrowd{count, c->dBodies.as<sge_body_state>(), c->dParams.as<sge_controller_params>(),
                         c->dCtrl.as<sge_controller_state>(), c->dIntents.as<sge_move_intent>(),
                         c->dLoco.as<sge_locomotion_state>(), c->dActions.as<sge_action_state>(), c->dPalettes[0].as<float>(),
-                        c->storePoseDebug ? c->dPoseModel.as<float>() : nullptr, c->storePoseDebug ? c->dPoseLocal.as<float>() : nullptr};
+                        c->storePoseDebug ? c->dPoseModel.as<float>() : nullptr, c->storePoseDebug ? c->dPoseLocal.as<float>() : nullptr,
+                        nullptr};
     if (c->mesh.vertexCount > 0 && (rc = allocCrowdOutputs(c)) != SGE_OK) return rc;
     if ((rc = ensureBlasBuffers(c)) != SGE_OK) return rc;
     SGE_HIP(hipStreamSynchronize(c->stream));
@@ -1206,6 +1242,7 @@ int sge_characters_upload(sge_context* c, int32_t first, int32_t count, const sg
     if (a)
         for (int i = 0; i < count; ++i)
             if ((a[i].flags & SGE_ACTION_PRESENT) && (a[i].profile < 0 || a[i].profile >= c->prof.count)) { set_error("action profile index out of range"); return SGE_ERR_INVALID; }
+    { int rcp = joinPose(c); if (rcp != SGE_OK) return rcp; } // a pose launch on the pose stream owns the animation states meanwhile
     hipStream_t s = c->stream;
 #define SGE_UP(ptr, buf, T) if (ptr) SGE_HIP(hipMemcpyAsync((buf).template as<T>() + first, ptr, (size_t)count * sizeof(T), hipMemcpyHostToDevice, s));
     SGE_UP(b, c->dBodies, sge_body_state) SGE_UP(p, c->dParams, sge_controller_params) SGE_UP(cs, c->dCtrl, sge_controller_state)
@@ -1219,6 +1256,7 @@ int sge_characters_download(sge_context* c, int32_t first, int32_t count, sge_bo
                             sge_controller_state* cs, sge_move_intent* in, sge_locomotion_state* l, sge_action_state* a) {
     SGE_RANGE_CHECK();
     (void)hipSetDevice(c->device);
+    { int rcp = joinPose(c); if (rcp != SGE_OK) return rcp; }
     hipStream_t s = c->stream;
 #define SGE_DN(ptr, buf, T) if (ptr) SGE_HIP(hipMemcpyAsync(ptr, (buf).template as<T>() + first, (size_t)count * sizeof(T), hipMemcpyDeviceToHost, s));
     SGE_DN(b, c->dBodies, sge_body_state) SGE_DN(p, c->dParams, sge_controller_params) SGE_DN(cs, c->dCtrl, sge_controller_state)
@@ -1270,6 +1308,15 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
     if (count == 0) return SGE_OK;
     (void)hipSetDevice(c->device);
     const uint32_t st = d->stages;
+    // Overlap mode, a whole-crowd tick with move + pose + skin: the pose launch goes to the pose stream and reads the move stage's
+    // results from the copy the move kernels write (PoseInput), so that the NEXT tick's move stage does not queue behind it.
+    // (not with the separation stage, which moves bodies after the move kernels have written the copy; not with the cycle-stamp
+    // diagnostics, whose buffer is cleared on the main stream)
+    const bool pipedPose = c->pipelinePose && c->overlapSkin && c->poseStream && first == 0 && count == c->crowd.count &&
+                           (st & (SGE_STAGE_INTENT | SGE_STAGE_GRAVITY | SGE_STAGE_MOVE)) && !(st & SGE_STAGE_SEPARATION) &&
+                           (st & SGE_STAGE_POSE) && (st & SGE_STAGE_SKIN) && !c->waveProfOn && c->boneCount > 0 && c->prof.count > 0 &&
+                           c->mesh.vertexCount > 0;
+    const int poseSlot = c->poseSlot ^ 1;
     if (st & (SGE_STAGE_INTENT | SGE_STAGE_GRAVITY | SGE_STAGE_MOVE)) {
         if ((st & SGE_STAGE_MOVE) && c->col.root < 0 && c->col.triCount != 0) { set_error("collision world not built"); return SGE_ERR_STATE; }
         if ((st & SGE_STAGE_AGENTS) && (st & SGE_STAGE_MOVE)) {
@@ -1303,12 +1350,19 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
             L.waveProf = c->dWaveProf.as<unsigned long long>();
         }
         if (!(st & SGE_STAGE_AGENTS) || !c->agents.grid) L.agents.all = nullptr;
-        Bracket br(c, &c->evMove);
-        const bool built = launch_move(L, c->stream);
-        if (st & SGE_STAGE_MOVE) {
-            c->listsValid = built;
-            c->listsFirst = first; c->listsCount = count; c->listsThreshold = c->heavyThreshold; c->listsCap = capNow;
+        if (pipedPose) { // the copy pose(n-2) read must be free again
+            if (c->posePending[poseSlot]) { SGE_HIP(hipStreamWaitEvent(c->stream, c->evPosePiped[poseSlot], 0)); c->posePending[poseSlot] = false; }
+            L.crowd.poseIn = c->dPoseIn[poseSlot].as<PoseInput>();
         }
+        {
+            Bracket br(c, &c->evMove);
+            const bool built = launch_move(L, c->stream);
+            if (st & SGE_STAGE_MOVE) {
+                c->listsValid = built;
+                c->listsFirst = first; c->listsCount = count; c->listsThreshold = c->heavyThreshold; c->listsCap = capNow;
+            }
+        }
+        if (pipedPose) SGE_HIP(hipEventRecord(c->evMoveDone, c->stream));
     }
     if (st & SGE_STAGE_SEPARATION) { // AgentSeparationSystem: after the move stage, before the animation stages (DemoScene.swift:66-71)
         if (first != 0 || count != c->crowd.count) { set_error("SGE_STAGE_SEPARATION works on the whole crowd (first = 0, count = all)"); return SGE_ERR_INVALID; }
@@ -1323,11 +1377,16 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
     }
     if (st & (SGE_STAGE_LOCOMOTION | SGE_STAGE_ACTION | SGE_STAGE_POSE | SGE_STAGE_WRITEBACK)) {
         if ((st & SGE_STAGE_POSE) && (c->boneCount == 0 || c->prof.count == 0)) { set_error("pose stage needs a skeleton and motion profiles"); return SGE_ERR_STATE; }
+        hipStream_t ps = pipedPose ? c->poseStream : c->stream;
+        if (!pipedPose) { int rcp = joinPose(c); if (rcp != SGE_OK) return rcp; } // the animation states are the pose stream's meanwhile
         if (st & SGE_STAGE_POSE) {
             const bool flip = c->overlapSkin && first == 0 && count == c->crowd.count;
             if (flip) { // write the buffer no skin launch newer than skin(n-1) reads
                 const int f = c->palRead ^ 1;
-                if (c->skinPending[f]) { SGE_HIP(hipStreamWaitEvent(c->stream, c->evSkinDone[f], 0)); c->skinPending[f] = false; }
+                if (c->skinPending[f]) {
+                    SGE_HIP(hipStreamWaitEvent(ps, c->evSkinDone[f], 0));
+                    if (!pipedPose) c->skinPending[f] = false; // (piped: the main stream itself has not joined that launch)
+                }
                 c->palRead = f;
             } else { // palettes are rewritten in place
                 int rcj = joinSkin(c);
@@ -1337,8 +1396,19 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         }
         PoseLaunch L{c->crowd, c->sk, c->prof, d->dt, st, first, count,
                      c->waveProfOn && c->dWaveProf.p ? c->dWaveProf.as<unsigned long long>() + (size_t)c->crowd.count * 2 * 8 : nullptr};
-        Bracket br(c, &c->evPose);
-        launch_pose(L, c->stream);
+        if (pipedPose) {
+            SGE_HIP(hipStreamWaitEvent(ps, c->evMoveDone, 0));
+            L.crowd.poseIn = c->dPoseIn[poseSlot].as<PoseInput>();
+        }
+        {
+            Bracket br(c, &c->evPose, ps);
+            launch_pose(L, ps);
+        }
+        if (pipedPose) {
+            SGE_HIP(hipEventRecord(c->evPosePiped[poseSlot], ps));
+            c->posePending[poseSlot] = true;
+            c->poseSlot = poseSlot;
+        }
     }
     if (st & SGE_STAGE_SKIN) {
         if (c->mesh.vertexCount == 0) { set_error("skin stage needs a skinned mesh"); return SGE_ERR_STATE; }
@@ -1355,8 +1425,11 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         if (overlap) {
             // skin(n) on its own stream after pose(n) (and, stream order, after skin(n-1)); move(n+1) and pose(n+1) may run on
             // the main stream meanwhile
-            SGE_HIP(hipEventRecord(c->evPoseDone, c->stream));
-            SGE_HIP(hipStreamWaitEvent(c->skinStream, c->evPoseDone, 0));
+            if (pipedPose) SGE_HIP(hipStreamWaitEvent(c->skinStream, c->evPosePiped[poseSlot], 0));
+            else {
+                SGE_HIP(hipEventRecord(c->evPoseDone, c->stream));
+                SGE_HIP(hipStreamWaitEvent(c->skinStream, c->evPoseDone, 0));
+            }
             ss = c->skinStream;
         } else { // the output streams may still be written by an overlapped launch of an earlier tick
             int rcj = joinSkin(c);
@@ -1376,11 +1449,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
                 // resident workgroups or workgroups that hand their places over (see kResidentSkinCharacters)
                 int quarters = 0;
                 if (overlap && c->residentSkinQuarters >= 0) quarters = c->residentSkinQuarters;
-                else if (overlap && count >= kResidentSkinCharacters) {
-                    const long long evals = c->hHeavyDemand ? (long long)*(volatile int*)(c->hHeavyDemand + 1) : -1;
-                    const bool moveHeavy = (st & SGE_STAGE_MOVE) && evals > (long long)kMoveHeavyEvaluations * c->lastMoveCount;
-                    quarters = moveHeavy ? 0 : kResidentSkinQuarters;
-                }
+                else if (overlap && count >= kResidentSkinCharacters) quarters = kResidentSkinQuarters;
                 launch_skin(L, ss, overlap ? c->overlapSkinWorkgroups : 0, c->dSkinQueue.as<int>(), quarters, c->residentSkinCharsPerUnit);
                 c->lastSkinQuarters = quarters;
                 c->lastSkinCharsPerUnit = quarters > 0 && count >= 64 ? c->residentSkinCharsPerUnit : 1;

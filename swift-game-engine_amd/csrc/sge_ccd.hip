@@ -116,6 +116,21 @@ __shared__ sge_controller_params sParamsA[kGroup];
 __shared__ sge_controller_state sCtrlA[kGroup];
 
 __device__ __forceinline__ int laneId() { return threadIdx.x & (kWave - 1); }
+// Write-back of LDS slot g to character e: the body words the move stage owns, the controller, and (crowd.poseIn) the animation
+// stages' copy of what they read of the two (PoseInput: lanes 32..47 gather its 16 dwords from the same LDS slots).
+__device__ __forceinline__ void storeCharacter(const DevCrowd& crowd, const int e, const int g, const int lane) {
+    uint32_t* gb = reinterpret_cast<uint32_t*>(crowd.bodies + e);
+    uint32_t* gc = reinterpret_cast<uint32_t*>(crowd.controllers + e);
+    const uint32_t* sb = reinterpret_cast<const uint32_t*>(&sBodyA[g]);
+    const uint32_t* sc = reinterpret_cast<const uint32_t*>(&sCtrlA[g]);
+    if (lane < kBodyMoveWords) gb[lane] = sb[lane];
+    if (lane < 32) gc[lane] = sc[lane];
+    if (crowd.poseIn && lane >= 32 && lane < 48) {
+        const int j = lane - 32;
+        const uint32_t* src = j < 10 ? sb + 6 + j : (j < 13 ? sc + (j - 10) : sc + kCtrlFlagsWord + (j - 13)); // j = 15: the controller's first pad word
+        reinterpret_cast<uint32_t*>(crowd.poseIn + e)[j] = *src;
+    }
+}
 __device__ __forceinline__ int prefixCount(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
 }
@@ -1767,12 +1782,7 @@ __global__ __launch_bounds__(HEAVY ? kWave * kHeavyWaves : kWave, PART == 0 ? (S
     }
     __syncthreads();
     if (PART == 0 && lane < (int)(sizeof(MoveState) / 4)) scratch[lane] = reinterpret_cast<const uint32_t*>(&ms)[lane];
-    {
-        uint32_t* gb = reinterpret_cast<uint32_t*>(K.crowd.bodies + e);
-        uint32_t* gc = reinterpret_cast<uint32_t*>(K.crowd.controllers + e);
-        if (lane < 24) gb[lane] = reinterpret_cast<const uint32_t*>(&sBodyA[0])[lane];
-        if (lane < 32) gc[lane] = reinterpret_cast<const uint32_t*>(&sCtrlA[0])[lane];
-    }
+    storeCharacter(K.crowd, e, 0, lane);
 #ifdef SGE_CCD_TIMING
     if (lane == 0) {
         atomicAdd(&g_cycTotal, (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - tStart));
@@ -2390,10 +2400,7 @@ __global__ __launch_bounds__(kWave, SGE_CCD_EXCLUSIVE ? 2 : SGE_GROUP_WAVES) voi
             sBodyA[g].linearVelocity[0] = velocity.x; sBodyA[g].linearVelocity[1] = velocity.y; sBodyA[g].linearVelocity[2] = velocity.z;
         }
         __syncthreads();
-        uint32_t* gb = reinterpret_cast<uint32_t*>(K.crowd.bodies + e);
-        uint32_t* gc = reinterpret_cast<uint32_t*>(K.crowd.controllers + e);
-        if (lane < 24) gb[lane] = reinterpret_cast<const uint32_t*>(&sBodyA[g])[lane];
-        if (lane < 32) gc[lane] = reinterpret_cast<const uint32_t*>(&sCtrlA[g])[lane];
+        storeCharacter(K.crowd, e, g, lane);
         if (lane == 0) {
             if (K.cost) K.cost[e] = sGroupCost[g];
             if (K.hint) K.hint[e] = (uint8_t)(ms.sampled != 0);
@@ -2654,10 +2661,7 @@ __global__ __launch_bounds__(kWave, 3) void separation_post_kernel(SepLaunch K) 
     body.position[0] = pd.x; body.position[1] = pd.y; body.position[2] = pd.z;
     body.linearVelocity[0] = vd.x; body.linearVelocity[1] = vd.y; body.linearVelocity[2] = vd.z;
     __syncthreads();
-    uint32_t* gb = reinterpret_cast<uint32_t*>(K.crowd.bodies + e);
-    uint32_t* gc = reinterpret_cast<uint32_t*>(K.crowd.controllers + e);
-    if (lane < 24) gb[lane] = reinterpret_cast<const uint32_t*>(&sBodyA[0])[lane];
-    if (lane < 32) gc[lane] = reinterpret_cast<const uint32_t*>(&sCtrlA[0])[lane];
+    storeCharacter(K.crowd, e, 0, lane);
 }
 
 
@@ -3214,14 +3218,14 @@ bool launch_move(const MoveLaunch& L, hipStream_t s) {
             hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, q, L.orderHist, L.listCounts);
             hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, q, L.cost, L.first, L.count, L.heavyFlags, L.orderHist, L.lists);
         }
-        // how many characters asked for the multi-wave launch, and the crowd's evaluations: read by the host when it enqueues a
-        // later step (pinned memory)
+    };
+    // how many characters asked for the multi-wave launch, and the crowd's evaluations: read by the host when it enqueues a later
+    // step (pinned memory; the copy takes ~45 us, so it goes behind the event that says the lists are ready)
+    auto copyDemand = [&](hipStream_t q) {
         if (heavy && L.heavyDemandHost) (void)hipMemcpyAsync(L.heavyDemandHost, L.listCounts + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, q);
     };
-    if (move) {
-        if (pipelined && L.listsReady) (void)hipStreamWaitEvent(s, L.evListsReady, 0); // built behind the previous step, on the second stream
-        else buildLists(s, L.heavyCap);                                                 // first step, or something changed
-    }
+    const bool listsFromLastStep = move && pipelined && L.listsReady; // built behind the previous step, on the second stream
+    if (move && !listsFromLastStep) { buildLists(s, L.heavyCap); copyDemand(s); } // first step, or something changed
     // (part 0 at the head of the grouped launch instead — no launch in front of the stage, no round trip of the working set — was
     // built and measured: the grouped kernel then needs 166 registers instead of 155, one wavefront fewer fits beside two resident
     // LBS wavefronts, and the step is 1-6 % slower: 0.998 against 0.987 ms, against 0.937 with 155)
@@ -3229,6 +3233,7 @@ bool launch_move(const MoveLaunch& L, hipStream_t s) {
     // 0.946 ms per step: the launch is short either way and a wavefront's four overlap queries in a row are not)
     hipLaunchKernelGGL((move_kernel<0, false>), dim3(L.count), dim3(kWave), 0, s, L);
     if (!move) return false;
+    if (listsFromLastStep) (void)hipStreamWaitEvent(s, L.evListsReady, 0); // part 0 reads none of the lists: the wait goes behind it
     MoveLaunch G = L;
     // The multi-wave launch goes FIRST and stays on the main stream, right behind part 0: its 512-thread workgroups need
     // two free wavefront places on every SIMD of one CU at the same moment, which they find while the chip holds nothing but the
@@ -3262,6 +3267,7 @@ bool launch_move(const MoveLaunch& L, hipStream_t s) {
         (void)hipStreamWaitEvent(gs, L.evClassified, 0);
         buildLists(gs, L.nextHeavyCap);
         (void)hipEventRecord(L.evListsReady, gs);
+        copyDemand(gs);
     }
     return pipelined;
 }
@@ -3539,7 +3545,9 @@ void launch_agents_pad(sge_agent_state* d_out, int n, hipStream_t s) {
 }
 void launch_agents_export(const DevCrowd& crowd, sge_agent_state* d_out, hipStream_t s) {
     if (crowd.count <= 0) return;
-    hipLaunchKernelGGL(agents_export_kernel, dim3((crowd.count + 255) / 256), dim3(256), 0, s, crowd, d_out);
+    // one-wave workgroups: beside a pose launch on the pose stream (16k one-wave workgroups taking every place that comes free) a
+    // 256-thread workgroup waited for four free places on one CU and the launch took 57 us for 10,000 agents
+    hipLaunchKernelGGL(agents_export_kernel, dim3((crowd.count + kWave - 1) / kWave), dim3(kWave), 0, s, crowd, d_out);
 }
 
 } // namespace sge

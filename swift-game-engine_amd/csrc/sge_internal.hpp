@@ -1,6 +1,7 @@
 // Internal declarations of libsge_amd.so (context, device layouts, launchers).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <string>
 #include <vector>
 #include "../../include/sge_amd.h"
@@ -94,6 +95,26 @@ struct DevCollision {
     const int* slotOfRank;          // slot in `tris` of the triangle with a given (offset) visit rank
 };
 
+// What the animation stages read of a character's body and controller, copied out by the move stage's write-back (16 dwords): with it
+// pose(n) needs nothing that move(n+1) writes and runs BESIDE move(n+1), on a stream of its own, instead of in front of it
+// (overlap mode, sge_tick). The dwords are body words 6..15 (linearVelocity, rotation), controller words 0..2 (groundNormal) and the
+// controller's flags / groundDistance pair.
+struct PoseInput {
+    double linearVelocity[3];
+    float rotation[4];
+    float groundNormal[3];
+    uint32_t flags;
+    float groundDistance;
+    uint32_t pad;
+};
+static_assert(sizeof(PoseInput) == 64, "one 64-byte line per character");
+static_assert(offsetof(sge_body_state, linearVelocity) == 24 && offsetof(sge_body_state, rotation) == 48 &&
+              offsetof(sge_body_state, transformRotation) == 64, "PoseInput copies body words 6..15; words 16.. are not the move stage's");
+static_assert(offsetof(sge_controller_state, groundNormal) == 0 &&
+              offsetof(sge_controller_state, groundDistance) == offsetof(sge_controller_state, flags) + 4, "PoseInput controller words");
+constexpr int kCtrlFlagsWord = (int)(offsetof(sge_controller_state, flags) / 4);
+constexpr int kBodyMoveWords = 16; // the words of sge_body_state the move / separation kernels store (transformRotation is the pose stage's)
+
 struct DevCrowd {
     int count;
     sge_body_state* bodies;
@@ -105,6 +126,8 @@ struct DevCrowd {
     float* palettes;   // [N][B][16]
     float* poseModel;  // [N][B][16] (debug) or null
     float* poseLocal;  // [N][B][16] (debug) or null
+    PoseInput* poseIn; // [N] or null. Move stage: written with every body / controller write-back. Animation stages: read INSTEAD of
+                       // bodies / controllers (null: read those).
 };
 
 struct DevMesh {
@@ -258,13 +281,14 @@ constexpr int kMoveScratchBytes = 256;
 constexpr int kTraversalStackCap = 256; // LDS stack of pending wide nodes per query (sge_ccd.hip)
 constexpr int kStatShards = 256; // device counters: kStatShards lines of 8 x u64
 // Overlap mode: crowds from this size on skin with RESIDENT workgroups (kResidentSkinQuarters / 4 per CU, drawing work
-// units of kResidentSkinCharsPerUnit characters from a ticket counter) — unless the move stage is the longer side of the step anyway
-// (more than kMoveHeavyEvaluations distance evaluations per character in the last step that reported back), where LBS workgroups
-// that come and go slow the collision chain less than resident ones.
-constexpr int kResidentSkinCharacters = 4096;
+// units of kResidentSkinCharsPerUnit characters from a ticket counter); smaller crowds with workgroups that come and go. Measured with
+// the pose launch beside the next move stage (profiles/r3_pose_beside_move.txt): 5,000 characters 0.534 (come and go) against 0.554 ms
+// on the cheese mesh and 0.68 against 0.74 on the synthetic terrain; 6,500 characters 0.72 against 0.62 and 0.85 against 0.78;
+// 10,000 on the synthetic terrain 1.35-1.42 against 1.13-1.17 (the rule that kept collision-heavy steps with the come-and-go form
+// dates from the schedule with pose in front of the next move stage and is gone).
+constexpr int kResidentSkinCharacters = 6000;
 constexpr int kResidentSkinQuarters = 6;
 constexpr int kResidentSkinCharsPerUnit = 4;
-constexpr int kMoveHeavyEvaluations = 300;
 // returns true when the lists of the NEXT step (same range, threshold, cap = nextHeavyCap) have been enqueued behind this stage
 bool launch_move(const MoveLaunch& L, hipStream_t s);
 constexpr size_t kSeparationAgentBytes = 56; // SepAgentDev (sge_ccd.hip)

@@ -190,18 +190,25 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
     sge_action_state A = K.crowd.actions[e];
     const sge_body_state& body = K.crowd.bodies[e];
     const sge_controller_state& C = K.crowd.controllers[e];
-    const uint32_t ctrlFlags = C.flags;
+    // what the stages read of the move stage's results: from the move stage's copy when the launch runs beside the NEXT step's move
+    // stage (K.crowd.poseIn), from the body / controller themselves otherwise. transformRotation is this kernel's own.
+    const PoseInput* const pin = K.crowd.poseIn ? K.crowd.poseIn + e : nullptr;
+    const double* const velocityIn = pin ? pin->linearVelocity : body.linearVelocity;
+    const float* const rotationIn = pin ? pin->rotation : body.rotation;
+    const float* const groundNormalIn = pin ? pin->groundNormal : C.groundNormal;
+    const float* const groundDistanceIn = pin ? &pin->groundDistance : &C.groundDistance;
+    const uint32_t ctrlFlags = pin ? pin->flags : C.flags;
     const bool hasLoco = (L.flags & SGE_LOCO_PRESENT) != 0;
     const bool hasMotion = (L.flags & SGE_MOTION_PRESENT) != 0;
 
     // ---- LocomotionProfileSystem (Systems.swift:326-406) ----
     if ((K.stages & SGE_STAGE_LOCOMOTION) && hasLoco && hasMotion) {
-        D3 hv{body.linearVelocity[0], 0.0, body.linearVelocity[2]};
+        D3 hv{velocityIn[0], 0.0, velocityIn[2]};
         float speed = (float)length(hv);
         bool isAirborne = !(ctrlFlags & SGE_CTRL_GROUNDED_NEAR);
         int nextState;
         if (isAirborne) {
-            bool highFall = C.groundDistance >= L.fallMinDropHeight;
+            bool highFall = *groundDistanceIn >= L.fallMinDropHeight;
             if (L.state == SGE_LOCO_FALLING || highFall) nextState = SGE_LOCO_FALLING;
             else nextState = groundedNextState(L.state, speed, L);
         } else {
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
             F3 forward = quatAct(trot, F3{0, 0, -1});
             F3 fh{forward.x, 0, forward.z};
             F3 forwardHoriz = lengthSq(fh) > 0.0001f ? normalize(fh) : F3{0, 0, -1};
-            F3 groundNormal{C.groundNormal[0], C.groundNormal[1], C.groundNormal[2]};
+            F3 groundNormal{groundNormalIn[0], groundNormalIn[1], groundNormalIn[2]};
             bool useTilt = (ctrlFlags & SGE_CTRL_GROUNDED_NEAR) != 0;
             Quat alignQuat;
             if (!useTilt) {
@@ -544,7 +551,7 @@ __global__ __launch_bounds__(kWave, SGE_POSE_WAVES) void pose_kernel(PoseLaunch 
         if (K.stages & SGE_STAGE_WRITEBACK) {
             sge_body_state& b = K.crowd.bodies[e];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) b.transformRotation[k] = b.rotation[k];
+            for (int k = 0; k < 4; ++k) b.transformRotation[k] = rotationIn[k];
         }
     }
 }

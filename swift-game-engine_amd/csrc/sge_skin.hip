@@ -310,6 +310,17 @@ __device__ __forceinline__ void skinRangeMulti(const SkinLaunch& L, const int c0
     }
 }
 
+// The ticket counter of the resident forms is left at zero by the launch itself: queue[1] counts the workgroups that have drawn
+// their last ticket, and the last of them clears both words (every ticket has been answered by then: a workgroup waits for its
+// ticket before it goes on). The launcher's memset in front of every launch was a 5 us fill kernel plus a dispatch on the skin
+// stream, between two skin launches that follow each other directly in overlap mode. (The words are zeroed once, at allocation.)
+__device__ __forceinline__ void ticketsDone(int* __restrict__ queue) {
+    if (threadIdx.x == 0 && atomicAdd(queue + 1, 1) == (int)gridDim.x - 1) {
+        __hip_atomic_store(queue, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(queue + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // The resident form with CPW characters per work unit (unit u = (group of CPW consecutive characters, vertex split)); dynamic LDS:
 // CPW palettes of L.paletteCount bones + the ticket slot behind them.
 template <int DST_STRIDE, int CPW>
@@ -332,6 +343,7 @@ __global__ __launch_bounds__(kSkinBlock, SGE_SKIN_MULTI_MIN_BLOCKS) void skin_ti
         __syncthreads(); // also: every thread is done with the palettes
         u = *sNextUnit;
     }
+    ticketsDone(queue);
 }
 
 template <int SRC_STRIDE, int DST_STRIDE>
@@ -371,6 +383,7 @@ __global__ __launch_bounds__(kSkinBlock, SGE_SKIN_MIN_BLOCKS) void skin_ticket_k
         __syncthreads(); // also: every thread is done with the palette
         u = sNextUnit; // the next write follows the next unit's barrier in skinRange
     }
+    ticketsDone(queue);
 }
 
 // RTSkinningEncoder.encode over a heterogeneous job list (RTSkinningEncoder.swift:37-54 dispatches once per job): ONE launch.
@@ -460,7 +473,6 @@ void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU, int
         int vps = ((L.vertexCount + sp2 - 1) / sp2 + kSkinBlock - 1) / kSkinBlock * kSkinBlock;
         sp2 = (L.vertexCount + vps - 1) / vps;
         const size_t lds = (size_t)cpw * L.paletteCount * 48 + 16;
-        (void)hipMemsetAsync(residentQueue, 0, sizeof(int), s);
         dim3 pgrid((unsigned)std::min<size_t>((size_t)sp2 * groups, (size_t)currentDeviceCUs() * residentQuarters / 4));
         if (cpw == 2) {
             if (ds == 3) hipLaunchKernelGGL((skin_ticket_multi_kernel<3, 2>), pgrid, dim3(kSkinBlock), lds, s, L, sp2, vps, residentQueue);
@@ -474,8 +486,7 @@ void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU, int
         }
         return;
     }
-    if (residentQueue && residentQuarters > 0 && L.srcLayout != SGE_LAYOUT_PADDED16) { // resident workgroups + ticket counter
-        (void)hipMemsetAsync(residentQueue, 0, sizeof(int), s);
+    if (residentQueue && residentQuarters > 0 && L.srcLayout != SGE_LAYOUT_PADDED16) { // resident workgroups + ticket counter (left at zero by the launch before)
         dim3 pgrid((unsigned)std::min<size_t>((size_t)splits * L.chars, (size_t)currentDeviceCUs() * residentQuarters / 4));
         if (ds == 3) hipLaunchKernelGGL((skin_ticket_kernel<3, 3>), pgrid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit, residentQueue);
         else hipLaunchKernelGGL((skin_ticket_kernel<3, 4>), pgrid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit, residentQueue);

@@ -1116,6 +1116,62 @@ def test_bench_default_full_size(sge):
     cpu.close()
 
 
+def test_pose_beside_the_next_move_stage(sge, monkeypatch):
+    """Overlap mode runs pose(n) on a stream of its own, beside move(n+1): the move kernels leave a copy of what the animation stages
+    read of bodies / controllers (PoseInput, two buffers) and no longer store transformRotation, which is the pose stage's. The
+    schedule must not change a bit: 3,000 characters stepped back to back (no host synchronisation between the ticks, so the
+    launches really overlap), with everything that leaves the pipelined form mixed in — a partial-range tick, a tick without the skin
+    stage, a tick with the separation stage, states re-uploaded mid-run, a pose-only tick — against the same sequence with the
+    pose launch kept on the main stream (SGE_POSE_PIPELINE=0, read when a context is created)."""
+    abi = sge.abi
+    ybot = sge.assets.YBotAssets()
+    n, V_check = 3000, (0, 1499, 2999)
+
+    def run(piped):
+        monkeypatch.setenv("SGE_POSE_PIPELINE", "1" if piped else "0")
+        eng = sge.CharacterEngine(0)
+        eng.set_option(abi.OPT_OVERLAP_SKIN, 1)
+        sge.crowd.upload_character_assets(eng, ybot, rings=8, segments=8)
+        scene = sge.crowd.upload_asset_scene(eng, ("cheese",), footprint=120.0)
+        sge.crowd.spawn_crowd(eng, ybot, n, scene, seed=77, mixed=True, agents=True)
+        snaps = []
+        for s in range(64):
+            if s == 9:
+                eng.tick(first=100, count=900)                                  # partial range: pose on the main stream
+            elif s == 17:
+                eng.tick(stages=abi.STAGE_ALL & ~abi.STAGE_SKIN)                # no skin stage
+            elif s == 23:
+                eng.tick(stages=abi.STAGE_ALL | abi.STAGE_SEPARATION)           # bodies move again behind the move kernels
+            elif s == 31:
+                eng.tick(stages=abi.STAGE_LOCOMOTION | abi.STAGE_ACTION | abi.STAGE_POSE | abi.STAGE_WRITEBACK | abi.STAGE_SKIN)
+            elif s == 40:                                                       # teleport a block of characters, reset their clocks
+                st = eng.download(first=500, count=64)
+                st["bodies"]["position"][:, 1] += 3.0
+                st["bodies"]["linearVelocity"][:] = 0
+                st["locomotion"]["motionTime"][:] = 0
+                eng.upload(first=500, bodies=st["bodies"], locomotion=st["locomotion"])
+                eng.tick()
+            else:
+                eng.tick()
+            if s in (8, 9, 10, 17, 18, 23, 24, 31, 32, 40, 41, 63):
+                d = eng.download()
+                V = eng.vertex_count
+                snaps.append((s, d, eng.palettes()[0].copy(), [[a.copy() for a in eng.skinned(first_vertex=c * V, vertex_count=V)] for c in V_check]))
+        assert eng.move_stats().overflow == 0
+        eng.close()
+        return snaps
+
+    a, b = run(True), run(False)
+    monkeypatch.delenv("SGE_POSE_PIPELINE", raising=False)
+    for (s, da, pa, va), (_, db, pb, vb) in zip(a, b):
+        for k in ("bodies", "controllers", "locomotion", "actions"):
+            assert_struct_equal(da[k], db[k], "%s after tick %d (pose beside move vs pose in front of it)" % (k, s))
+        assert np.array_equal(pa, pb), s
+        for ca, cb in zip(va, vb):
+            for x, y in zip(ca, cb):
+                assert np.array_equal(x, y), s
+
+
 def test_overlap_on_a_caller_stream_with_a_consumer(sge):
     """SGE_OPT_OVERLAP_SKIN behind the reference's calling convention: RTSkinningEncoder.encode enqueues on the CALLER's command
     buffer and the consumer enqueued right behind it sees the skinned vertices (RTSkinningEncoder.swift:27-56,
