@@ -247,7 +247,11 @@ enum {
                                    * (sge_context_set_stream): the skin launch is ordered behind the pose stage on that stream by
                                    * events. What is enqueued on the caller's stream behind sge_tick is then NOT ordered behind
                                    * the skin launch by itself: a consumer of the skinned streams calls sge_skin_wait first
-                                   * (sge_blas_refit*, sge_skinning_encode, the downloads and sge_synchronize join by themselves). */
+                                   * (sge_blas_refit*, sge_skinning_encode, the downloads and sge_synchronize join by themselves).
+                                   * A whole-crowd tick with move + pose + skin stages also runs its POSE launch on a stream of
+                                   * the context's own, beside the next tick's move stage: palettes, locomotion / action states and
+                                   * transformRotation of tick n are complete where its skin launch is — sge_skin_wait orders a
+                                   * consumer behind both, sge_characters_upload / _download join by themselves. */
 };
 enum {
     SGE_LAYOUT_PACKED = 0,  /* positions/normals float[3] (12 B), tangents float[4] */
@@ -366,8 +370,8 @@ int sge_crowd_buffers(sge_context* ctx, void** d_palettes, void** d_outPositions
 /* Both palette buffers ([2]; they do not move until sge_characters_resize) and the index of the one holding the newest pose. */
 int sge_crowd_palette_buffers(sge_context* ctx, void** d_palettes, int32_t* latest);
 /* Orders `consumer_stream` (a hipStream_t; NULL: the context's own current stream) behind every skin launch and every other kernel
- * the context has enqueued so far, without a host synchronisation: hipStreamWaitEvent on the newest skin launch's event (+ a
- * marker on the main stream when the consumer is a different stream). The equivalent of enqueueing behind
+ * the context has enqueued so far, without a host synchronisation: hipStreamWaitEvent on the newest skin launch's event and on the
+ * newest pose launch's, if that ran on the pose stream (+ a marker on the main stream when the consumer is a different stream). The equivalent of enqueueing behind
  * RTSkinningEncoder.encode on the same MTLCommandBuffer (RTSkinningEncoder.swift:27-56; consumed at RayTracingScene.swift:35-43). */
 int sge_skin_wait(sge_context* ctx, void* consumer_stream);
 /* The reverse ordering, for a consumer that reads the skinned streams asynchronously on a stream of its own: everything

@@ -1310,11 +1310,10 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
     const uint32_t st = d->stages;
     // Overlap mode, a whole-crowd tick with move + pose + skin: the pose launch goes to the pose stream and reads the move stage's
     // results from the copy the move kernels write (PoseInput), so that the NEXT tick's move stage does not queue behind it.
-    // (not with the separation stage, which moves bodies after the move kernels have written the copy; not with the cycle-stamp
-    // diagnostics, whose buffer is cleared on the main stream)
+    // (not with the separation stage, which moves bodies after the move kernels have written the copy)
     const bool pipedPose = c->pipelinePose && c->overlapSkin && c->poseStream && first == 0 && count == c->crowd.count &&
                            (st & (SGE_STAGE_INTENT | SGE_STAGE_GRAVITY | SGE_STAGE_MOVE)) && !(st & SGE_STAGE_SEPARATION) &&
-                           (st & SGE_STAGE_POSE) && (st & SGE_STAGE_SKIN) && !c->waveProfOn && c->boneCount > 0 && c->prof.count > 0 &&
+                           (st & SGE_STAGE_POSE) && (st & SGE_STAGE_SKIN) && c->boneCount > 0 && c->prof.count > 0 &&
                            c->mesh.vertexCount > 0;
     const int poseSlot = c->poseSlot ^ 1;
     if (st & (SGE_STAGE_INTENT | SGE_STAGE_GRAVITY | SGE_STAGE_MOVE)) {
@@ -1346,7 +1345,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         L.nextHeavyCap = capNow;
         if (c->waveProfOn) {
             if (c->dWaveProf.alloc((size_t)c->crowd.count * 3 * 64) != SGE_OK) return SGE_ERR_DEVICE;
-            SGE_HIP(hipMemsetAsync(c->dWaveProf.p, 0, (size_t)c->crowd.count * 3 * 64, c->stream));
+            SGE_HIP(hipMemsetAsync(c->dWaveProf.p, 0, (size_t)c->crowd.count * 2 * 64, c->stream)); // (region 2 is cleared on the stream the pose launch takes)
             L.waveProf = c->dWaveProf.as<unsigned long long>();
         }
         if (!(st & SGE_STAGE_AGENTS) || !c->agents.grid) L.agents.all = nullptr;
@@ -1400,6 +1399,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
             SGE_HIP(hipStreamWaitEvent(ps, c->evMoveDone, 0));
             L.crowd.poseIn = c->dPoseIn[poseSlot].as<PoseInput>();
         }
+        if (L.waveProf) SGE_HIP(hipMemsetAsync(L.waveProf, 0, (size_t)c->crowd.count * 64, ps));
         {
             Bracket br(c, &c->evPose, ps);
             launch_pose(L, ps);

@@ -282,7 +282,7 @@ constexpr int kTraversalStackCap = 256; // LDS stack of pending wide nodes per q
 constexpr int kStatShards = 256; // device counters: kStatShards lines of 8 x u64
 // Overlap mode: crowds from this size on skin with RESIDENT workgroups (kResidentSkinQuarters / 4 per CU, drawing work
 // units of kResidentSkinCharsPerUnit characters from a ticket counter); smaller crowds with workgroups that come and go. Measured with
-// the pose launch beside the next move stage (profiles/r3_pose_beside_move.txt): 5,000 characters 0.534 (come and go) against 0.554 ms
+// the pose launch beside the next move stage (profiles/r3_schedule_sweeps.txt, block 15): 5,000 characters 0.534 (come and go) against 0.554 ms
 // on the cheese mesh and 0.68 against 0.74 on the synthetic terrain; 6,500 characters 0.72 against 0.62 and 0.85 against 0.78;
 // 10,000 on the synthetic terrain 1.35-1.42 against 1.13-1.17 (the rule that kept collision-heavy steps with the come-and-go form
 // dates from the schedule with pose in front of the next move stage and is gone).

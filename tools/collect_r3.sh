@@ -16,6 +16,7 @@ for mode in default serial; do
   timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/trace_$mode -o run --output-format csv -- python3 $REPO/bench.py --steps 200 --warmup 20 $flags > $OUT/bench_$mode.json 2> $OUT/bench_$mode.err || { echo "trace $mode failed"; tail -5 $OUT/bench_$mode.err; }
   cp $(find $OUT/trace_$mode -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_$mode.csv
   [ $mode = default ] && python3 $REPO/tools/overlap_timeline.py $(find $OUT/trace_$mode -name "*kernel_trace.csv" | head -1) > $OUT/overlap_timeline.txt
+  [ $mode = default ] && python3 $REPO/tools/step_gaps.py $(find $OUT/trace_$mode -name "*kernel_trace.csv" | head -1) > $OUT/step_chain.txt
   find $OUT/trace_$mode -name "*_kernel_trace.csv" -delete
 done
 echo "== pmc FETCH_SIZE / WRITE_SIZE (LBS kernel of the default schedule)"

@@ -5,6 +5,7 @@ OUT=$REPO/gpurun_out/profiles_r3
 mkdir -p $OUT
 cd $REPO
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver_style.json 2> $OUT/bench_driver_style.err
+python3 bench.py > $OUT/bench_default_untraced.json 2> $OUT/bench_default_untraced.err   # the default line (200 steps) without the profiler
 bash tools/r2_trace.sh profiles_r3/trace_timeline > /dev/null 2>&1
 python3 tools/overlap_timeline.py $(find $OUT/trace_timeline/trace -name "*kernel_trace.csv" | head -1) > $OUT/overlap_timeline.txt 2>&1
 rm -rf $OUT/trace_timeline/trace
