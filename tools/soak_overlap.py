@@ -1,4 +1,4 @@
-"""Soak (GPU box): 400 steps of the full 10k mixed crowd on the cheese scene with SGE_OPT_OVERLAP_SKIN off and on: the state, every
+"""Soak (GPU box): N steps (argv[1], default 400) of the full 10k mixed crowd on the cheese scene with SGE_OPT_OVERLAP_SKIN off and on: the state, every
 palette and sampled skinned output must agree bit for bit (the two-palette-buffer schedule changes no result)."""
 import importlib, os, sys
 import numpy as np
@@ -20,11 +20,12 @@ def run(overlap, steps=400):
     sk = [eng.skinned(i * eng.vertex_count, 512) for i in range(0, 10000, 53)]
     eng.close()
     return d, pal, sk
-a = run(0); b = run(1)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+a = run(0, N); b = run(1, N)
 for k in a[0]:
     assert np.array_equal(a[0][k].view(np.uint8), b[0][k].view(np.uint8)), k
 assert np.array_equal(a[1], b[1])
 for x, y in zip(a[2], b[2]):
     for u, v in zip(x, y):
         assert np.array_equal(u, v)
-print("overlap on/off agree bit for bit: state, all palettes, sampled skinned output")
+print("overlap on/off agree bit for bit after %d steps: state, all palettes, sampled skinned output" % N)
