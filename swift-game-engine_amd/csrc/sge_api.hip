@@ -1316,6 +1316,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
                            (st & SGE_STAGE_POSE) && (st & SGE_STAGE_SKIN) && c->boneCount > 0 && c->prof.count > 0 &&
                            c->mesh.vertexCount > 0;
     const int poseSlot = c->poseSlot ^ 1;
+    bool movedOnTwoStreams = false;
     if (st & (SGE_STAGE_INTENT | SGE_STAGE_GRAVITY | SGE_STAGE_MOVE)) {
         if ((st & SGE_STAGE_MOVE) && c->col.root < 0 && c->col.triCount != 0) { set_error("collision world not built"); return SGE_ERR_STATE; }
         if ((st & SGE_STAGE_AGENTS) && (st & SGE_STAGE_MOVE)) {
@@ -1361,7 +1362,12 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
                 c->listsFirst = first; c->listsCount = count; c->listsThreshold = c->heavyThreshold; c->listsCap = capNow;
             }
         }
-        if (pipedPose) SGE_HIP(hipEventRecord(c->evMoveDone, c->stream));
+        // what the pose stream waits for: with the two-stream move stage its two "done" events (no packet of its own on the main
+        // stream, whose next kernel is the next tick's part 0), otherwise a marker behind the stage
+        if (pipedPose) {
+            movedOnTwoStreams = (st & SGE_STAGE_MOVE) && c->heavyThreshold >= 0;
+            if (!movedOnTwoStreams) SGE_HIP(hipEventRecord(c->evMoveDone, c->stream));
+        }
     }
     if (st & SGE_STAGE_SEPARATION) { // AgentSeparationSystem: after the move stage, before the animation stages (DemoScene.swift:66-71)
         if (first != 0 || count != c->crowd.count) { set_error("SGE_STAGE_SEPARATION works on the whole crowd (first = 0, count = all)"); return SGE_ERR_INVALID; }
@@ -1396,7 +1402,12 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         PoseLaunch L{c->crowd, c->sk, c->prof, d->dt, st, first, count,
                      c->waveProfOn && c->dWaveProf.p ? c->dWaveProf.as<unsigned long long>() + (size_t)c->crowd.count * 2 * 8 : nullptr};
         if (pipedPose) {
-            SGE_HIP(hipStreamWaitEvent(ps, c->evMoveDone, 0));
+            if (movedOnTwoStreams) {
+                SGE_HIP(hipStreamWaitEvent(ps, c->evClassified, 0)); // part 0 + the multi-wave launch (main stream)
+                SGE_HIP(hipStreamWaitEvent(ps, c->evHeavyDone, 0));  // the grouped launch (second stream)
+            } else {
+                SGE_HIP(hipStreamWaitEvent(ps, c->evMoveDone, 0));
+            }
             L.crowd.poseIn = c->dPoseIn[poseSlot].as<PoseInput>();
         }
         if (L.waveProf) SGE_HIP(hipMemsetAsync(L.waveProf, 0, (size_t)c->crowd.count * 64, ps));

@@ -3233,7 +3233,6 @@ bool launch_move(const MoveLaunch& L, hipStream_t s) {
     // 0.946 ms per step: the launch is short either way and a wavefront's four overlap queries in a row are not)
     hipLaunchKernelGGL((move_kernel<0, false>), dim3(L.count), dim3(kWave), 0, s, L);
     if (!move) return false;
-    if (listsFromLastStep) (void)hipStreamWaitEvent(s, L.evListsReady, 0); // part 0 reads none of the lists: the wait goes behind it
     MoveLaunch G = L;
     // The multi-wave launch goes FIRST and stays on the main stream, right behind part 0: its 512-thread workgroups need
     // two free wavefront places on every SIMD of one CU at the same moment, which they find while the chip holds nothing but the
@@ -3241,15 +3240,23 @@ bool launch_move(const MoveLaunch& L, hipStream_t s) {
     // grouped launch have taken every place that comes free (beside resident LBS workgroups the move stage took 0.94 ms instead of
     // 0.52 for exactly this reason). So the grouped launch runs on the second stream,
     // behind an event: the cross-stream hand-over is what gives the multi-wave workgroups their head start.
+    // Queue packets between two dependent launches cost ~5 us each (tools/step_gaps.py), so nothing sits on the way from part 0 to
+    // the grouped launch but that one event, and nothing between the end of the grouped launch and the main stream's next kernel but
+    // the wait for it: the wait for the lists (part 0 reads none of them; the order list is the second stream's own earlier work)
+    // stands in front of the multi-wave launch only, and "the multi-wave launch is done" is recorded right behind that launch.
     hipStream_t gs = heavy ? L.heavyStream : s;
     if (heavy) {
         (void)hipEventRecord(L.evClassified, s);
+        (void)hipStreamWaitEvent(gs, L.evClassified, 0);
+        if (listsFromLastStep) (void)hipStreamWaitEvent(s, L.evListsReady, 0);
         MoveLaunch H = L;
         H.list = L.lists + L.count; H.listCount = L.listCounts + 1;
         const int heavyGrid = L.count < L.heavyCap ? L.count : L.heavyCap;
         if (agents) hipLaunchKernelGGL((move_kernel<1, true, true>), dim3(heavyGrid), dim3(kWave * kHeavyWaves), 0, s, H);
         else hipLaunchKernelGGL((move_kernel<1, false, true>), dim3(heavyGrid), dim3(kWave * kHeavyWaves), 0, s, H);
-        (void)hipStreamWaitEvent(gs, L.evClassified, 0);
+        (void)hipEventRecord(L.evClassified, s); // from here on: "part 0 and the multi-wave launch are done" (sge_tick orders the pose stream behind it)
+    } else if (listsFromLastStep) {
+        (void)hipStreamWaitEvent(s, L.evListsReady, 0);
     }
     if (grouped) {
         G.order = L.lists; G.orderCount = L.listCounts; G.solo = solo;
@@ -3258,17 +3265,14 @@ bool launch_move(const MoveLaunch& L, hipStream_t s) {
         else hipLaunchKernelGGL((move_group_kernel<false>), dim3(groups), dim3(kWave), ldsPad, gs, G);
     } else if (agents) hipLaunchKernelGGL((move_kernel<1, true>), dim3(L.count), dim3(kWave), 0, gs, L); // skips flagged characters
     else hipLaunchKernelGGL((move_kernel<1, false>), dim3(L.count), dim3(kWave), ldsPad, gs, L);
-    if (heavy) {
-        (void)hipEventRecord(L.evHeavyDone, gs);
-        (void)hipStreamWaitEvent(s, L.evHeavyDone, 0);
-    }
+    if (heavy) (void)hipEventRecord(L.evHeavyDone, gs); // the second stream's launch is done
     if (pipelined) { // the NEXT step's lists, behind both launches of this one, beside whatever the main stream does next
-        (void)hipEventRecord(L.evClassified, s);
         (void)hipStreamWaitEvent(gs, L.evClassified, 0);
         buildLists(gs, L.nextHeavyCap);
         (void)hipEventRecord(L.evListsReady, gs);
         copyDemand(gs);
     }
+    if (heavy) (void)hipStreamWaitEvent(s, L.evHeavyDone, 0);
     return pipelined;
 }
 
