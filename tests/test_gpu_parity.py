@@ -901,7 +901,7 @@ def test_overlap_mode_parity(sge):
 
 
 def test_resident_lbs_form_writes_the_same_streams(sge, monkeypatch):
-    """Overlap mode skins large crowds (>= 16,384 characters with a move stage) with resident workgroups that draw their work units
+    """Overlap mode skins large crowds (from 6,000 characters on) with resident workgroups that draw their work units
     from a ticket counter; SGE_SKIN_PERSISTENT (read when a context is created) forces the form on (q/4 workgroups per CU) or off (0).
     Same arithmetic either way, so the three output streams must be bit-identical: a small crowd whose characters are split over
     several work units and a larger one with the form forced, then the automatic choice at 16,500 characters against the form
