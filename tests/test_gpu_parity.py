@@ -1172,6 +1172,71 @@ def test_pose_beside_the_next_move_stage(sge, monkeypatch):
                 assert np.array_equal(x, y), s
 
 
+def test_schedule_transitions_leave_no_launch_behind(sge):
+    """The three-stream schedule across everything that changes it in mid-run, with no host synchronisation of the caller's own in
+    between: the overlap option switched off and on, the context moved to a caller's stream and back, the crowd resized (smaller,
+    then larger again) and re-uploaded while launches of the old crowd are in flight. A context in serial order fed the same calls
+    must end with the same states and the same skinned streams, bit for bit."""
+    import torch
+
+    A = sge.abi
+    ybot = sge.assets.YBotAssets()
+    n = 2000
+
+    def run(scheduled):
+        eng = sge.CharacterEngine(0)
+        lib, h = eng.t.lib, eng.h
+        sge.crowd.upload_character_assets(eng, ybot, rings=8, segments=8)
+        scene = sge.crowd.upload_asset_scene(eng, ("cheese",), footprint=100.0)
+        sge.crowd.spawn_crowd(eng, ybot, n, scene, seed=5, mixed=True)
+        state0 = eng.download()
+        caller = torch.cuda.Stream(device=0)
+        if scheduled:
+            eng.set_option(A.OPT_OVERLAP_SKIN, 1)
+        for _ in range(12):
+            eng.tick()
+        if scheduled:
+            eng.set_option(A.OPT_OVERLAP_SKIN, 0)                    # pending pose / skin launches are joined inside
+        for _ in range(3):
+            eng.tick()
+        if scheduled:
+            eng.set_option(A.OPT_OVERLAP_SKIN, 1)
+            assert lib.sge_context_set_stream(h, C.c_void_p(caller.cuda_stream)) == 0
+        for _ in range(5):
+            eng.tick()
+        if scheduled:
+            assert lib.sge_context_set_stream(h, None) == 0          # back to the context's own stream
+        for _ in range(4):
+            eng.tick()
+        mid = eng.download()
+        eng.resize(n // 4)                                           # launches of the 2,000-character crowd may still be in flight
+        eng.upload(**{k: v[: n // 4] for k, v in state0.items()})
+        for _ in range(6):
+            eng.tick()
+        small = eng.download()
+        small_skin = [a.copy() for a in eng.skinned()]
+        eng.resize(n)
+        eng.upload(**state0)
+        for _ in range(6):
+            eng.tick()
+        out = eng.download()
+        V = eng.vertex_count
+        skin = [a.copy() for a in eng.skinned(first_vertex=(n - 2) * V, vertex_count=2 * V)]
+        pal = eng.palettes()[0].copy()
+        assert eng.move_stats().overflow == 0
+        eng.close()
+        return mid, small, small_skin, out, skin, pal
+
+    a, b = run(True), run(False)
+    for k in ("bodies", "controllers", "locomotion", "actions"):
+        assert_struct_equal(a[0][k], b[0][k], "%s before the resize" % k)
+        assert_struct_equal(a[1][k], b[1][k], "%s of the smaller crowd" % k)
+        assert_struct_equal(a[3][k], b[3][k], "%s at the end" % k)
+    for x, y in zip(a[2] + a[4], b[2] + b[4]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a[5], b[5])
+
+
 def test_overlap_on_a_caller_stream_with_a_consumer(sge):
     """SGE_OPT_OVERLAP_SKIN behind the reference's calling convention: RTSkinningEncoder.encode enqueues on the CALLER's command
     buffer and the consumer enqueued right behind it sees the skinned vertices (RTSkinningEncoder.swift:27-56,
