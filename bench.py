@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: characters/sec through the per-frame character update on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N = 1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+    python bench.py --gpus N --steps K --warmup W            (any N: without a launcher's WORLD_SIZE in the environment this
+                                                              process starts the N ranks itself, before touching the GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the driver's form for N > 1)
 
 A "step" is one fixed step (dt = 1/60) of the whole hot path over one batch of synthetic
 characters already resident in HBM: intent -> gravity -> capsule-CCD move-and-slide ->
@@ -26,6 +27,7 @@ import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,6 +36,33 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 SETTLE_STEPS = 120     # scene preparation: let the spawned crowd land and reach its walk/run speed
+
+
+def _self_launch(gpus):
+    """`python bench.py --gpus N` with N > 1 and no launcher: this process — which has not imported torch and never touches the GPU
+    — starts N fresh rank processes of this same script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's one JSON
+    line, forwards every rank's stderr, and returns the worst child's exit code. A rank that fails ends the others' wait through
+    the process-group timeout; nothing is re-executed in this process."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SGE_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = [l for l in (out0 or "").splitlines() if l.startswith("{")]
+    worst = max((abs(c) for c in codes), default=0)
+    if line and worst == 0:
+        print(line[-1])
+    else:
+        sys.stderr.write("bench.py: rank exit codes %s\n%s" % (codes, out0 or ""))
+    return worst or (0 if line else 1)
 
 
 def main():
@@ -63,6 +92,14 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only to rehearse N>1 on one GPU")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-sync", choices=["resident", "world"], default="resident",
+                    help="resident (default, the headline): state stays in HBM for the whole timed region. world: the TIMED loop is the drop-in loop of "
+                         "GPUCharacterStepSystem.fixedUpdate — pinned push of every character's intent, tick, asynchronous pull of bodies + controllers + "
+                         "locomotion + actions, wait for it, copy into host arrays — every step (metric name says so; not the headline)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the legs outside the timed region that the default N=1 line carries: `world_sync` (the drop-in loop beside the resident "
+                         "figure) and `real_mesh` (the same workload on the FBX-derived 35,440-vertex Y-Bot)")
+    ap.add_argument("--dump-lbs-events", default=None, help="write the HIP-event duration of every skin launch of the timed region to this file")
     ap.add_argument("--cpu-sample-chars", type=int, default=2048)
     ap.add_argument("--cpu-sample-steps", type=int, default=16)
     args = ap.parse_args()
@@ -73,6 +110,9 @@ def main():
     args.mesh = args.mesh or "synthetic"
     args.scene = args.scene or ("merged" if args.workload == "mixed" else "cheese")
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_self_launch(args.gpus))  # (before torch is imported: the parent never initialises the GPU)
+
     import numpy as np
     import torch
 
@@ -80,7 +120,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     if args.single_device:
@@ -122,9 +162,13 @@ def main():
     if args.workload == "agents":
         exchange = sge.parallel.AgentExchange(eng, n_total, rank, world, torch.device("cuda", local_rank), dist)
 
+    world_loop = _WorldLoop(sge, eng, "immediate") if args.host_sync == "world" else None
+
     def step():
         if exchange is not None:
             exchange.step(stages=stages)
+        elif world_loop is not None:
+            world_loop.step(stages)
         else:
             eng.tick(stages=stages)
 
@@ -156,6 +200,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if args.dump_lbs_events:
+        ev = eng.skin_launch_times()
+        with open(args.dump_lbs_events, "w") as f:
+            f.write("# HIP-event duration (ms) of every skin launch of the timed region, in launch order: `python bench.py %s`\n" % " ".join(sys.argv[1:]))
+            f.write("# launches %d  mean %.6f  min %.6f  max %.6f\n" % (len(ev), float(ev.mean()) if len(ev) else 0.0, float(ev.min()) if len(ev) else 0.0, float(ev.max()) if len(ev) else 0.0))
+            f.writelines("%.6f\n" % x for x in ev)
     prof = eng.profile_read(reset=True)
     stats = eng.move_stats(reset=True)
     import ctypes as _C
@@ -197,7 +247,8 @@ def main():
     traffic = _recorded_traffic(count, V, "skin_ticket_multi_kernel" if (_q.value > 0 and _cpw.value > 1) else "skin_ticket_kernel" if _q.value > 0 else "skin_kernel<")
     value = n_total * args.steps / elapsed
     out = {
-        "metric": "characters/sec (skin+CCD)" if mode == "ccd" else "characters/sec (pose+skin, no CCD)",
+        "metric": ("characters/sec (skin+CCD)" if mode == "ccd" else "characters/sec (pose+skin, no CCD)") + (
+            " with the World synchronised every step (pinned push of intents, pull of bodies + controllers + locomotion + actions)" if world_loop is not None else ""),
         "value": value,
         "unit": "characters/s",
         "n_gpus": world,
@@ -263,13 +314,164 @@ def main():
                         "frac": (refit_bytes / (refit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if refit_ms > 0 else 0.0,
                         "triangles_per_character": int(info.triangleCount), "clusters": int(info.clusterCount),
                         "entries": int(info.entryCount), "wide_nodes": int(info.wideCount)}
+    # what a SCALE record needs to be checked: the process group's size and backend, and every rank's output-stream placement
+    place = eng.placement()
+    ranks = [{"rank": rank, "device": local_rank, "placement_ms": round(place[0], 4), "placements_timed": place[1], "ms_per_step": elapsed / args.steps * 1e3}]
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, ranks[0])
+        ranks = gathered
+    out["ranks"] = {"world_size": dist.get_world_size() if dist is not None else 1, "backend": (dist.get_backend() if dist is not None else None),
+                    "self_launched": bool(os.environ.get("SGE_BENCH_SELF_LAUNCHED")), "per_rank": ranks}
+    if exchange is not None:
+        out["ranks"]["agent_exchange"] = exchange.describe()
+    extras = rank == 0 and world == 1 and not args.no_extras and world_loop is None and exchange is None and not args.refit
+    if extras:
+        out["world_sync"] = _world_sync_leg(sge, eng, stages, count, elapsed / args.steps * 1e3)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = _cpu_baseline(sge, eng, ybot, terrain, stages & ~abi.STAGE_BLAS_REFIT, args, mode)  # the oracle has no refit
+    eng.close()
+    if extras and mode == "ccd" and args.mesh == "synthetic" and args.workload == "ccd":
+        out["real_mesh"] = _real_mesh_leg(sge, args, local_rank, ybot)
     if rank == 0:
         print(json.dumps(out))
-    eng.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+class _WorldLoop:
+    """The drop-in loop: what host/swift/GPUCrowd.swift (C++ twin: host/sge_host.hpp GPUCrowd) does around sge_tick every fixed step when the
+    engine's World keeps its component stores (Systems.swift:1802-1821 writeBack, World.swift:64-75): push every character's
+    MoveIntent, tick, pull bodies + controllers + locomotion + actions and copy them into the host's arrays.
+      immediate  pinned push, tick(n), asynchronous pull(n), wait for pull(n): the World holds step n when fixedUpdate returns
+      lagged     the same, but the pull waited for is the previous step's: tick(n + 1) is enqueued before pull(n) is read
+      pageable   sge_characters_upload / _download (pageable memory, host synchronisation of the whole context): round 3's binding"""
+
+    def __init__(self, sge, eng, mode):
+        import numpy as np
+        self.np, self.eng, self.abi, self.mode = np, eng, sge.abi, mode
+        self.intents = eng.download(what=("intents",))["intents"]
+        A = sge.abi
+        self.world = {"bodies": np.zeros(eng.count, A.body_dtype), "controllers": np.zeros(eng.count, A.controller_dtype),
+                      "locomotion": np.zeros(eng.count, A.locomotion_dtype), "actions": np.zeros(eng.count, A.action_dtype)}
+        self.prev = None
+        self.host_s = {"push": 0.0, "tick": 0.0, "pull": 0.0, "wait": 0.0, "store": 0.0}  # where the HOST spends the step
+
+    def _store(self, view):
+        t0 = time.perf_counter()
+        for k, v in view.items():
+            self.np.copyto(self.world[k], v)  # the decode into the World's stores: one memcpy per array here
+        self.host_s["store"] += time.perf_counter() - t0
+
+    def _wait(self, ticket):
+        t0 = time.perf_counter()
+        view = self.eng.state_wait(ticket)
+        self.host_s["wait"] += time.perf_counter() - t0
+        self._store(view)
+
+    def step(self, stages):
+        eng, A, H = self.eng, self.abi, self.host_s
+        t0 = time.perf_counter()
+        if self.mode == "pageable":
+            eng.upload(intents=self.intents)
+            t1 = time.perf_counter()
+            eng.tick(stages=stages)
+            t2 = time.perf_counter()
+            d = eng.download(what=("bodies", "controllers", "locomotion", "actions"))
+            t3 = time.perf_counter()
+            H["push"] += t1 - t0; H["tick"] += t2 - t1; H["wait"] += t3 - t2
+            self._store(d)
+            return
+        stg = eng.state_push_begin(A.STATE_INTENTS)
+        self.np.copyto(stg["intents"], self.intents)
+        eng.state_push_commit()
+        t1 = time.perf_counter()
+        eng.tick(stages=stages)
+        t2 = time.perf_counter()
+        t = eng.state_pull_async(A.STATE_WORLD)
+        t3 = time.perf_counter()
+        H["push"] += t1 - t0; H["tick"] += t2 - t1; H["pull"] += t3 - t2
+        if self.mode == "immediate":
+            self._wait(t)
+        else:
+            if self.prev is not None:
+                self._wait(self.prev)
+            self.prev = t
+
+    def finish(self):
+        if self.prev is not None:
+            self._wait(self.prev)
+            self.prev = None
+
+
+def _world_sync_leg(sge, eng, stages, count, resident_ms, steps=100):
+    """Outside the timed region: the same crowd stepped through the drop-in loop, three ways (see _WorldLoop)."""
+    res = {"steps": steps, "bytes_per_character": {"push": 32, "pull": 352}, "resident_ms_per_step": resident_ms,
+           "what": "push of every character's sge_move_intent + pull of bodies, controllers, locomotion and actions EVERY fixed step "
+                   "(KinematicMoveStopSystem.writeBack / World.store traffic, Systems.swift:1802-1821, World.swift:64-75), copied into host arrays"}
+    for mode in ("immediate", "lagged", "pageable"):
+        loop = _WorldLoop(sge, eng, mode)
+        for _ in range(10):
+            loop.step(stages)
+        loop.finish()
+        eng.synchronize()
+        for k in loop.host_s:
+            loop.host_s[k] = 0.0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loop.step(stages)
+        loop.finish()
+        eng.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        res[mode] = {"ms_per_step": ms, "characters_per_s": count / (ms * 1e-3), "frac_of_resident": resident_ms / ms,
+                     "host_us_per_step": {k: round(v / steps * 1e6, 1) for k, v in loop.host_s.items()}}
+    # the resident loop's host cost, for comparison: enqueueing one tick
+    eng.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.tick(stages=stages)
+    t1 = time.perf_counter()
+    eng.synchronize()
+    res["resident_host_enqueue_us_per_step"] = round((t1 - t0) / steps * 1e6, 1)
+    res["note"] = ("immediate = pinned + event-ordered, the World holds step n when fixedUpdate returns (the host waits for move(n) + pose(n) + a 3.5 MB copy, "
+                   "not for skin(n)); lagged = the World one step behind, nothing waited for; pageable = sge_characters_upload/_download (round 3)")
+    return res
+
+
+def _real_mesh_leg(sge, args, device, ybot, steps=20, warmup=20):
+    """The default workload on the FBX-derived Y-Bot (35,440 welded vertices, real weights and bone indices) instead of the synthetic
+    14,080-vertex mesh: a second context, the same scene, crowd, schedule and roofline arithmetic; outside the headline's timed region."""
+    abi = sge.abi
+    eng = sge.CharacterEngine(device)
+    eng.set_option(abi.OPT_OVERLAP_SKIN, 1 if args.overlap else 0)
+    ns = argparse.Namespace(**dict(vars(args), mesh="ybot"))
+    terrain = _build_world(sge, eng, ybot, ns)
+    n = args.chars
+    eng.resize(n)
+    _spawn_block(sge, eng, ybot, n, 0, n, terrain, "ccd", agents=False, mixed=False)
+    for _ in range(SETTLE_STEPS + warmup):
+        eng.tick()
+    eng.synchronize()
+    eng.set_option(abi.OPT_PROFILE, 1)
+    eng.profile_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.tick()
+    eng.synchronize()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read(reset=True)
+    V, B = eng.vertex_count, eng.bone_count
+    lbs_bytes = n * (40.0 * V + B * 64.0) + 64.0 * V
+    lbs_ms = prof.skin_ms / max(prof.skin_launches, 1)
+    place = eng.placement()
+    overflow = int(eng.move_stats().overflow)
+    eng.close()
+    return {"mesh": "FBX-derived Y-Bot (tests/golden/ybot_skinned.npz)", "vertices_per_character": V, "characters": n, "steps": steps, "warmup": warmup,
+            "value": n * steps / dt, "unit": "characters/s", "ms_per_step": dt / steps * 1e3,
+            "roofline": {"bound": "hbm", "bytes_per_launch": lbs_bytes, "ms_per_launch": lbs_ms, "achieved": lbs_bytes / (lbs_ms * 1e-3) / 1e9 if lbs_ms > 0 else 0.0,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (lbs_bytes / (lbs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if lbs_ms > 0 else 0.0},
+            "whole_path_hbm_frac": (n * steps / dt) * (40.0 * V + 64.0 * V / n + 2 * B * 64.0 + 640.0) / (HBM_PEAK_GBS * 1e9),
+            "placement_ms": round(place[0], 4), "overflow": overflow}
 
 
 def _build_world(sge, e, ybot, args):

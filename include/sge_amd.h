@@ -38,7 +38,10 @@
 extern "C" {
 #endif
 
-#define SGE_ABI_VERSION 1
+/* 2: SGE_OPT_OVERLAP_SKIN takes effect on a caller-provided stream only with the value 2 (1 keeps version 1's contract there: the
+ *    option is ignored and work enqueued behind sge_tick sees the skinned streams); sge_skin_wait / sge_skin_consumed /
+ *    sge_crowd_palette_buffers, SGE_STAGE_SIDE_CONTACT_CACHE; the asynchronous World write-back (sge_state_*). */
+#define SGE_ABI_VERSION 2
 
 typedef struct sge_context sge_context;
 
@@ -47,7 +50,8 @@ enum {
     SGE_ERR_INVALID = 1,   /* bad argument / shape mismatch */
     SGE_ERR_DEVICE = 2,    /* HIP error (message via sge_last_error) */
     SGE_ERR_STATE = 3,     /* required upload missing */
-    SGE_ERR_CAPACITY = 4   /* a fixed device-side capacity was exceeded */
+    SGE_ERR_CAPACITY = 4,  /* a fixed device-side capacity was exceeded */
+    SGE_ERR_NOT_READY = 5  /* sge_state_poll: the pull has not landed yet (not an error) */
 };
 
 #define SGE_MAX_BONES 256
@@ -242,12 +246,17 @@ enum {
                                    * kernel (the boxes are reduced from the positions while they are still on chip), except
                                    * under SGE_OPT_OVERLAP_SKIN, where the fused kernel would keep the next step's collision
                                    * kernels off the chip; 2: always; 0: two launches, the refit reads the positions back */
-    SGE_OPT_OVERLAP_SKIN = 4      /* 1: the skin stage of sge_tick runs on the context's second stream, so that skin(n) overlaps
-                                   * move(n+1) + pose(n+1) (the benchmarked schedule). Holds on a caller-provided stream as well
-                                   * (sge_context_set_stream): the skin launch is ordered behind the pose stage on that stream by
-                                   * events. What is enqueued on the caller's stream behind sge_tick is then NOT ordered behind
-                                   * the skin launch by itself: a consumer of the skinned streams calls sge_skin_wait first
-                                   * (sge_blas_refit*, sge_skinning_encode, the downloads and sge_synchronize join by themselves).
+    SGE_OPT_OVERLAP_SKIN = 4      /* 1 or 2: the skin stage of sge_tick runs on the context's second stream, so that skin(n) overlaps
+                                   * move(n+1) + pose(n+1) (the benchmarked schedule). On the context's own stream 1 and 2 mean the
+                                   * same. On a caller-provided stream (sge_context_set_stream) the value 1 is IGNORED, as in ABI
+                                   * version 1: stages run back to back on the caller's stream, whatever the caller enqueues behind
+                                   * sge_tick sees the skinned streams, and the palette pointer of sge_crowd_buffers does not move.
+                                   * The value 2 is the explicit opt-in there: the skin launch is ordered behind the pose stage on
+                                   * the caller's stream by events, and what is enqueued on the caller's stream behind sge_tick is
+                                   * then NOT ordered behind the skin launch by itself: a consumer of the skinned streams calls
+                                   * sge_skin_wait first and sge_skin_consumed after its last read, and queries the palette pointer
+                                   * again after every tick (sge_blas_refit*, sge_skinning_encode, the downloads and
+                                   * sge_synchronize join by themselves).
                                    * A whole-crowd tick with move + pose + skin stages also runs its POSE launch on a stream of
                                    * the context's own, beside the next tick's move stage: palettes, locomotion / action states and
                                    * transformRotation of tick n are complete where its skin launch is — sge_skin_wait orders a
@@ -376,7 +385,8 @@ int sge_crowd_palette_buffers(sge_context* ctx, void** d_palettes, int32_t* late
 int sge_skin_wait(sge_context* ctx, void* consumer_stream);
 /* The reverse ordering, for a consumer that reads the skinned streams asynchronously on a stream of its own: everything
  * `consumer_stream` holds so far completes before the context's NEXT skin / refit launch overwrites the streams (an event on the
- * consumer's stream that the context's streams wait for). Not needed when the consumer runs on the context's stream in serial order,
+ * consumer's stream that the context's main, skin and pose streams wait for: the pose launch two ticks on rewrites the palette
+ * buffer the consumer's jobs may name). Not needed when the consumer runs on the context's stream in serial order,
  * or synchronises with the host before the next sge_tick. One command buffer per frame gives the reference both orderings
  * (Renderer.swift:159, 224). */
 int sge_skin_consumed(sge_context* ctx, void* consumer_stream);
@@ -544,6 +554,51 @@ int sge_palettes_download(sge_context* ctx, int32_t first, int32_t count,
 int sge_skinned_download(sge_context* ctx, int64_t first_vertex, int64_t vertex_count,
                          float* positions, float* normals, float* tangents);
 
+/* ---- Asynchronous World synchronisation ------------------------------------------------------------------------------------
+ * The reference's systems read and write their components in process memory: KinematicMoveStopSystem.writeBack
+ * (Systems.swift:1802-1821), the locomotion / action clocks (:279-407, :475-517) and PhysicsWritebackSystem (:2249-2267) store into
+ * `world.store(T.self)[e]` (World.swift:64-75) every fixed step, and PhysicsIntentSystem reads MoveIntentComponent from there
+ * (:205-250). A host that keeps its World has to see every step's results and feed every step's intents; sge_characters_download /
+ * _upload do that with pageable memory and a host synchronisation of the whole context. The calls below are the pinned,
+ * event-ordered form: nothing here waits for the skin launch of the step, and the next tick may be enqueued while a pull is in
+ * flight (the arrays are first copied on the device, behind the kernels that wrote them and in front of the next step's, then
+ * moved to pinned host memory on a stream of their own). */
+enum {
+    SGE_STATE_BODIES = 1u << 0,      /* sge_body_state */
+    SGE_STATE_CONTROLLERS = 1u << 1, /* sge_controller_state */
+    SGE_STATE_LOCOMOTION = 1u << 2,  /* sge_locomotion_state */
+    SGE_STATE_ACTIONS = 1u << 3,     /* sge_action_state */
+    SGE_STATE_INTENTS = 1u << 4,     /* sge_move_intent (push only: nothing on the device writes it) */
+    SGE_STATE_WORLD = 0xFu           /* what GPUCrowd.pullBack decodes into the World */
+};
+/* Host pointers into context-owned pinned memory, [count] each, NULL for arrays that were not asked for. */
+typedef struct sge_state_view {
+    int32_t first, count;
+    uint32_t which;
+    int32_t ticket;
+    sge_body_state* bodies;
+    sge_controller_state* controllers;
+    sge_locomotion_state* locomotion;
+    sge_action_state* actions;
+    sge_move_intent* intents;
+} sge_state_view;
+/* Snapshot of the selected arrays of characters [first, first + count) (count 0 = all) as they stand behind everything enqueued so
+ * far — call it right after sge_tick(n) for "the World after step n": bodies (less transformRotation) and controllers as the move /
+ * separation stage left them, locomotion / action states and transformRotation as the pose stage left them, wherever those stages ran.
+ * Returns at once; *ticket names the pull. Two pulls may be in flight; the third reuses the first one's memory (and waits for it). */
+int sge_state_pull_async(sge_context* ctx, uint32_t which, int32_t first, int32_t count, int32_t* ticket);
+/* Blocks the host until pull `ticket` has landed (its copy only: not the skin launch, not later ticks) and fills `view`. The
+ * pointers stay valid until the pull after next is enqueued. SGE_ERR_STATE for a ticket that has been overwritten. */
+int sge_state_wait(sge_context* ctx, int32_t ticket, sge_state_view* view);
+/* SGE_OK when pull `ticket` has landed, SGE_ERR_NOT_READY while it is in flight. */
+int sge_state_poll(sge_context* ctx, int32_t ticket);
+/* The other direction: pinned staging for what the host's systems wrote since the last step (intents every step; bodies /
+ * controllers / locomotion / actions of teleported or edited characters). begin() hands out host arrays [count] for characters
+ * [first, first + count) of the arrays in `which`; the caller fills them; commit() enqueues the copies on the context's stream in
+ * front of the next tick and returns at once. One begin / commit pair at a time; two stagings alternate. */
+int sge_state_push_begin(sge_context* ctx, uint32_t which, int32_t first, int32_t count, sge_state_view* staging);
+int sge_state_push_commit(sge_context* ctx);
+
 enum {
     SGE_STAGE_INTENT = 1u << 0,     /* PhysicsIntentSystem, Systems.swift:205-250 */
     SGE_STAGE_GRAVITY = 1u << 1,    /* GravitySystem, Systems.swift:596-620 */
@@ -638,6 +693,12 @@ int sge_debug_separation(sge_context* ctx, int32_t* out);
    workgroup per character, coming and going) and characters per work unit. bench.py names the kernel it prices from this. */
 int sge_debug_skin_form(sge_context* ctx, int32_t* quarters, int32_t* chars_per_unit);
 int sge_move_stats_read(sge_context* ctx, sge_move_stats* out, int reset);
+/* Diagnostics (SGE_OPT_PROFILE): the HIP-event duration in ms of every skin launch since the last reset of sge_profile_read, oldest
+   first. *count = how many there are; min(*count, cap) are written (at most 65,536 are kept). */
+int sge_debug_skin_launch_times(sge_context* ctx, float* out_ms, int32_t cap, int32_t* count);
+/* Diagnostics: the placement search of the skinned output streams at the last (re)allocation (SGE_OPT_PLACEMENT_PROBES): time of one
+   three-stream store pass over the kept placement in ms (0: not probed) and how many placements were timed. */
+int sge_debug_placement(sge_context* ctx, float* kept_ms, int32_t* tried);
 /* Per-character share of CollisionQueryStats.capsuleSweepIterations (CollisionQuery.swift:280-318) for the LAST fixed step:
    distance evaluations each of characters [first, first + count) spent in its casts (what the scheduler balances on). */
 int sge_move_cost_read(sge_context* ctx, int32_t first, int32_t count, int32_t* evaluations);

@@ -9,7 +9,8 @@ import os
 
 import numpy as np
 
-SGE_OK, SGE_ERR_INVALID, SGE_ERR_DEVICE, SGE_ERR_STATE, SGE_ERR_CAPACITY = 0, 1, 2, 3, 4
+SGE_OK, SGE_ERR_INVALID, SGE_ERR_DEVICE, SGE_ERR_STATE, SGE_ERR_CAPACITY, SGE_ERR_NOT_READY = 0, 1, 2, 3, 4, 5
+SGE_ABI_VERSION = 2
 SGE_MAX_COEFFS = 17
 SGE_MAX_PLATFORMS = 64
 SET_STATIC, SET_DYNAMIC = 0, 1
@@ -42,6 +43,8 @@ STAGE_ALL_FIXED, STAGE_ALL = 0x7F, 0xFF
 # options
 OPT_STORE_POSE_DEBUG, OPT_SKIN_LAYOUT, OPT_PROFILE, OPT_OVERLAP_SKIN, OPT_HEAVY_THRESHOLD, OPT_PLACEMENT_PROBES = 1, 2, 3, 4, 5, 6
 OPT_FUSE_BLAS_REFIT = 7
+# sge_state_* array bits
+STATE_BODIES, STATE_CONTROLLERS, STATE_LOCOMOTION, STATE_ACTIONS, STATE_INTENTS, STATE_WORLD = 1, 2, 4, 8, 16, 15
 BLAS_WIDTH, BLAS_CLUSTER = 64, 64
 LAYOUT_PACKED, LAYOUT_PADDED16 = 0, 1
 
@@ -90,6 +93,11 @@ class LocomotionState(C.Structure):
 class ActionState(C.Structure):
     _fields_ = [("profile", i32), ("time", f32), ("playbackRate", f32), ("weight", f32),
                 ("blendInTime", f32), ("blendOutHalfLife", f32), ("dodgeEnd", f32), ("flags", u32)]
+
+
+class StateView(C.Structure):
+    _fields_ = [("first", i32), ("count", i32), ("which", u32), ("ticket", i32), ("bodies", C.c_void_p),
+                ("controllers", C.c_void_p), ("locomotion", C.c_void_p), ("actions", C.c_void_p), ("intents", C.c_void_p)]
 
 
 class SkeletonDesc(C.Structure):
@@ -285,6 +293,11 @@ PROTOTYPES = {
     "sge_palettes_download": (C.c_int, [VP, i32, i32, VP, VP, VP]),
     "sge_skinned_download": (C.c_int, [VP, i64, i64, VP, VP, VP]),
     "sge_tick": (C.c_int, [VP, P(TickDesc)]),
+    "sge_state_pull_async": (C.c_int, [VP, u32, i32, i32, P(i32)]),
+    "sge_state_wait": (C.c_int, [VP, i32, P(StateView)]),
+    "sge_state_poll": (C.c_int, [VP, i32]),
+    "sge_state_push_begin": (C.c_int, [VP, u32, i32, i32, P(StateView)]),
+    "sge_state_push_commit": (C.c_int, [VP]),
     "sge_agents_export": (C.c_int, [VP, VP]),
     "sge_agents_import": (C.c_int, [VP, VP, i32, i32]),
     "sge_profile_read": (C.c_int, [VP, P(StageTimes), C.c_int]),
@@ -297,6 +310,8 @@ PROTOTYPES = {
     "sge_debug_move_lists": (C.c_int, [VP, VP, VP]),
     "sge_debug_separation": (C.c_int, [VP, VP]),
     "sge_debug_skin_form": (C.c_int, [VP, P(i32), P(i32)]),
+    "sge_debug_skin_launch_times": (C.c_int, [VP, VP, i32, P(i32)]),
+    "sge_debug_placement": (C.c_int, [VP, P(f32), P(i32)]),
     "sge_blas_topology": (C.c_int, [VP, i32, VP, i32, P(BlasInfo), VP, VP, VP, VP, VP, VP]),
     "sge_blas_build": (C.c_int, [VP, VP, i32]),
     "sge_blas_info_get": (C.c_int, [VP, P(BlasInfo)]),

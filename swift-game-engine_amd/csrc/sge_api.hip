@@ -40,6 +40,7 @@ struct Events {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double ms = 0;
     long long launches = 0;
+    std::vector<float>* each = nullptr; // when set: every launch's duration as well (bounded by the reader, sge_debug_skin_launch_times)
 };
 
 } // namespace sge
@@ -82,6 +83,8 @@ struct sge_context {
     bool listsValid = false; int listsFirst = 0, listsCount = 0, listsThreshold = 0, listsCap = 0;
     hipEvent_t evListsReady = nullptr;
     bool skinPending[2] = {false, false}, overlapSkin = false, customStream = false;
+    int overlapRequested = 0;    // SGE_OPT_OVERLAP_SKIN as set: 0 off, 1 on the context's own stream only, 2 on a caller's stream as well
+                                 // (overlapSkin = what holds for the stream in use; see applyOverlapOption)
     // options
     bool storePoseDebug = false, profile = false;
     bool waveProfOn = false; // SGE_WAVE_PROF=1: in-kernel cycle stamps of the move and pose kernels (diagnostics, tools/wave_prof.py)
@@ -130,6 +133,20 @@ struct sge_context {
     DevBuf dStats, dWaveProf, dOrderHist, dSepAgents, dSepCounts, dSepFlow;
     int separationIterations = 2; float separationMargin = 0.2f, separationHeightMargin = 0.1f; // AgentSeparationSystem.init :2146-2152
     Events evMove, evPose, evSkin, evAgents, evBlas;
+    std::vector<float> skinLaunchMs; // per-launch durations of the skin stage since the last profile reset (SGE_OPT_PROFILE)
+    // asynchronous World synchronisation (sge_state_*): device-side snapshots behind the kernels that wrote the arrays, moved to pinned
+    // host memory on a stream of their own; pinned staging the other way
+    hipStream_t copyStream = nullptr;
+    struct PullSlot {
+        int ticket = -1, first = 0, count = 0; uint32_t which = 0; bool inFlight = false;
+        size_t off[5] = {0, 0, 0, 0, 0};
+        DevBuf stage; void* host = nullptr; size_t hostBytes = 0;
+        hipEvent_t evMain = nullptr, evPose = nullptr, evLanded = nullptr;
+    } pull[2];
+    int pullTickets = 0;
+    struct PushSlot { void* host = nullptr; size_t hostBytes = 0; hipEvent_t evCopied = nullptr; bool inFlight = false; } push[2];
+    int pushSlot = 0, pushFirst = 0, pushCount = 0; uint32_t pushWhich = 0; bool pushOpen = false;
+    size_t pushOff[5] = {0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -149,6 +166,7 @@ int drainEvents(Events& ev) {
         SGE_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
         ev.ms += ms;
         ev.launches += 1;
+        if (ev.each && ev.each->size() < 65536) ev.each->push_back(ms);
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
     }
@@ -176,6 +194,7 @@ int syncAll(sge_context* c) {
     if (c->skinStream) SGE_HIP(hipStreamSynchronize(c->skinStream));
     if (c->heavyStream) SGE_HIP(hipStreamSynchronize(c->heavyStream));
     if (c->poseStream) SGE_HIP(hipStreamSynchronize(c->poseStream));
+    if (c->copyStream) SGE_HIP(hipStreamSynchronize(c->copyStream));
     c->skinPending[0] = c->skinPending[1] = false;
     c->posePending[0] = c->posePending[1] = false;
     return SGE_OK;
@@ -194,6 +213,11 @@ int joinSkin(sge_context* c) {
         if (c->skinPending[f]) { SGE_HIP(hipStreamWaitEvent(c->stream, c->evSkinDone[f], 0)); c->skinPending[f] = false; }
     return SGE_OK;
 }
+
+// SGE_OPT_OVERLAP_SKIN = 1 keeps the contract of ABI version 1 on a caller-provided stream: there the option is ignored, what the
+// caller enqueues behind sge_tick is ordered behind the skin launch, and the palette pointer does not move. Value 2 is the explicit
+// opt-in for a caller that orders its consumers with sge_skin_wait / sge_skin_consumed. Callers have synchronised (syncAll) before.
+void applyOverlapOption(sge_context* c) { c->overlapSkin = c->overlapRequested >= 2 || (c->overlapRequested == 1 && !c->customStream); }
 
 int refreshInvBind(sge_context* c, const float* meshInvBind, int meshInvBindCount) {
     // Systems.swift:2523: re-bind only when the mesh carries invBindModel of matching count
@@ -499,6 +523,7 @@ sge_context* sge_context_create(int device_index) {
     if (hipSetDevice(device_index) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
     sge_context* c = new sge_context();
     c->device = device_index;
+    c->evSkin.each = &c->skinLaunchMs;
     c->waveProfOn = getenv("SGE_WAVE_PROF") != nullptr;
     if (getenv("SGE_HEAVY_THRESHOLD")) c->heavyThreshold = atoi(getenv("SGE_HEAVY_THRESHOLD")); // experiments
     if (getenv("SGE_HEAVY_CAP")) c->heavyCap = std::max(1, atoi(getenv("SGE_HEAVY_CAP")));
@@ -551,6 +576,12 @@ sge_context* sge_context_create(int device_index) {
         hipEventCreateWithFlags(&c->evClassified, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evHeavyDone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evTablesCopied, hipEventDisableTiming) != hipSuccess) { set_error("stream/event creation failed"); delete c; return nullptr; }
+    for (int k = 0; k < 2; ++k)
+        if (hipEventCreateWithFlags(&c->pull[k].evMain, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->pull[k].evPose, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->pull[k].evLanded, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->push[k].evCopied, hipEventDisableTiming) != hipSuccess) { set_error("event creation failed"); delete c; return nullptr; }
+    if (hipStreamCreateWithPriority(&c->copyStream, hipStreamNonBlocking, prGreatest) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
     if (c->dSkinQueue.alloc(256) != SGE_OK || hipMemsetAsync(c->dSkinQueue.p, 0, 256, c->stream) != hipSuccess) { delete c; return nullptr; } // the resident LBS forms leave their ticket words at zero
     if (hipHostMalloc(reinterpret_cast<void**>(&c->hHeavyDemand), 2 * sizeof(int), hipHostMallocDefault) == hipSuccess) { c->hHeavyDemand[0] = -1; c->hHeavyDemand[1] = -1; }
     else { (void)hipGetLastError(); c->hHeavyDemand = nullptr; }
@@ -573,6 +604,13 @@ void sge_context_destroy(sge_context* c) {
                       &c->dBlasIndices, &c->dBlasBounds, &c->dBlasInstances, &c->dBlasRays, &c->dBlasHits, &c->dBlasTileStart,
                       &c->dBlasRoundLen, &c->dBlasRoundCluster, &c->dBlasRoundIds, &c->dBlasWorldBoxes, &c->dBlasUVs, &c->dBlasQueue, &c->dSkinQueue};
     for (DevBuf* b : bufs) b->release();
+    for (int k = 0; k < 2; ++k) {
+        c->pull[k].stage.release();
+        if (c->pull[k].host) (void)hipHostFree(c->pull[k].host);
+        if (c->push[k].host) (void)hipHostFree(c->push[k].host);
+        for (hipEvent_t e : {c->pull[k].evMain, c->pull[k].evPose, c->pull[k].evLanded, c->push[k].evCopied}) if (e) (void)hipEventDestroy(e);
+    }
+    if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
     if (c->evPoseDone) (void)hipEventDestroy(c->evPoseDone);
     if (c->evMoveDone) (void)hipEventDestroy(c->evMoveDone);
     for (hipEvent_t e : c->evPosePiped) if (e) (void)hipEventDestroy(e);
@@ -599,6 +637,7 @@ int sge_context_set_stream(sge_context* c, void* hip_stream) {
     // (SGE_OPT_OVERLAP_SKIN keeps its meaning on a caller's stream: the skin launch then runs on the context's second stream, ordered
     // behind the pose stage on the caller's stream by events, and a consumer orders itself behind it with sge_skin_wait)
     c->customStream = hip_stream != nullptr;
+    applyOverlapOption(c);
     return SGE_OK;
 }
 
@@ -623,8 +662,14 @@ int sge_context_set_option(sge_context* c, int option, int value) {
         c->skinLayout = value;
         break;
     case SGE_OPT_PROFILE: c->profile = value != 0; break;
-    case SGE_OPT_OVERLAP_SKIN: { int rcs = syncAll(c); if (rcs != SGE_OK) return rcs; c->overlapSkin = value != 0; break; }
-    case SGE_OPT_HEAVY_THRESHOLD: c->heavyThreshold = value; break;
+    case SGE_OPT_OVERLAP_SKIN: {
+        int rcs = syncAll(c);
+        if (rcs != SGE_OK) return rcs;
+        c->overlapRequested = value <= 0 ? 0 : (value >= 2 ? 2 : 1);
+        applyOverlapOption(c);
+        break;
+    }
+    case SGE_OPT_HEAVY_THRESHOLD: c->heavyThreshold = value; break; // (lists built for the old threshold are joined and rebuilt: launch_move)
     case SGE_OPT_PLACEMENT_PROBES: c->placementProbes = value; break;
     default: set_error("unknown option"); return SGE_ERR_INVALID;
     }
@@ -833,6 +878,9 @@ int sge_skin_consumed(sge_context* c, void* consumer_stream) {
     if (s == c->stream && !c->overlapSkin) return SGE_OK; // same stream, serial order: already ordered
     SGE_HIP(hipEventRecord(c->evConsumed, s));
     if (c->skinStream) SGE_HIP(hipStreamWaitEvent(c->skinStream, c->evConsumed, 0));
+    // the palettes are a consumer's input as well (jobs built from sge_crowd_buffers): pose(n+2) rewrites the buffer skin(n) read, and
+    // with the pose launch on a stream of its own neither of the two waits above stands in front of it
+    if (c->poseStream) SGE_HIP(hipStreamWaitEvent(c->poseStream, c->evConsumed, 0));
     if (s != c->stream) SGE_HIP(hipStreamWaitEvent(c->stream, c->evConsumed, 0));
     return SGE_OK;
 }
@@ -1299,6 +1347,193 @@ int sge_skinned_download(sge_context* c, int64_t first_vertex, int64_t vertex_co
     return SGE_OK;
 }
 
+// ---- asynchronous World synchronisation ------------------------------------------------------
+namespace {
+// the arrays of sge_state_*: bit k of `which` <-> row k
+constexpr int kStateArrays = 5;
+constexpr size_t kStateBytes[kStateArrays] = {sizeof(sge_body_state), sizeof(sge_controller_state), sizeof(sge_locomotion_state),
+                                              sizeof(sge_action_state), sizeof(sge_move_intent)};
+// 16-byte chunks of every struct that the move / separation stage writes, and that the animation stages write. A body is both sides':
+// words 0..15 (position, velocity, rotation) and the body type are the move stage's, transformRotation (chunk 4) is the pose
+// stage's write-back — with the pose launch on a stream of its own the two halves of one step are complete at different places.
+constexpr uint32_t kMoveSideChunks[kStateArrays] = {0x2Fu, 0xFFu, 0u, 0u, 0x3u};
+constexpr uint32_t kPoseSideChunks[kStateArrays] = {0x10u, 0u, 0x3Fu, 0x3u, 0u};
+static_assert(sizeof(sge_body_state) == 6 * 16 && offsetof(sge_body_state, transformRotation) == 4 * 16, "chunk masks");
+static_assert(sizeof(sge_controller_state) == 8 * 16 && sizeof(sge_locomotion_state) == 6 * 16 && sizeof(sge_action_state) == 2 * 16 &&
+              sizeof(sge_move_intent) == 2 * 16, "chunk masks");
+
+struct SnapArray { const uint4* src; uint4* dst; int chunks; uint32_t mask; };
+struct SnapLaunch { SnapArray a[kStateArrays]; int first, count; };
+// One thread per 16-byte chunk, blockIdx.y = array: dst is [count] structs, src the context's array of the whole crowd.
+__global__ void state_snapshot_kernel(SnapLaunch S) {
+    const SnapArray A = S.a[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S.count * A.chunks) return;
+    const int ch = i / A.chunks, k = i - ch * A.chunks;
+    if (!((A.mask >> k) & 1u)) return;
+    A.dst[i] = A.src[(size_t)(S.first + ch) * A.chunks + k];
+}
+
+void* stateArray(sge_context* c, int k) {
+    switch (k) {
+    case 0: return c->dBodies.p; case 1: return c->dCtrl.p; case 2: return c->dLoco.p; case 3: return c->dActions.p; default: return c->dIntents.p;
+    }
+}
+// offsets of the requested arrays in one packed block, [count] structs each; returns the block's size
+size_t stateLayout(uint32_t which, int count, size_t off[kStateArrays]) {
+    size_t total = 0;
+    for (int k = 0; k < kStateArrays; ++k) {
+        off[k] = total;
+        if (which & (1u << k)) total += (size_t)count * kStateBytes[k];
+    }
+    return total;
+}
+int pinnedReserve(void*& host, size_t& have, size_t need) {
+    if (need <= have && host) return SGE_OK;
+    if (host) (void)hipHostFree(host);
+    host = nullptr; have = 0;
+    if (need == 0) return SGE_OK;
+    need = (need + 4095) / 4096 * 4096;
+    SGE_HIP(hipHostMalloc(&host, need, hipHostMallocDefault));
+    have = need;
+    return SGE_OK;
+}
+void fillView(sge_state_view* v, char* base, uint32_t which, int first, int count, int ticket, const size_t off[kStateArrays]) {
+    *v = sge_state_view{};
+    v->first = first; v->count = count; v->which = which; v->ticket = ticket;
+    if (!base) return;
+    if (which & SGE_STATE_BODIES) v->bodies = reinterpret_cast<sge_body_state*>(base + off[0]);
+    if (which & SGE_STATE_CONTROLLERS) v->controllers = reinterpret_cast<sge_controller_state*>(base + off[1]);
+    if (which & SGE_STATE_LOCOMOTION) v->locomotion = reinterpret_cast<sge_locomotion_state*>(base + off[2]);
+    if (which & SGE_STATE_ACTIONS) v->actions = reinterpret_cast<sge_action_state*>(base + off[3]);
+    if (which & SGE_STATE_INTENTS) v->intents = reinterpret_cast<sge_move_intent*>(base + off[4]);
+}
+} // namespace
+
+int sge_state_pull_async(sge_context* c, uint32_t which, int32_t first, int32_t count, int32_t* ticket) {
+    if (!c || !ticket || which == 0 || (which & ~(uint32_t)SGE_STATE_WORLD)) { set_error("sge_state_pull_async: bad argument (which = SGE_STATE_BODIES | CONTROLLERS | LOCOMOTION | ACTIONS)"); return SGE_ERR_INVALID; }
+    if (count == 0) { first = 0; count = c->crowd.count; }
+    SGE_RANGE_CHECK();
+    (void)hipSetDevice(c->device);
+    sge_context::PullSlot& P = c->pull[c->pullTickets & 1];
+    if (P.inFlight) { SGE_HIP(hipEventSynchronize(P.evLanded)); P.inFlight = false; } // the pull before last: its memory is taken over
+    const size_t total = stateLayout(which, count, P.off);
+    int rc;
+    if ((rc = P.stage.alloc(total)) != SGE_OK || (rc = pinnedReserve(P.host, P.hostBytes, total)) != SGE_OK) return rc;
+    P.ticket = c->pullTickets++;
+    P.which = which; P.first = first; P.count = count;
+    *ticket = P.ticket;
+    if (total == 0) return SGE_OK;
+    // The animation stages' half of the step: where the newest pose launch ran. A launch on the pose stream is followed there (the
+    // next tick's pose launch queues behind the snapshot, its move stage does not wait for either); otherwise everything is the
+    // main stream's and one launch takes both halves.
+    const bool piped = c->posePending[0] || c->posePending[1];
+    SnapLaunch M{}, A{};
+    M.first = A.first = first; M.count = A.count = count;
+    int nm = 0, na = 0;
+    for (int k = 0; k < 4; ++k) {
+        if (!(which & (1u << k))) continue;
+        const uint32_t ms = piped ? kMoveSideChunks[k] : (kMoveSideChunks[k] | kPoseSideChunks[k]), as = piped ? kPoseSideChunks[k] : 0u;
+        const int chunks = (int)(kStateBytes[k] / 16);
+        uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<char*>(P.stage.p) + P.off[k]);
+        if (ms) M.a[nm++] = SnapArray{reinterpret_cast<const uint4*>(stateArray(c, k)), dst, chunks, ms};
+        if (as) A.a[na++] = SnapArray{reinterpret_cast<const uint4*>(stateArray(c, k)), dst, chunks, as};
+    }
+    const int blocks = (count * 8 + 255) / 256;
+    if (nm) hipLaunchKernelGGL(state_snapshot_kernel, dim3(blocks, nm), dim3(256), 0, c->stream, M);
+    SGE_HIP(hipEventRecord(P.evMain, c->stream));
+    SGE_HIP(hipStreamWaitEvent(c->copyStream, P.evMain, 0));
+    if (na) {
+        hipLaunchKernelGGL(state_snapshot_kernel, dim3(blocks, na), dim3(256), 0, c->poseStream, A);
+        SGE_HIP(hipEventRecord(P.evPose, c->poseStream));
+        SGE_HIP(hipStreamWaitEvent(c->copyStream, P.evPose, 0));
+    }
+    SGE_HIP(hipGetLastError());
+    SGE_HIP(hipMemcpyAsync(P.host, P.stage.p, total, hipMemcpyDeviceToHost, c->copyStream));
+    SGE_HIP(hipEventRecord(P.evLanded, c->copyStream));
+    P.inFlight = true;
+    return SGE_OK;
+}
+
+namespace {
+sge_context::PullSlot* findPull(sge_context* c, int32_t ticket) {
+    for (auto& P : c->pull) if (P.ticket == ticket && ticket >= 0) return &P;
+    return nullptr;
+}
+} // namespace
+
+int sge_state_wait(sge_context* c, int32_t ticket, sge_state_view* view) {
+    if (!c || !view) { set_error("sge_state_wait: bad argument"); return SGE_ERR_INVALID; }
+    sge_context::PullSlot* P = findPull(c, ticket);
+    if (!P) { set_error("sge_state_wait: unknown ticket (two pulls have been enqueued since, or none with this number)"); return SGE_ERR_STATE; }
+    (void)hipSetDevice(c->device);
+    if (P->inFlight) { SGE_HIP(hipEventSynchronize(P->evLanded)); P->inFlight = false; }
+    fillView(view, reinterpret_cast<char*>(P->host), P->which, P->first, P->count, P->ticket, P->off);
+    return SGE_OK;
+}
+
+int sge_state_poll(sge_context* c, int32_t ticket) {
+    if (!c) return SGE_ERR_INVALID;
+    sge_context::PullSlot* P = findPull(c, ticket);
+    if (!P) { set_error("sge_state_poll: unknown ticket"); return SGE_ERR_STATE; }
+    if (!P->inFlight) return SGE_OK;
+    (void)hipSetDevice(c->device);
+    const hipError_t e = hipEventQuery(P->evLanded);
+    if (e == hipSuccess) return SGE_OK;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return SGE_ERR_NOT_READY; }
+    return hip_fail(e, "hipEventQuery");
+}
+
+int sge_state_push_begin(sge_context* c, uint32_t which, int32_t first, int32_t count, sge_state_view* staging) {
+    if (!c || !staging || which == 0 || (which & ~(uint32_t)(SGE_STATE_WORLD | SGE_STATE_INTENTS))) { set_error("sge_state_push_begin: bad argument"); return SGE_ERR_INVALID; }
+    if (c->pushOpen) { set_error("sge_state_push_begin: the previous staging has not been committed"); return SGE_ERR_STATE; }
+    if (count == 0) { first = 0; count = c->crowd.count; }
+    SGE_RANGE_CHECK();
+    (void)hipSetDevice(c->device);
+    sge_context::PushSlot& S = c->push[c->pushSlot];
+    if (S.inFlight) { SGE_HIP(hipEventSynchronize(S.evCopied)); S.inFlight = false; } // the push before last still reads this staging
+    const size_t total = stateLayout(which, count, c->pushOff);
+    int rc = pinnedReserve(S.host, S.hostBytes, total);
+    if (rc != SGE_OK) return rc;
+    c->pushWhich = which; c->pushFirst = first; c->pushCount = count; c->pushOpen = true;
+    fillView(staging, reinterpret_cast<char*>(S.host), which, first, count, -1, c->pushOff);
+    return SGE_OK;
+}
+
+int sge_state_push_commit(sge_context* c) {
+    if (!c) return SGE_ERR_INVALID;
+    if (!c->pushOpen) { set_error("sge_state_push_commit without sge_state_push_begin"); return SGE_ERR_STATE; }
+    c->pushOpen = false;
+    sge_context::PushSlot& S = c->push[c->pushSlot];
+    const int count = c->pushCount, first = c->pushFirst;
+    if (count == 0) return SGE_OK;
+    if (first + count > c->crowd.count) { set_error("sge_state_push_commit: the crowd was resized under an open staging"); return SGE_ERR_STATE; }
+    sge_state_view v;
+    fillView(&v, reinterpret_cast<char*>(S.host), c->pushWhich, first, count, -1, c->pushOff);
+    // the same index checks as sge_characters_upload: the kernels index the profile table with these
+    if (v.locomotion)
+        for (int i = 0; i < count; ++i) {
+            const sge_locomotion_state& l = v.locomotion[i];
+            for (int k = 0; k < 4; ++k)
+                if ((l.flags & SGE_LOCO_PRESENT) && (l.profile[k] < 0 || l.profile[k] >= c->prof.count)) { set_error("locomotion profile index out of range"); return SGE_ERR_INVALID; }
+            if ((l.flags & SGE_MOTION_PRESENT) && (l.motionProfile < 0 || l.motionProfile >= c->prof.count)) { set_error("motion profile index out of range"); return SGE_ERR_INVALID; }
+            if ((l.flags & SGE_LOCO_PRESENT) && ((unsigned)l.state > 3u || (unsigned)l.fromState > 3u)) { set_error("locomotion state out of range"); return SGE_ERR_INVALID; }
+        }
+    if (v.actions)
+        for (int i = 0; i < count; ++i)
+            if ((v.actions[i].flags & SGE_ACTION_PRESENT) && (v.actions[i].profile < 0 || v.actions[i].profile >= c->prof.count)) { set_error("action profile index out of range"); return SGE_ERR_INVALID; }
+    (void)hipSetDevice(c->device);
+    // a pose launch on the pose stream owns the animation states and transformRotation meanwhile; intents are nobody's but the host's
+    if (c->pushWhich & ~(uint32_t)SGE_STATE_INTENTS) { int rcp = joinPose(c); if (rcp != SGE_OK) return rcp; }
+    const void* src[kStateArrays] = {v.bodies, v.controllers, v.locomotion, v.actions, v.intents};
+    for (int k = 0; k < kStateArrays; ++k)
+        if (src[k]) SGE_HIP(hipMemcpyAsync(reinterpret_cast<char*>(stateArray(c, k)) + (size_t)first * kStateBytes[k], src[k], (size_t)count * kStateBytes[k], hipMemcpyHostToDevice, c->stream));
+    SGE_HIP(hipEventRecord(S.evCopied, c->stream));
+    S.inFlight = true;
+    c->pushSlot ^= 1;
+    return SGE_OK;
+}
+
 // ---- the batched fixed step --------------------------------------------------------------
 int sge_tick(sge_context* c, const sge_tick_desc* d) {
     if (!c || !d) { set_error("sge_tick: bad argument"); return SGE_ERR_INVALID; }
@@ -1342,6 +1577,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         // lists built behind the previous step's move stage serve this one if nothing they depend on has changed; their cap is the grid
         const bool listsReady = c->listsValid && c->listsFirst == first && c->listsCount == count && c->listsThreshold == c->heavyThreshold;
         L.listsReady = listsReady ? 1 : 0;
+        L.listsPending = c->listsValid ? 1 : 0; // a build enqueued behind an earlier move stage; launch_move joins it when it cannot use it
         L.heavyCap = listsReady ? c->listsCap : capNow;
         L.nextHeavyCap = capNow;
         if (c->waveProfOn) {
@@ -1724,7 +1960,29 @@ int sge_profile_read(sge_context* c, sge_stage_times* out, int reset) {
                            c->evMove.launches, c->evPose.launches, c->evSkin.launches, c->evAgents.launches};
     if (reset) {
         for (Events* e : {&c->evMove, &c->evPose, &c->evSkin, &c->evAgents}) { e->ms = 0; e->launches = 0; }
+        c->skinLaunchMs.clear();
     }
+    return SGE_OK;
+}
+
+// diagnostics: the HIP-event duration of every skin launch since the last reset of sge_profile_read, oldest first (what the
+// `roofline.ms_per_launch` of bench.py averages); *count = how many there are, min(*count, cap) are written
+int sge_debug_skin_launch_times(sge_context* c, float* out_ms, int32_t cap, int32_t* count) {
+    if (!c || !count || cap < 0 || (cap > 0 && !out_ms)) return SGE_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    int rc = drainEvents(c->evSkin);
+    if (rc != SGE_OK) return rc;
+    *count = (int32_t)c->skinLaunchMs.size();
+    for (int i = 0; i < cap && i < *count; ++i) out_ms[i] = c->skinLaunchMs[(size_t)i];
+    return SGE_OK;
+}
+
+// diagnostics: what allocCrowdOutputs found when it placed the skinned output streams: the kept placement's time for one
+// three-stream store pass (0: not probed) and how many placements were timed
+int sge_debug_placement(sge_context* c, float* kept_ms, int32_t* tried) {
+    if (!c) return SGE_ERR_INVALID;
+    if (kept_ms) *kept_ms = c->placementMs;
+    if (tried) *tried = c->placementTried;
     return SGE_OK;
 }
 

@@ -3225,6 +3225,10 @@ bool launch_move(const MoveLaunch& L, hipStream_t s) {
         if (heavy && L.heavyDemandHost) (void)hipMemcpyAsync(L.heavyDemandHost, L.listCounts + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, q);
     };
     const bool listsFromLastStep = move && pipelined && L.listsReady; // built behind the previous step, on the second stream
+    // A build of the previous stage that this one cannot use (another range, another threshold, the option switched off) may still be
+    // running on the second stream: it writes the same lists, counts, flags and histogram as the build below and as the kernels of
+    // this stage read, so the main stream joins it first (the stage that CAN use it waits further down, in front of its first reader).
+    if (move && L.listsPending && !listsFromLastStep) (void)hipStreamWaitEvent(s, L.evListsReady, 0);
     if (move && !listsFromLastStep) { buildLists(s, L.heavyCap); copyDemand(s); } // first step, or something changed
     // (part 0 at the head of the grouped launch instead — no launch in front of the stage, no round trip of the working set — was
     // built and measured: the grouped kernel then needs 166 registers instead of 155, one wavefront fewer fits beside two resident

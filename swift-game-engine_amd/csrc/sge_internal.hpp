@@ -258,6 +258,7 @@ struct MoveLaunch {
     // diagnostics (SGE_WAVE_PROF=1), rows of 8 x u64 in three regions of crowd.count rows each: [0] one row per wavefront of
     // move_group_kernel, [1] one row per character of move_kernel<0>, [2] one row per character of pose_kernel
     unsigned long long* waveProf;
+    int listsPending;                      // an earlier launch_move left a list build in flight on heavyStream (evListsReady marks its end)
 };
 // Per-device launch state: a process may hold contexts on several GPUs (sge_context_create(device_index)), and function attributes
 // and the CU count belong to the device that is current at the launch (every entry point calls hipSetDevice(ctx->device) first).

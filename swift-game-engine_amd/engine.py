@@ -22,7 +22,7 @@ class _ProductTable:
 
     def __init__(self, device_index=0, lib_path=None):
         self.lib = abi.load_library(lib_path)
-        if self.lib.sge_abi_version() != 1:
+        if self.lib.sge_abi_version() != abi.SGE_ABI_VERSION:
             raise SgeError("libsge_amd.so ABI version mismatch")
         self.handle = self.lib.sge_context_create(int(device_index))
         if not self.handle:
@@ -307,6 +307,49 @@ class CharacterEngine:
         self._call("characters_download", int(first), int(count), *[ptr(out[k]) for k in dts])
         return {k: v for k, v in out.items() if v is not None}
 
+    # -- asynchronous World synchronisation (pinned, event-ordered; product only) -- #
+    _STATE = (("bodies", abi.STATE_BODIES, abi.body_dtype), ("controllers", abi.STATE_CONTROLLERS, abi.controller_dtype),
+              ("locomotion", abi.STATE_LOCOMOTION, abi.locomotion_dtype), ("actions", abi.STATE_ACTIONS, abi.action_dtype),
+              ("intents", abi.STATE_INTENTS, abi.intent_dtype))
+
+    @classmethod
+    def _view_arrays(cls, view):
+        """numpy views (no copy) of the pinned arrays a sge_state_view names."""
+        out = {}
+        for name, bit, dt in cls._STATE:
+            p = getattr(view, name)
+            if p and view.count > 0:
+                buf = (C.c_char * (view.count * dt.itemsize)).from_address(p)
+                out[name] = np.frombuffer(buf, dtype=dt, count=view.count)
+        return out
+
+    def state_pull_async(self, which=abi.STATE_WORLD, first=0, count=0):
+        """Snapshot of the selected arrays behind everything enqueued so far, on its way to pinned host memory -> ticket."""
+        t = C.c_int32(-1)
+        self._call("state_pull_async", int(which), int(first), int(count), C.byref(t))
+        return t.value
+
+    def state_wait(self, ticket):
+        """Blocks until the pull has landed -> dict of numpy views of the context's pinned memory (valid until the pull after next)."""
+        v = abi.StateView()
+        self._call("state_wait", int(ticket), C.byref(v))
+        return self._view_arrays(v)
+
+    def state_ready(self, ticket):
+        rc = self.t.fn("state_poll")(self.h, int(ticket))
+        if rc not in (abi.SGE_OK, abi.SGE_ERR_NOT_READY):
+            raise SgeError(f"state_poll failed with code {rc}: {self.t.last_error()}")
+        return rc == abi.SGE_OK
+
+    def state_push_begin(self, which=abi.STATE_INTENTS, first=0, count=0):
+        """Pinned staging arrays (numpy views) for the host to fill; state_push_commit() enqueues the copies in front of the next tick."""
+        v = abi.StateView()
+        self._call("state_push_begin", int(which), int(first), int(count), C.byref(v))
+        return self._view_arrays(v)
+
+    def state_push_commit(self):
+        self._call("state_push_commit")
+
     def palettes(self, first=0, count=None, model=False, local=False):
         count = self.count - first if count is None else count
         pal = np.zeros((count, self.bone_count, 16), np.float32)
@@ -435,6 +478,20 @@ class CharacterEngine:
         st = abi.StageTimes()
         self._call("profile_read", C.byref(st), int(reset))
         return st
+
+    def skin_launch_times(self):
+        """HIP-event duration (ms) of every skin launch since the last profile reset (product only, OPT_PROFILE on)."""
+        n = C.c_int32(0)
+        self._call("debug_skin_launch_times", None, 0, C.byref(n))
+        out = np.zeros(max(n.value, 1), np.float32)
+        self._call("debug_skin_launch_times", ptr(out), int(out.shape[0]), C.byref(n))
+        return out[: n.value]
+
+    def placement(self):
+        """(ms of one three-stream store pass over the kept placement of the skinned output streams, placements timed)."""
+        ms, tried = C.c_float(0), C.c_int32(0)
+        self._call("debug_placement", C.byref(ms), C.byref(tried))
+        return ms.value, tried.value
 
     def move_cost(self, first=0, count=None):
         """Distance evaluations each character spent in the casts of its last fixed step (product only)."""

@@ -6,8 +6,11 @@
 //
 //  What it replaces: the per-entity dictionary traffic of `world.store(T.self)[e]` (World.swift:64-75) inside the hot systems. The GPU
 //  keeps the authoritative copy of every character's PhysicsBodyComponent / CharacterControllerComponent / locomotion / action state
-//  as SoA-of-PODs; the World's copies are refreshed once per fixed step (pullBack), and whatever other Swift systems wrote into the
-//  World since the last step (intents, teleports, dodge / jump edits) is pushed before the step (pushDirtyState).
+//  as SoA-of-PODs; the World's copies are refreshed once per fixed step (beginPull right behind sge_tick, pullBack when the host wants
+//  them), and whatever other Swift systems wrote into the World since the last step (intents, teleports, dodge / jump edits) is
+//  pushed before the step (pushDirtyState). Both directions go through the context's pinned memory, ordered by events
+//  (sge_state_pull_async / sge_state_wait, sge_state_push_begin / _commit): no call here synchronises the whole context, and none
+//  waits for the step's skin launch.
 
 import simd
 import CSGE
@@ -155,51 +158,70 @@ public final class GPUCrowd {
         let n = entities.count
         guard n > 0 else { return }
         let mStore = world.store(MoveIntentComponent.self), mvStore = world.store(MovementComponent.self), dStore = world.store(DodgeActionComponent.self)
-        for i in 0..<n { intents[i] = encodeIntent(mStore[entities[i]], mvStore[entities[i]], dStore[entities[i]]) }
-        check(sge_characters_upload(ctx, 0, Int32(n), nil, nil, nil, intents, nil, nil))
+        var staging = sge_state_view()
+        check(sge_state_push_begin(ctx, UInt32(SGE_STATE_INTENTS), 0, Int32(n), &staging))        // pinned staging, filled in place
+        for i in 0..<n { staging.intents[i] = encodeIntent(mStore[entities[i]], mvStore[entities[i]], dStore[entities[i]]) }
+        check(sge_state_push_commit(ctx))                                                          // copies enqueued in front of the next tick
         for e in dirtyBodies {
             guard let i = indexOf[e] else { continue }
             encode(entity: e, at: Int(i), world: world)
-            withUnsafePointer(to: &bodies[Int(i)]) { b in withUnsafePointer(to: &controllers[Int(i)]) { c in
-                check(sge_characters_upload(ctx, i, 1, b, nil, c, nil, nil, nil))
-            }}
+            check(sge_state_push_begin(ctx, UInt32(SGE_STATE_BODIES) | UInt32(SGE_STATE_CONTROLLERS), i, 1, &staging))
+            staging.bodies[0] = bodies[Int(i)]
+            staging.controllers[0] = controllers[Int(i)]
+            check(sge_state_push_commit(ctx))
         }
+    }
+
+    /// Right behind the step's sge_tick: the snapshot of this step starts its way to pinned host memory (taken on the device behind
+    /// the kernels that wrote the arrays, so the next tick may be enqueued at once). Returns immediately.
+    private var pendingPull: Int32 = -1
+    public func beginPull(which: UInt32 = UInt32(SGE_STATE_WORLD)) {
+        guard !entities.isEmpty else { return }
+        check(sge_state_pull_async(ctx, which, 0, 0, &pendingPull))
     }
 
     /// After the step: what the reference's systems would have written into the World (KinematicMoveStopSystem.writeBack
     /// Systems.swift:1802-1821, LocomotionProfileSystem :279-407, ActionAnimationSystem :475-517, PhysicsWritebackSystem :2249-2267).
+    /// Waits for the pull begun last — its copy only, not the skin launch, not later ticks — and decodes it from pinned memory.
     public func pullBack(into world: World, palettes: Bool = false) {
-        let n = entities.count
-        guard n > 0 else { return }
-        check(sge_characters_download(ctx, 0, Int32(n), &bodies, nil, &controllers, nil, &locomotion, &actions))
+        guard pendingPull >= 0 else { return }
+        var v = sge_state_view()
+        check(sge_state_wait(ctx, pendingPull, &v))
+        pendingPull = -1
+        let n = Int(v.count), first = Int(v.first)
         let pStore = world.store(PhysicsBodyComponent.self), cStore = world.store(CharacterControllerComponent.self)
         let lStore = world.store(LocomotionProfileComponent.self), mStore = world.store(MotionProfileComponent.self)
         let aStore = world.store(ActionAnimationComponent.self), tStore = world.store(TransformComponent.self)
         for i in 0..<n {
-            let e = entities[i]
-            if var b = pStore[e] { decode(bodies[i], into: &b); pStore[e] = b }
-            if var c = cStore[e] { decode(controllers[i], into: &c); cStore[e] = c }
-            if var l = lStore[e] { decode(locomotion[i], into: &l); lStore[e] = l }
-            if var m = mStore[e] { m.time = locomotion[i].motionTime; mStore[e] = m }
-            if var a = aStore[e] { decode(actions[i], into: &a); aStore[e] = a }
-            if var t = tStore[e] {      // PhysicsWritebackSystem: TransformComponent from the body
-                t.translation = SIMD3<Float>(Float(bodies[i].position.0), Float(bodies[i].position.1), Float(bodies[i].position.2))
-                t.rotation = quat(bodies[i].transformRotation)
-                tStore[e] = t
+            let e = entities[first + i]
+            if let vb = v.bodies {
+                let body = vb[i]
+                if var b = pStore[e] { decode(body, into: &b); pStore[e] = b }
+                if var t = tStore[e] {      // PhysicsWritebackSystem: TransformComponent from the body
+                    t.translation = SIMD3<Float>(Float(body.position.0), Float(body.position.1), Float(body.position.2))
+                    t.rotation = quat(body.transformRotation)
+                    tStore[e] = t
+                }
             }
+            if let vc = v.controllers, var c = cStore[e] { decode(vc[i], into: &c); cStore[e] = c }
+            if let vl = v.locomotion {
+                if var l = lStore[e] { decode(vl[i], into: &l); lStore[e] = l }
+                if var m = mStore[e] { m.time = vl[i].motionTime; mStore[e] = m }
+            }
+            if let va = v.actions, var a = aStore[e] { decode(va[i], into: &a); aStore[e] = a }
         }
-        if palettes, let s = skeleton {     // only if something on the CPU still wants PoseComponent.palette
-            var flat = [Float](repeating: 0, count: n * s.boneCount * 16)
-            check(sge_palettes_download(ctx, 0, Int32(n), &flat, nil, nil))
+        if palettes, let s = skeleton, let vl = v.locomotion {     // only if something on the CPU still wants PoseComponent.palette
+            var flat = [Float](repeating: 0, count: entities.count * s.boneCount * 16)
+            check(sge_palettes_download(ctx, 0, Int32(entities.count), &flat, nil, nil))         // (synchronises: debugging aid, not a per-step path)
             let poseStore = world.store(PoseComponent.self)
             for i in 0..<n {
-                guard var pose = poseStore[entities[i]] else { continue }
+                guard var pose = poseStore[entities[first + i]] else { continue }
                 flat.withUnsafeBytes { raw in
-                    let base = raw.baseAddress!.advanced(by: i * s.boneCount * 64).assumingMemoryBound(to: matrix_float4x4.self)
+                    let base = raw.baseAddress!.advanced(by: (first + i) * s.boneCount * 64).assumingMemoryBound(to: matrix_float4x4.self)
                     pose.palette = Array(UnsafeBufferPointer(start: base, count: s.boneCount))
                 }
-                pose.phase = locomotion[i].posePhase
-                poseStore[entities[i]] = pose
+                pose.phase = vl[i].posePhase
+                poseStore[entities[first + i]] = pose
             }
         }
     }

@@ -54,6 +54,7 @@ public final class KinematicMoveStopSystem: FixedStepSystem {
         crowd.pushDirtyState(from: world)
         uploadPlatforms(world: world)
         sgeTick(crowd, dt: dt, gravity: gravity, stages: UInt32(SGE_STAGE_MOVE) | policyBit)
+        crowd.beginPull(which: UInt32(SGE_STATE_BODIES) | UInt32(SGE_STATE_CONTROLLERS))   // writeBack, Systems.swift:1802-1821
         crowd.pullBack(into: world)
     }
 
@@ -131,6 +132,7 @@ public final class AgentSeparationSystem: FixedStepSystem {
     public func setQuery(_ query: CollisionQuery?) {}
     public func fixedUpdate(world: World, dt: Float) {
         sgeTick(crowd, dt: dt, stages: UInt32(SGE_STAGE_SEPARATION))
+        crowd.beginPull(which: UInt32(SGE_STATE_BODIES))
         crowd.pullBack(into: world)
     }
 }
@@ -142,6 +144,9 @@ public final class GPUCharacterStepSystem: FixedStepSystem {
     public var gravity = SIMD3<Float>(0, -98.0, 0)
     public var separation = false
     public var skin = true                     // RTSkinningEncoder work of the frame folded into the step (SGE_STAGE_SKIN)
+    /// false: the World holds step n when fixedUpdate returns (the host waits for move(n) + pose(n) + a 352 B/character copy, never for
+    /// skin(n)). true: the World runs one step behind and nothing is waited for — tick n + 1 is enqueued while pull n is on its way.
+    public var lagged = false
     public init(crowd: GPUCrowd) {
         self.crowd = crowd
         crowd.check(sge_context_set_option(crowd.ctx, Int32(SGE_OPT_OVERLAP_SKIN), 1))     // skin(n) beside move(n+1) + pose(n+1)
@@ -152,6 +157,8 @@ public final class GPUCharacterStepSystem: FixedStepSystem {
         if skin { stages |= UInt32(SGE_STAGE_SKIN) }
         if separation { stages |= UInt32(SGE_STAGE_SEPARATION) }
         sgeTick(crowd, dt: dt, gravity: gravity, stages: stages)
-        crowd.pullBack(into: world)
+        if lagged { crowd.pullBack(into: world) }     // the previous step's pull, long landed
+        crowd.beginPull()
+        if !lagged { crowd.pullBack(into: world) }
     }
 }

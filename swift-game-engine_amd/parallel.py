@@ -49,6 +49,7 @@ class AgentExchange:
         import os
         self.force_sync = os.environ.get("SGE_EXCHANGE_SYNC", "0") not in ("", "0")  # host synchronisation around the collective
         self.checked = False
+        self.self_check = None  # "passed" once the first stream-ordered exchange has been compared with a synchronised one
         if self.product and world == 1:
             return  # sge_agents_allgather keeps its own buffers
         self.staged = self.product and dist is not None and dist.get_backend() != "nccl"  # rehearsal: gloo moves host memory
@@ -59,6 +60,19 @@ class AgentExchange:
             self.local = torch.zeros((self.slot, 8), dtype=torch.float32, device=device)
             self.local[:, 3] = -1.0
             self.all = torch.zeros((world * self.slot, 8), dtype=torch.float32, device=device)
+
+    def describe(self):
+        """What a bench record says about the exchange that ran."""
+        if self.product and self.world == 1:
+            path = "sge_agents_allgather (one rank: export + import, no collective)"
+        elif self.product and not self.staged:
+            path = "stream-ordered: export kernel -> all_gather_into_tensor (RCCL) -> import, on the engine's stream, no host synchronisation" + (
+                " [SGE_EXCHANGE_SYNC: host synchronisation around the collective]" if self.force_sync else "")
+        elif self.staged:
+            path = "staged rehearsal: export -> host memory -> gloo all-gather -> device -> import (synchronising)"
+        else:
+            path = "host arrays (CPU oracle under test)"
+        return {"path": path, "records_per_rank": self.slot, "bytes_per_rank": self.slot * 32, "self_check": self.self_check}
 
     def step(self, dt=1.0 / 60.0, stages=abi.STAGE_ALL, gravity=(0.0, -98.0, 0.0)):
         """One fixed step with character-vs-character sweeps. The snapshot is taken inside
@@ -78,22 +92,24 @@ class AgentExchange:
                 if self.force_sync:
                     self.torch.cuda.synchronize()
             if not self.checked:
-                # The stream-ordered path (no host synchronisation between export, collective and import) has never run on more than
-                # one GPU before the first multi-GPU job does: the first exchange is repeated with host synchronisation on both
-                # sides and compared. A mismatch switches this exchange to the synchronising form for good and says so.
+                # The stream-ordered path (no host synchronisation between export, collective and import) is repeated once with host
+                # synchronisation on both sides and compared. A mismatch is an ordering bug, not a condition to run with: every rank
+                # learns of it (all-reduce of the verdict, so that no rank is left waiting in a collective) and raises.
+                # SGE_EXCHANGE_SYNC=1 is the explicit escape hatch (host synchronisation around every exchange).
                 self.checked = True
                 eng.synchronize()
                 self.torch.cuda.synchronize()
                 check = self.torch.empty_like(self.all)
                 self.dist.all_gather_into_tensor(check, self.local)
                 self.torch.cuda.synchronize()
-                if not self.torch.equal(check, self.all):
-                    import sys
-                    print("[sge] rank %d: the stream-ordered agent exchange disagrees with the synchronised one; "
-                          "using host synchronisation from here on" % self.rank, file=sys.stderr, flush=True)
-                    self.force_sync = True
-                    self.all.copy_(check)
-                    self.torch.cuda.synchronize()
+                differ = int((check != self.all).any(dim=1).sum().item())
+                verdict = self.torch.tensor([differ], dtype=self.torch.int64, device=self.all.device)
+                self.dist.all_reduce(verdict, op=self.dist.ReduceOp.MAX)
+                self.self_check = "passed" if int(verdict.item()) == 0 else "failed"
+                if self.self_check == "failed":
+                    raise RuntimeError("[sge] rank %d: the stream-ordered agent exchange disagrees with the synchronised one (%d of %d records "
+                                       "differ on this rank; some rank saw %d). Set SGE_EXCHANGE_SYNC=1 to run with host synchronisation "
+                                       "around the collective." % (self.rank, differ, self.all.shape[0], int(verdict.item())))
             eng.agents_import(self.all.data_ptr(), self.all.shape[0], self.self_offset)
         else:
             eng.agents_export(self.local.data_ptr())

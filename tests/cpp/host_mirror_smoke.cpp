@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <unordered_set>
 #include "../../swift-game-engine_amd/host/sge_host.hpp"
 
 #define CHECK(cond) do { if (!(cond)) { std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } } while (0)
@@ -79,6 +80,72 @@ int main() {
     bool threw = false;
     try { sge::PoseStackSystem().fixedUpdate(*world, 1.0f / 60.0f); } catch (const sge::Error& e) { threw = std::strstr(e.what(), "skeleton") != nullptr; }
     CHECK(threw);
+    // ---- the World <-> GPU bridge: a host that keeps its component stores (World.swift:64-75) ----------------------------------
+    // 256 entities with non-contiguous ids walk over the ground quad; a "steering system" rewrites the MoveIntent store every
+    // step; GPUCharacterStepSystem pushes the intents through the pinned staging, ticks, pulls the step back into the stores.
+    // The stores after every step must equal a synchronous download, in both modes (World at step n / World one step behind).
+    {
+        const uint32_t stages = SGE_STAGE_INTENT | SGE_STAGE_GRAVITY | SGE_STAGE_MOVE | SGE_STAGE_LOCOMOTION | SGE_STAGE_ACTION | SGE_STAGE_WRITEBACK;
+        for (int lagged = 0; lagged < 2; ++lagged) {
+            sge::EntityWorld ew;
+            std::unordered_map<sge::Entity, double> startX;
+            const int n = 256;
+            for (int i = 0; i < n; ++i) {
+                const sge::Entity e = 1000u + 7u * (uint32_t)((i * 37) % n);   // ids out of order: the crowd sorts them
+                sge::PhysicsBodyComponent b;
+                b.position[0] = -30.0 + 4.0 * (i % 16); b.position[1] = -0.45; b.position[2] = -30.0 + 4.0 * (i / 16);
+                ew.bodies[e] = b;
+                startX[e] = b.position[0];
+                ew.transforms[e] = sge::TransformComponent{};
+                ew.controllers[e] = sge::CharacterControllerComponent{};
+                ew.intents[e] = sge::MoveIntentComponent{};
+                ew.movements[e] = sge::MovementComponent{};
+            }
+            sge::GPUCrowd crowd(*world);
+            crowd.rebuild(ew);
+            CHECK((int)crowd.entities().size() == n && crowd.entities()[0] < crowd.entities()[1] && crowd.index(crowd.entities()[5]).value() == 5);
+            sge::GPUCharacterStepSystem step(*world, crowd, ew, stages, lagged != 0);
+            std::vector<sge_body_state> prevBodies(n), nowBodies(n);
+            std::vector<sge_controller_state> nowCtrl(n);
+            for (int s = 0; s < 90; ++s) {
+                for (auto& kv : ew.intents) {   // the steering system: everybody circles, phase by entity id
+                    const float a = 0.05f * (float)s + 0.01f * (float)kv.first;
+                    kv.second.desiredVelocity[0] = 4.5f * std::cos(a); kv.second.desiredVelocity[2] = 4.5f * std::sin(a);
+                }
+                std::unordered_set<sge::Entity> dirty;
+                if (s == 40) {                 // a teleport written into the World by some other system
+                    const sge::Entity e = crowd.entities()[17];
+                    ew.bodies[e].position[1] += 3.0;
+                    dirty.insert(e);
+                }
+                step.fixedUpdate(1.0f / 60.0f, dirty);
+                prevBodies = nowBodies;
+                world->download(0, n, nowBodies.data(), nullptr, nowCtrl.data(), nullptr, nullptr, nullptr);   // synchronous reference
+                const std::vector<sge_body_state>& expect = lagged ? prevBodies : nowBodies;
+                if (lagged && s == 0) continue;
+                for (int i = 0; i < n; ++i) {
+                    const sge::PhysicsBodyComponent& b = ew.bodies.at(crowd.entities()[(size_t)i]);
+                    // (the step after a teleport the lagged World still holds the teleported value the host wrote: skip that entity)
+                    if (lagged && s == 40 && i == 17) continue;
+                    CHECK(std::memcmp(b.position, expect[i].position, sizeof(b.position)) == 0);
+                    CHECK(std::memcmp(b.linearVelocity, expect[i].linearVelocity, sizeof(b.linearVelocity)) == 0);
+                }
+                if (!lagged)
+                    for (int i = 0; i < n; ++i) {
+                        const sge::CharacterControllerComponent& c = ew.controllers.at(crowd.entities()[(size_t)i]);
+                        CHECK(c.grounded == ((nowCtrl[i].flags & SGE_CTRL_GROUNDED) != 0) && c.groundTriangleIndex == nowCtrl[i].groundTriangleIndex);
+                        CHECK((int)c.contactManifoldTriangles.size() == nowCtrl[i].manifoldCount);
+                    }
+            }
+            step.finish();
+            // everybody moved, the teleported one came down again
+            double moved = 0;
+            for (const auto& kv : ew.bodies) moved += std::fabs(kv.second.position[0] - startX.at(kv.first));
+            CHECK(moved > 10.0);
+            CHECK(std::fabs(ew.bodies.at(crowd.entities()[17]).position[1] - (-0.45)) < 0.05);
+            CHECK(std::fabs(ew.transforms.at(crowd.entities()[3]).translation[0] - (float)ew.bodies.at(crowd.entities()[3]).position[0]) < 1e-6f);
+        }
+    }
     std::printf("host mirror smoke ok: settled at y = %.4f\n", body.position[1]);
     return 0;
 }

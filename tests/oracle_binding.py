@@ -20,10 +20,12 @@ abi = _pkg.abi
 
 _SKIP = {"sge_context_create", "sge_context_destroy", "sge_last_error", "sge_abi_version", "sge_context_set_stream",
          "sge_synchronize", "sge_context_set_option", "sge_skinning_encode", "sge_crowd_buffers", "sge_crowd_palette_buffers", "sge_skin_wait", "sge_skin_consumed",
-         "sge_skinned_mesh_buffers", "sge_profile_read", "sge_move_cost_read", "sge_debug_wave_profile", "sge_debug_move_lists", "sge_debug_separation", "sge_debug_skin_form", "sge_context_get_stream", "sge_agents_allgather",
+         "sge_skinned_mesh_buffers", "sge_profile_read", "sge_move_cost_read", "sge_debug_wave_profile", "sge_debug_move_lists", "sge_debug_separation", "sge_debug_skin_form", "sge_debug_skin_launch_times", "sge_debug_placement", "sge_context_get_stream", "sge_agents_allgather",
          # the acceleration structure is the product's own layout; the oracle only scans the index buffer
          "sge_blas_topology", "sge_blas_info_get", "sge_blas_refit", "sge_blas_refit_buffers", "sge_blas_bounds_download",
-         "sge_blas_buffers", "sge_blas_profile_read", "sge_blas_intersect_device"}
+         "sge_blas_buffers", "sge_blas_profile_read", "sge_blas_intersect_device",
+         # the pinned, event-ordered World synchronisation is plumbing of the HIP product
+         "sge_state_pull_async", "sge_state_wait", "sge_state_poll", "sge_state_push_begin", "sge_state_push_commit"}
 
 
 def build_oracle():

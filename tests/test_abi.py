@@ -40,7 +40,8 @@ def test_library_exports_every_declared_symbol(sge, lib):
     out = subprocess.check_output(["nm", "-D", "--defined-only", sge.abi.library_path()], text=True)
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
     assert set(declared_functions()) <= exported
-    assert lib.sge_abi_version() == 1
+    assert lib.sge_abi_version() == 2 == sge.abi.SGE_ABI_VERSION  # 2: SGE_OPT_OVERLAP_SKIN on a caller's stream needs the value 2; sge_state_*
+    assert re.search(r"#define SGE_ABI_VERSION 2\b", open(HEADER).read())
 
 
 def test_struct_layouts_match_the_header(sge, tmp_path):
@@ -56,7 +57,7 @@ def test_struct_layouts_match_the_header(sge, tmp_path):
              "sge_agent_state": sge.abi.AgentState, "sge_stage_times": sge.abi.StageTimes,
              "sge_move_stats": sge.abi.MoveStats, "sge_surface_material": sge.abi.SurfaceMaterial,
              "sge_blas_info": sge.abi.BlasInfo, "sge_blas_ray": sge.abi.BlasRay, "sge_blas_hit": sge.abi.BlasHit,
-             "sge_ray_query": sge.abi.RayQuery, "sge_raycast_hit": sge.abi.RaycastHit, "sge_platform_state": sge.abi.PlatformState}
+             "sge_state_view": sge.abi.StateView, "sge_ray_query": sge.abi.RayQuery, "sge_raycast_hit": sge.abi.RaycastHit, "sge_platform_state": sge.abi.PlatformState}
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "sge_amd.h"\nint main(void){' +
                    "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}\n")

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import oracle_binding as ob
-from scenes import PlatformScene, assert_struct_equal, box_mesh, build_scene, compare_states, spawn_on_platforms, translation_matrix
+from scenes import PlatformScene, assert_close, assert_struct_equal, box_mesh, build_scene, compare_states, spawn_on_platforms, translation_matrix
 
 pytestmark = pytest.mark.gpu
 REL = 1e-5
@@ -28,7 +28,7 @@ def engines(sge):
 
 def test_library_refuses_without_fallback(sge):
     # the product path is the HIP library; the loader has no alternative
-    assert sge.abi.load_library().sge_abi_version() == 1
+    assert sge.abi.load_library().sge_abi_version() == sge.abi.SGE_ABI_VERSION == 2
 
 
 def test_bvh_build_bit_exact(sge, engines):
@@ -148,7 +148,7 @@ def test_skinning_kernel_vs_oracle(sge, engines):
     gp, gn, gt = gpu.skinned()
     cp, cn, ct = cpu.skinned()
     assert gp.shape[0] == n * gpu.vertex_count
-    assert np.abs(gp - cp).max() <= REL * np.abs(cp).max()
+    assert_close(gp, cp, "gp vs cp")
     assert np.abs(gn - cn).max() <= 2e-6 and np.abs(gt - ct).max() <= 2e-6
     assert np.allclose(np.linalg.norm(gn, axis=1), 1, atol=1e-5)
     # padded (Metal float3 stride) layout gives the same numbers
@@ -198,7 +198,7 @@ def test_full_tick_parity(sge, engines, mixed):
     assert (g["locomotion"]["state"] != 0).any()
     gp, gn, gt = gpu.skinned()
     cp, cn, ct = cpu.skinned()
-    assert np.abs(gp - cp).max() <= REL * np.abs(cp).max()
+    assert_close(gp, cp, "gp vs cp")
     assert gpu.move_stats().overflow == 0
 
 
@@ -386,7 +386,7 @@ def test_real_assets_full_tick_parity(sge):
     ob.tick_mt(cpu, 8, dt=0.0, stages=sge.abi.STAGE_SKIN)
     gp, gn, gt = gpu.skinned()
     cp, cn, ct = cpu.skinned()
-    assert np.abs(gp - cp).max() <= REL * np.abs(cp).max()
+    assert_close(gp, cp, "gp vs cp")
     assert np.abs(gn - cn).max() <= 2e-5 and np.abs(gt - ct).max() <= 2e-5
     gpu.close()
     cpu.close()
@@ -704,7 +704,7 @@ def test_demo_scene_example_parity(sge):
     assert len(tg) == len(tc) == 16
     for (s1, p1, f1, g1, l1), (s2, p2, f2, g2, l2) in zip(tg, tc):
         assert s1 == s2 and np.array_equal(p1, p2) and (f1, g1, l1) == (f2, g2, l2), (s1, p1, p2)
-    assert np.abs(sg - sc).max() <= REL * np.abs(sc).max()
+    assert_close(sg, sc, "sg vs sc")
     pushed = [p[0] for _, p, _, _, _ in tg]
     assert min(pushed) < -12.0            # it reached the mover and was pushed along with it
     # the renderer's next step: primary rays at the player's refitted acceleration structure (GPU: wide-BVH traversal over the
@@ -781,7 +781,7 @@ def test_full_size_properties(sge):
     assert np.array_equal(d1["locomotion"]["state"][pick], c["locomotion"]["state"])
     gp = gpu.skinned(int(pick[5]) * V, V)[0]
     cp = cpu.skinned(5 * V, V)[0]
-    assert np.abs(gp - cp).max() <= REL * np.abs(cp).max()
+    assert_close(gp, cp, "gp vs cp")
     gpu.close()
     cpu.close()
 
@@ -809,7 +809,7 @@ def test_config_lbs_only_parity(sge, engines):
             compare_states(sge, gpu, cpu, n)
             gp, gn, gt = gpu.skinned()
             cp, cn, ct = cpu.skinned()
-            assert np.abs(gp - cp).max() <= REL * np.abs(cp).max()
+            assert_close(gp, cp, "gp vs cp")
             assert np.abs(gn - cn).max() <= 2e-5 and np.abs(gt - ct).max() <= 2e-5
     # no collision stage ran: bodies are untouched, the pose moved
     assert_struct_equal(gpu.download(what=("bodies",))["bodies"], before, "bodies")
@@ -859,11 +859,11 @@ def test_config_lbs_only_full_size(sge):
         cpu.tick(stages=stages)
     gpal = np.stack([gpu.palettes(int(i), 1)[0][0] for i in pick])
     cpal, _, _ = cpu.palettes()
-    assert np.abs(gpal - cpal).max() <= REL * np.abs(cpal).max()
+    assert_close(gpal, cpal, "gpal vs cpal")
     for k in (0, 17, 47):
         gp = gpu.skinned(int(pick[k]) * V, V)[0]
         cp = cpu.skinned(k * V, V)[0]
-        assert np.abs(gp - cp).max() <= REL * np.abs(cp).max()
+        assert_close(gp, cp, "gp vs cp")
     gpu.close()
     cpu.close()
 
@@ -884,7 +884,7 @@ def test_overlap_mode_parity(sge):
             compare_states(sge, gpu, cpu, n)      # downloads join both streams
             gp, gn, gt = gpu.skinned()
             cp, cn, ct = cpu.skinned()
-            assert np.abs(gp - cp).max() <= REL * np.abs(cp).max()
+            assert_close(gp, cp, "gp vs cp")
             assert np.abs(gn - cn).max() <= 2e-5 and np.abs(gt - ct).max() <= 2e-5
     # stage subsets and the non-overlapped path mid-run
     gpu.tick(stages=sge.abi.STAGE_ALL & ~sge.abi.STAGE_SKIN)
@@ -894,7 +894,7 @@ def test_overlap_mode_parity(sge):
         gpu.tick()
         ob.tick_mt(cpu, 8)
     compare_states(sge, gpu, cpu, n)
-    assert np.abs(gpu.skinned()[0] - cpu.skinned()[0]).max() <= REL * np.abs(cpu.skinned()[0]).max()
+    assert_close(gpu.skinned()[0], cpu.skinned()[0], "skinned positions")
     assert gpu.move_stats().overflow == 0
     gpu.close()
     cpu.close()
@@ -1107,11 +1107,11 @@ def test_bench_default_full_size(sge):
     assert_struct_equal(out["bodies"][pick], c["bodies"], "bodies(subset vs oracle)")
     assert_struct_equal(out["controllers"][pick], c["controllers"], "controllers(subset vs oracle)")
     cpal = cpu.palettes(0, len(pick))[0]
-    assert np.abs(pal - cpal).max() <= REL * np.abs(cpal).max()
+    assert_close(pal, cpal, "pal vs cpal")
     for j, cidx in ((0, int(pick[0])), (len(pick) // 2, int(pick[len(pick) // 2])), (len(pick) - 1, int(pick[-1]))):
         cp, cn, ct = cpu.skinned(first_vertex=j * V, vertex_count=V)
         gp, gn, gt = skinned[cidx]
-        assert np.abs(gp - cp).max() <= REL * np.abs(cp).max()
+        assert_close(gp, cp, "gp vs cp")
         assert np.abs(gn - cn).max() <= 2e-5 and np.abs(gt - ct).max() <= 2e-5
     cpu.close()
 
@@ -1200,7 +1200,7 @@ def test_schedule_transitions_leave_no_launch_behind(sge):
         for _ in range(3):
             eng.tick()
         if scheduled:
-            eng.set_option(A.OPT_OVERLAP_SKIN, 1)
+            eng.set_option(A.OPT_OVERLAP_SKIN, 2)                    # 2: the overlap schedule on a caller's stream as well (ABI version 2)
             assert lib.sge_context_set_stream(h, C.c_void_p(caller.cuda_stream)) == 0
         for _ in range(5):
             eng.tick()
@@ -1255,7 +1255,7 @@ def test_overlap_on_a_caller_stream_with_a_consumer(sge):
 
     def make(overlap):
         eng = sge.CharacterEngine(0)
-        eng.set_option(A.OPT_OVERLAP_SKIN, 1 if overlap else 0)
+        eng.set_option(A.OPT_OVERLAP_SKIN, 2 if overlap else 0)   # 2 = the explicit opt-in for a caller-provided stream
         sge.crowd.upload_character_assets(eng, ybot)
         terrain = sge.crowd.upload_terrain(eng)
         sge.crowd.spawn_crowd(eng, ybot, n, terrain, seed=31, mode="ccd", mixed=True)

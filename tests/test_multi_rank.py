@@ -89,3 +89,23 @@ def test_two_ranks_match_single_process(sge, tmp_path):
         eng3.tick(stages=sge.abi.STAGE_ALL_FIXED)
     free = eng3.download(what=("bodies",))["bodies"]
     assert np.abs(free["position"] - ref["bodies"]["position"]).max() > 1e-3
+
+
+def test_bench_launcher_starts_ranks_itself_and_reports_their_failure():
+    """`python bench.py --gpus 2` with no launcher in front of it (the shape of the driver's N=1 command with another N): the parent
+    starts two fresh rank processes before it imports torch. There is no GPU in this container, so every rank must end with the
+    product's "no CPU fallback" message and the parent must return non-zero without a JSON line — and without hanging on a
+    rendezvous. (On a GPU box: tests/test_multi_gpu.py.)"""
+    import subprocess
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: covered by tests/test_multi_gpu.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert out.stderr.count("there is no CPU fallback") == 2, out.stderr[-2000:]
+    assert "rank exit codes" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    # a launcher's world size that disagrees with --gpus is refused by the rank itself
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="4", RANK="0"),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "must agree" in out.stderr
