@@ -360,7 +360,8 @@ class _WorldLoop:
     def _store(self, view):
         t0 = time.perf_counter()
         for k, v in view.items():
-            self.np.copyto(self.world[k], v)  # the decode into the World's stores: one memcpy per array here
+            # the decode into the World's stores: one memcpy per array here (as bytes: numpy copies structured records field by field)
+            self.np.copyto(self.world[k].view(self.np.uint8), v.view(self.np.uint8))
         self.host_s["store"] += time.perf_counter() - t0
 
     def _wait(self, ticket):
@@ -383,7 +384,7 @@ class _WorldLoop:
             self._store(d)
             return
         stg = eng.state_push_begin(A.STATE_INTENTS)
-        self.np.copyto(stg["intents"], self.intents)
+        self.np.copyto(stg["intents"].view(self.np.uint8), self.intents.view(self.np.uint8))
         eng.state_push_commit()
         t1 = time.perf_counter()
         eng.tick(stages=stages)

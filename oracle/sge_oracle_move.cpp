@@ -689,6 +689,14 @@ static V3 platformCarryDelta(V3 position, const sge_controller_params& P, const 
     return V3{0, 0, 0};
 }
 
+// VelocityGate.apply :1037-1051
+static V3 velocityGate(D3& velocity, bool wasGrounded, bool wasGroundedNear, float dt) {
+    if (wasGrounded && wasGroundedNear && velocity.y < 0) velocity.y = 0;
+    D3 remD = velocity * (double)dt;
+    if (wasGrounded && wasGroundedNear && remD.y < 0) remD.y = 0;
+    return f3(remD);
+}
+
 // KinematicMoveStopSystem.fixedUpdate :1823-1902
 void kinematic_move_fixed_update(World& w, int first, int count, float dt, V3 gravity,
                                  const std::vector<AgentSweepState>* agentsPtr, int selfOffset) {
@@ -711,11 +719,7 @@ void kinematic_move_fixed_update(World& w, int first, int count, float dt, V3 gr
         }
         bool wasGrounded = (C.flags & SGE_CTRL_GROUNDED) != 0;
         bool wasGroundedNear = (C.flags & SGE_CTRL_GROUNDED_NEAR) != 0;
-        // VelocityGate.apply :1037-1051
-        if (wasGrounded && wasGroundedNear && velocity.y < 0) velocity.y = 0;
-        D3 remD = velocity * (double)dt;
-        if (wasGrounded && wasGroundedNear && remD.y < 0) remD.y = 0;
-        V3 remaining = f3(remD);
+        V3 remaining = velocityGate(velocity, wasGrounded, wasGroundedNear, dt);
         // applyPreSweepDepenetration :1635-1656
         V3 depenNormal;
         if (depenetrationResolve(position, velocity, P, C, query, depenNormal, w.sideContactCacheOnly)) {
@@ -911,3 +915,82 @@ void agent_separation_fixed_update(World& w, int iterations, float separationMar
 }
 
 } // namespace sgeo
+
+// ---- probes: the pieces of the move system the tick only reaches through a whole step, callable one at a time ---------------
+// (tests/test_independent_pins.py checks each against an independent float64 answer; same functions the tick runs, no copies)
+extern "C" {
+
+// capsuleCapsuleSweep (Systems.swift:1505-1590) for `n` independent pairs: in[i] = from[3], delta[3], radius, halfHeight,
+// otherPos[3], otherDelta[3], otherRadius, otherHalfHeight (16 floats); out[i] = hit (0/1), toi, normal[3] (5 floats)
+int sgeo_probe_capsule_capsule_sweep(const float* in, int32_t n, float* out) {
+    using namespace sgeo;
+    for (int i = 0; i < n; ++i) {
+        const float* p = in + (size_t)i * 16;
+        CapsuleCapsuleHit h{0, V3{0, 0, 0}, 0};
+        const bool hit = capsuleCapsuleSweep(ld3(p), ld3(p + 3), p[6], p[7], 1, ld3(p + 8), ld3(p + 11), p[14], p[15], h);
+        float* o = out + (size_t)i * 5;
+        o[0] = hit ? 1.0f : 0.0f; o[1] = hit ? h.toi : 0.0f; o[2] = h.normal.x; o[3] = h.normal.y; o[4] = h.normal.z;
+    }
+    return SGE_OK;
+}
+
+// AgentSweepSolver.bestHit (Systems.swift:1053-1091) over a snapshot of `count` agents (entity = index); self = `selfEntity`.
+// out = hit, toi, normal[3], other (6 floats)
+int sgeo_probe_agent_best_hit(const float position[3], const float remaining[3], float remainingLen, float baseMoveLen, float dt,
+                              int32_t selfEntity, int32_t selfSolid, float selfRadius, float halfHeight,
+                              const sge_agent_state* agents, int32_t count, float* out) {
+    using namespace sgeo;
+    std::vector<AgentSweepState> list;
+    for (int i = 0; i < count; ++i)
+        if (agents[i].radius >= 0) list.push_back(AgentSweepState{i, ld3(agents[i].position), ld3(agents[i].velocity), agents[i].radius, agents[i].halfHeight});
+    CapsuleCapsuleHit best{0, V3{0, 0, 0}, -1};
+    const bool hit = agentBestHit(ld3(position), ld3(remaining), remainingLen, baseMoveLen, dt, selfEntity, selfSolid != 0, selfRadius, halfHeight, list, best);
+    out[0] = hit ? 1.0f : 0.0f; out[1] = hit ? best.toi : 0.0f; out[2] = best.normal.x; out[3] = best.normal.y; out[4] = best.normal.z;
+    out[5] = hit ? (float)best.other : -1.0f;
+    return SGE_OK;
+}
+
+// VelocityGate.apply (Systems.swift:1037-1051): velocity in/out (double[3]), remaining out (float[3])
+int sgeo_probe_velocity_gate(double velocity[3], int32_t wasGrounded, int32_t wasGroundedNear, float dt, float remaining[3]) {
+    using namespace sgeo;
+    D3 v = ldd3(velocity);
+    st3(remaining, velocityGate(v, wasGrounded != 0, wasGroundedNear != 0, dt));
+    std3(velocity, v);
+    return SGE_OK;
+}
+
+// GroundSnap.apply (Systems.swift:945-963): position / velocity in/out; the probe result as canSnap, hasHit, nearGround, hit.toi, hit.normal
+int sgeo_probe_ground_snap(float position[3], double velocity[3], float groundSnapSkin, float groundSnapMaxStep, int32_t canSnap,
+                           int32_t hasHit, int32_t nearGround, float toi, const float normal[3]) {
+    using namespace sgeo;
+    sge_controller_params P{};
+    P.groundSnapSkin = groundSnapSkin; P.groundSnapMaxStep = groundSnapMaxStep;
+    GroundProbeResult R{};
+    R.canSnap = canSnap != 0; R.hasHit = hasHit != 0; R.nearGround = nearGround != 0;
+    R.hit.toi = toi; R.hit.normal = ld3(normal);
+    V3 pos = ld3(position);
+    D3 vel = ldd3(velocity);
+    groundSnap(pos, vel, P, R);
+    st3(position, pos);
+    std3(velocity, vel);
+    return SGE_OK;
+}
+
+// SlopeFriction.apply (Systems.swift:965-1021): velocity in/out, the controller's groundSliding flag and groundTransitionFrames in/out
+int sgeo_probe_slope_friction(double velocity[3], int32_t* groundSliding, int32_t* groundTransitionFrames, const float gravity[3], float dt,
+                              int32_t grounded, const float normal[3], float muS, float muK) {
+    using namespace sgeo;
+    sge_controller_state C{};
+    C.flags = *groundSliding ? (uint32_t)SGE_CTRL_GROUND_SLIDING : 0u;
+    C.groundTransitionFrames = *groundTransitionFrames;
+    GroundContactState st{};
+    st.grounded = grounded != 0; st.normal = ld3(normal); st.material = sge_surface_material{muS, muK, 0};
+    D3 vel = ldd3(velocity);
+    slopeFriction(vel, C, ld3(gravity), dt, st);
+    std3(velocity, vel);
+    *groundSliding = (C.flags & SGE_CTRL_GROUND_SLIDING) ? 1 : 0;
+    *groundTransitionFrames = C.groundTransitionFrames;
+    return SGE_OK;
+}
+
+} // extern "C"

@@ -56,6 +56,16 @@ def load_oracle():
         lib.sgeo_skinning_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(abi.SkinningJob), C.c_int32]
         lib.sgeo_skinned_upload.restype = C.c_int
         lib.sgeo_skinned_upload.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        # probes of single pieces of the move system (tests/test_independent_pins.py)
+        VP = C.c_void_p
+        for name, args in (("capsule_capsule_sweep", [VP, C.c_int32, VP]),
+                           ("agent_best_hit", [VP, VP, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_float, C.c_float, VP, C.c_int32, VP]),
+                           ("velocity_gate", [VP, C.c_int32, C.c_int32, C.c_float, VP]),
+                           ("ground_snap", [VP, VP, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_float, VP]),
+                           ("slope_friction", [VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32), VP, C.c_float, C.c_int32, VP, C.c_float, C.c_float])):
+            fn = getattr(lib, "sgeo_probe_" + name)
+            fn.restype = C.c_int
+            fn.argtypes = args
         _lib = lib
     return _lib
 

@@ -148,7 +148,7 @@ def test_skinning_kernel_vs_oracle(sge, engines):
     gp, gn, gt = gpu.skinned()
     cp, cn, ct = cpu.skinned()
     assert gp.shape[0] == n * gpu.vertex_count
-    assert_close(gp, cp, "gp vs cp")
+    assert_close(gp, cp, "skinned positions vs oracle", group=3 * gpu.vertex_count)
     assert np.abs(gn - cn).max() <= 2e-6 and np.abs(gt - ct).max() <= 2e-6
     assert np.allclose(np.linalg.norm(gn, axis=1), 1, atol=1e-5)
     # padded (Metal float3 stride) layout gives the same numbers
@@ -198,7 +198,7 @@ def test_full_tick_parity(sge, engines, mixed):
     assert (g["locomotion"]["state"] != 0).any()
     gp, gn, gt = gpu.skinned()
     cp, cn, ct = cpu.skinned()
-    assert_close(gp, cp, "gp vs cp")
+    assert_close(gp, cp, "skinned positions vs oracle", group=3 * gpu.vertex_count)
     assert gpu.move_stats().overflow == 0
 
 
@@ -386,7 +386,7 @@ def test_real_assets_full_tick_parity(sge):
     ob.tick_mt(cpu, 8, dt=0.0, stages=sge.abi.STAGE_SKIN)
     gp, gn, gt = gpu.skinned()
     cp, cn, ct = cpu.skinned()
-    assert_close(gp, cp, "gp vs cp")
+    assert_close(gp, cp, "skinned positions vs oracle", group=3 * gpu.vertex_count)
     assert np.abs(gn - cn).max() <= 2e-5 and np.abs(gt - ct).max() <= 2e-5
     gpu.close()
     cpu.close()
@@ -781,7 +781,7 @@ def test_full_size_properties(sge):
     assert np.array_equal(d1["locomotion"]["state"][pick], c["locomotion"]["state"])
     gp = gpu.skinned(int(pick[5]) * V, V)[0]
     cp = cpu.skinned(5 * V, V)[0]
-    assert_close(gp, cp, "gp vs cp")
+    assert_close(gp, cp, "skinned positions vs oracle", group=3 * gpu.vertex_count)
     gpu.close()
     cpu.close()
 
@@ -809,7 +809,7 @@ def test_config_lbs_only_parity(sge, engines):
             compare_states(sge, gpu, cpu, n)
             gp, gn, gt = gpu.skinned()
             cp, cn, ct = cpu.skinned()
-            assert_close(gp, cp, "gp vs cp")
+            assert_close(gp, cp, "skinned positions vs oracle", group=3 * gpu.vertex_count)
             assert np.abs(gn - cn).max() <= 2e-5 and np.abs(gt - ct).max() <= 2e-5
     # no collision stage ran: bodies are untouched, the pose moved
     assert_struct_equal(gpu.download(what=("bodies",))["bodies"], before, "bodies")
@@ -859,7 +859,7 @@ def test_config_lbs_only_full_size(sge):
         cpu.tick(stages=stages)
     gpal = np.stack([gpu.palettes(int(i), 1)[0][0] for i in pick])
     cpal, _, _ = cpu.palettes()
-    assert_close(gpal, cpal, "gpal vs cpal")
+    assert_close(gpal, cpal, "palettes vs oracle", group=gpal.shape[-2] * 16)
     for k in (0, 17, 47):
         gp = gpu.skinned(int(pick[k]) * V, V)[0]
         cp = cpu.skinned(k * V, V)[0]
@@ -884,7 +884,7 @@ def test_overlap_mode_parity(sge):
             compare_states(sge, gpu, cpu, n)      # downloads join both streams
             gp, gn, gt = gpu.skinned()
             cp, cn, ct = cpu.skinned()
-            assert_close(gp, cp, "gp vs cp")
+            assert_close(gp, cp, "skinned positions vs oracle", group=3 * gpu.vertex_count)
             assert np.abs(gn - cn).max() <= 2e-5 and np.abs(gt - ct).max() <= 2e-5
     # stage subsets and the non-overlapped path mid-run
     gpu.tick(stages=sge.abi.STAGE_ALL & ~sge.abi.STAGE_SKIN)
@@ -894,7 +894,7 @@ def test_overlap_mode_parity(sge):
         gpu.tick()
         ob.tick_mt(cpu, 8)
     compare_states(sge, gpu, cpu, n)
-    assert_close(gpu.skinned()[0], cpu.skinned()[0], "skinned positions")
+    assert_close(gpu.skinned()[0], cpu.skinned()[0], "skinned positions", group=3 * gpu.vertex_count)
     assert gpu.move_stats().overflow == 0
     gpu.close()
     cpu.close()
@@ -1107,7 +1107,7 @@ def test_bench_default_full_size(sge):
     assert_struct_equal(out["bodies"][pick], c["bodies"], "bodies(subset vs oracle)")
     assert_struct_equal(out["controllers"][pick], c["controllers"], "controllers(subset vs oracle)")
     cpal = cpu.palettes(0, len(pick))[0]
-    assert_close(pal, cpal, "pal vs cpal")
+    assert_close(pal, cpal, "palettes vs oracle", group=pal.shape[-2] * 16)
     for j, cidx in ((0, int(pick[0])), (len(pick) // 2, int(pick[len(pick) // 2])), (len(pick) - 1, int(pick[-1]))):
         cp, cn, ct = cpu.skinned(first_vertex=j * V, vertex_count=V)
         gp, gn, gt = skinned[cidx]

@@ -11,6 +11,8 @@ that share NO code, precision or algorithm with it:
   (c) step-level invariants of the move-and-slide on the engine's own scene (no deep penetration left behind, grounded characters
       have ground under them).
 All CPU, a few seconds each."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -373,3 +375,286 @@ def test_capsule_triangle_distance_matches_the_float64_method_through_overlap_qu
             assert abs(np.hypot(axis_dist, dy) - d64[i]) <= 5e-5 + 2e-5 * abs(d64[i])
     assert pierced > 50 and worst < 1e-4
 
+
+
+# ---- (d) capsule-capsule sweep and the agent solver (C22) ---------------------------------------------------------------------
+# Independent route: the distance between two vertical capsule axes is a convex function of time when one moves linearly relative
+# to the other (distance from a moving point to a convex set), so first contact = left end of the interval {t : d(t) <= rSum}.
+# float64, golden-section search for the minimum of d over [0, 1], then bisection for the crossing. No quadratics, no case split
+# into caps and cylinder, no intervals — everything capsuleCapsuleSweep (Systems.swift:1505-1590) is made of.
+def _axis_distance_f64(rel, h_sum):
+    """distance between the two vertical axes given the relative centre offset rel [..., 3]"""
+    sep_y = np.sign(rel[..., 1]) * np.maximum(np.abs(rel[..., 1]) - h_sum, 0.0)
+    return np.sqrt(rel[..., 0] ** 2 + rel[..., 2] ** 2 + sep_y ** 2)
+
+
+def _capsule_pair_first_contact_f64(rel0, rel_delta, r_sum, h_sum):
+    """-> (hit, t in [0, 1], min distance over the sweep), vectorised over pairs"""
+    n = rel0.shape[0]
+    d = lambda t: _axis_distance_f64(rel0 + rel_delta * t[:, None], h_sum)
+    lo, hi = np.zeros(n), np.ones(n)
+    g = (np.sqrt(5.0) - 1) / 2
+    for _ in range(90):                                     # golden section: d is convex on [0, 1]
+        a, b = hi - g * (hi - lo), lo + g * (hi - lo)
+        left = d(a) <= d(b)
+        hi = np.where(left, b, hi)
+        lo = np.where(left, lo, a)
+    t_min = 0.5 * (lo + hi)
+    d_min = np.minimum(np.minimum(d(t_min), d(np.zeros(n))), d(np.ones(n)))
+    hit = d_min <= r_sum
+    lo, hi = np.zeros(n), t_min.copy()                      # d(0) > rSum >= d(t_min): one crossing in between
+    start_inside = d(np.zeros(n)) <= r_sum
+    for _ in range(80):
+        mid = 0.5 * (lo + hi)
+        inside = d(mid) <= r_sum
+        hi = np.where(inside, mid, hi)
+        lo = np.where(inside, lo, mid)
+    return hit, np.where(start_inside, 0.0, hi), d_min
+
+
+def _sweep_cases(rng, n):
+    """random vertical-capsule pairs: general, cap against cap, cap against cylinder, already overlapping, (nearly) parallel motion,
+    vertical-only motion, resting relative motion"""
+    r, h = rng.uniform(0.3, 2.0, (n, 2)), rng.uniform(0.2, 2.0, (n, 2))
+    r_sum, h_sum = r.sum(1), h.sum(1)
+    kind = rng.integers(0, 7, n)
+    ang = rng.uniform(0, 2 * np.pi, n)
+    dist = rng.uniform(0.2, 3.0, n) * r_sum
+    rel0 = np.stack([np.cos(ang) * dist, rng.uniform(-1.5, 1.5, n) * (h_sum + r_sum), np.sin(ang) * dist], 1)
+    aim = -rel0 + rng.normal(0, 0.6, (n, 3)) * r_sum[:, None]               # towards the other capsule, with scatter
+    rel_delta = aim * rng.uniform(0.2, 1.6, n)[:, None]
+    cap = kind == 1                                                            # end cap against end cap: one above the other
+    rel0[cap, 1] = (h_sum[cap] + rng.uniform(0.2, 2.5, cap.sum()) * r_sum[cap]) * rng.choice([-1, 1], cap.sum())
+    rel0[cap, 0] *= 0.3; rel0[cap, 2] *= 0.3
+    rel_delta[cap] = -rel0[cap] * rng.uniform(0.3, 1.5, cap.sum())[:, None] + rng.normal(0, 0.2, (cap.sum(), 3))
+    cyl = kind == 2                                                            # side by side: cylinder against cylinder
+    rel0[cyl, 1] = rng.uniform(-0.9, 0.9, cyl.sum()) * h_sum[cyl]
+    rel_delta[cyl, 1] *= 0.05
+    ov = kind == 3                                                             # overlapping at the start
+    rel0[ov] *= rng.uniform(0.0, 0.3, ov.sum())[:, None]
+    par = kind == 4                                                            # both move alike: relative motion (nearly) zero
+    vert = kind == 5                                                           # relative motion along Y only
+    rel_delta[vert, 0] = 0; rel_delta[vert, 2] = 0
+    flat = kind == 6                                                           # no vertical relative motion at all (|vy| < eps branch)
+    rel_delta[flat, 1] = 0
+    other_delta = rng.normal(0, 0.5, (n, 3))
+    delta = rel_delta + other_delta
+    delta[par] = other_delta[par] + rng.normal(0, 1e-8, (par.sum(), 3))
+    other_pos = rng.uniform(-20, 20, (n, 3))
+    packed = np.zeros((n, 16), np.float32)
+    packed[:, 0:3] = other_pos + rel0
+    packed[:, 3:6] = delta
+    packed[:, 6], packed[:, 7] = r[:, 0], h[:, 0]
+    packed[:, 8:11] = other_pos
+    packed[:, 11:14] = other_delta
+    packed[:, 14], packed[:, 15] = r[:, 1], h[:, 1]
+    return packed, kind
+
+
+def test_capsule_capsule_sweep_matches_a_float64_first_contact_search():
+    """C22, capsuleCapsuleSweep (Systems.swift:1417-1590): 6,000 random pairs of every kind against the convex-distance search."""
+    lib = ob.load_oracle()
+    rng = np.random.default_rng(2210)
+    packed, kind = _sweep_cases(rng, 6000)
+    out = np.zeros((packed.shape[0], 5), np.float32)
+    assert lib.sgeo_probe_capsule_capsule_sweep(packed.ctypes.data, packed.shape[0], out.ctypes.data) == 0
+    p = packed.astype(np.float64)                         # the float32 inputs, exactly, in float64
+    rel0, rel_delta = p[:, 0:3] - p[:, 8:11], p[:, 3:6] - p[:, 11:14]
+    r_sum, h_sum = p[:, 6] + p[:, 14], p[:, 7] + p[:, 15]
+    move_len = np.linalg.norm(p[:, 3:6], axis=1)
+    hit, t, d_min = _capsule_pair_first_contact_f64(rel0, rel_delta, r_sum, h_sum)
+    resting = np.linalg.norm(rel_delta, axis=1) < 1e-6    # the reference tests overlap at the start only (:1517-1523)
+    hit = np.where(resting, _axis_distance_f64(rel0, h_sum) <= r_sum, hit)
+    t = np.where(resting, 0.0, t)
+    # pairs that graze (closest approach within 1e-4 of touching) may fall either way in float32: leave them out, count them
+    clear = np.abs(d_min - r_sum) > 1e-4 * r_sum
+    assert clear.mean() > 0.97
+    got_hit = out[:, 0] > 0.5
+    assert np.array_equal(got_hit[clear], hit[clear]), np.argwhere(got_hit[clear] != hit[clear])[:5]
+    both = clear & hit
+    assert both.sum() > 2500 and (~hit & clear).sum() > 500 and all((both & (kind == k)).sum() > 100 for k in (0, 1, 2, 3, 5, 6))
+    toi = t * move_len
+    err = np.abs(out[both, 1] - toi[both])
+    # float32 quadratics: the crossing time is conditioned by how steeply the distance falls there; 2e-4 of the path length covers it
+    assert err.max() <= 2e-4 * np.maximum(move_len[both], 1.0).max(), (err.max(), np.argmax(err))
+    assert np.median(err) < 2e-6
+    # normal = the separation direction at the time of contact (:1484-1497): upward parts only where a cap touches
+    rel_hit = rel0 + rel_delta * t[:, None]
+    sep = rel_hit.copy()
+    sep[:, 1] = np.sign(rel_hit[:, 1]) * np.maximum(np.abs(rel_hit[:, 1]) - h_sum, 0.0)
+    ln = np.linalg.norm(sep, axis=1)
+    solid = both & (ln > 1e-3) & (kind != 3)              # (overlapping starts with coincident axes take the fallback normals)
+    want = sep[solid] / ln[solid, None]
+    assert np.abs(out[solid, 2:5] - want).max() < 2e-3
+    assert np.abs(np.linalg.norm(out[got_hit, 2:5], axis=1) - 1).max() < 1e-5
+    # known answers: two equal capsules (r 1.5, hh 1) 10 apart on X, one moves 8 towards the other: touches after 7
+    ka = np.zeros((4, 16), np.float32)
+    ka[:, 6], ka[:, 7], ka[:, 14], ka[:, 15] = 1.5, 1.0, 1.5, 1.0
+    ka[0, 0:3], ka[0, 3:6] = (-10, 0, 0), (8, 0, 0)                         # head on: toi 7, normal -x
+    ka[1, 0:3], ka[1, 3:6] = (-10, 0, 0), (6.9, 0, 0)                       # stops short: nil
+    ka[2, 0:3], ka[2, 3:6] = (0, 10, 0), (0, -8, 0)                         # drops on top: caps touch after 10 - 2 - 3 = 5, normal +y
+    ka[3, 0:3], ka[3, 3:6], ka[3, 11:14] = (-10, 0, 0), (4, 0, 0), (-4, 0, 0)  # both approach: relative 8, touch at t = 7/8 -> toi 3.5
+    ko = np.zeros((4, 5), np.float32)
+    lib.sgeo_probe_capsule_capsule_sweep(ka.ctypes.data, 4, ko.ctypes.data)
+    assert ko[:, 0].tolist() == [1, 0, 1, 1]
+    assert abs(ko[0, 1] - 7.0) < 1e-5 and np.allclose(ko[0, 2:5], (-1, 0, 0), atol=1e-6)
+    assert abs(ko[2, 1] - 5.0) < 1e-5 and np.allclose(ko[2, 2:5], (0, 1, 0), atol=1e-6)
+    assert abs(ko[3, 1] - 3.5) < 1e-5
+
+
+def test_agent_best_hit_matches_the_float64_search_over_the_snapshot(sge):
+    """AgentSweepSolver.bestHit (Systems.swift:1053-1091): earliest hit over a snapshot of 40 agents, the others advanced by
+    velocity * dt * min(remainingLen / baseMoveLen, 1); self skipped; non-solid self never hits. 300 snapshots."""
+    lib = ob.load_oracle()
+    rng = np.random.default_rng(1053)
+    A = sge.abi
+    checked = 0
+    for trial in range(300):
+        m = 40
+        agents = np.zeros(m, A.agent_dtype)
+        agents["position"] = rng.uniform(-12, 12, (m, 3)) * np.array([1, 0.15, 1])
+        agents["velocity"] = rng.normal(0, 4, (m, 3)) * np.array([1, 0.2, 1])
+        agents["radius"] = rng.uniform(0.5, 1.6, m)
+        agents["halfHeight"] = rng.uniform(0.5, 1.2, m)
+        agents["radius"][rng.integers(0, m, 3)] = -1.0                      # not solid / no agent component: not in the snapshot
+        me = int(rng.integers(0, m))
+        if agents["radius"][me] < 0:
+            continue
+        dt = np.float32(1 / 60)
+        base = rng.uniform(0.05, 0.4)
+        remaining = rng.normal(0, 1, 3) * np.array([1, 0.1, 1])
+        remaining = (remaining / np.linalg.norm(remaining) * base * rng.uniform(0.2, 1.0)).astype(np.float32)
+        rem_len = float(np.linalg.norm(remaining.astype(np.float64)))
+        pos = agents["position"][me].copy()
+        out = np.zeros(6, np.float32)
+        lib.sgeo_probe_agent_best_hit(pos.ctypes.data, remaining.ctypes.data, C.c_float(rem_len), C.c_float(base), C.c_float(dt), me, 1,
+                                      C.c_float(agents["radius"][me]), C.c_float(agents["halfHeight"][me]), agents.ctypes.data, m, out.ctypes.data)
+        scale = min(np.float32(rem_len) / np.float32(base), np.float32(1.0))
+        others = [j for j in range(m) if j != me and agents["radius"][j] >= 0]
+        o = agents[others]
+        rel0 = pos.astype(np.float64)[None] - o["position"].astype(np.float64)
+        rel_delta = remaining.astype(np.float64)[None] - o["velocity"].astype(np.float64) * float(dt) * float(scale)
+        hit, t, d_min = _capsule_pair_first_contact_f64(rel0, rel_delta, o["radius"].astype(np.float64) + float(agents["radius"][me]),
+                                           o["halfHeight"].astype(np.float64) + float(agents["halfHeight"][me]))
+        toi = np.where(hit, t * rem_len, np.inf)
+        graze = np.abs(d_min - (o["radius"] + agents["radius"][me])) < 1e-4
+        if graze.any():
+            continue
+        checked += 1
+        if not hit.any():
+            assert out[0] == 0, trial
+            continue
+        best = int(np.argmin(toi))
+        assert out[0] == 1 and abs(out[1] - toi[best]) <= 2e-4, (trial, out, toi[best])
+        runner_up = np.partition(toi, 1)[1] if len(toi) > 1 else np.inf
+        if runner_up - toi[best] > 1e-3:
+            assert int(out[5]) == others[best], (trial, out[5], others[best])
+        # a non-solid self never hits (:1060)
+        lib.sgeo_probe_agent_best_hit(pos.ctypes.data, remaining.ctypes.data, C.c_float(rem_len), C.c_float(base), C.c_float(dt), me, 0,
+                                      C.c_float(agents["radius"][me]), C.c_float(agents["halfHeight"][me]), agents.ctypes.data, m, out.ctypes.data)
+        assert out[0] == 0
+    assert checked > 200
+
+
+# ---- (e) known-answer tables for the small stages (C12, C18, C19), derived by hand from the Swift text -----------------------
+def test_velocity_gate_known_answers():
+    """VelocityGate.apply (Systems.swift:1037-1051): only a character that was grounded AND near the ground loses its downward
+    velocity and the downward part of the step; remaining = Float3(velocity * Double(dt))."""
+    lib = ob.load_oracle()
+    dt = np.float32(1 / 60)
+    d = float(dt)
+    table = [  # grounded, near, v in -> v out, remaining
+        (0, 0, (1.0, -2.0, 3.0), (1.0, -2.0, 3.0), (1.0 * d, -2.0 * d, 3.0 * d)),      # airborne: untouched
+        (1, 0, (1.0, -2.0, 3.0), (1.0, -2.0, 3.0), (1.0 * d, -2.0 * d, 3.0 * d)),      # grounded but not near: untouched
+        (0, 1, (1.0, -2.0, 3.0), (1.0, -2.0, 3.0), (1.0 * d, -2.0 * d, 3.0 * d)),      # near but not grounded: untouched
+        (1, 1, (1.0, -2.0, 3.0), (1.0, 0.0, 3.0), (1.0 * d, 0.0, 3.0 * d)),            # standing: no sinking
+        (1, 1, (0.0, 5.0, 0.0), (0.0, 5.0, 0.0), (0.0, 5.0 * d, 0.0)),                 # a jump leaves the ground freely
+        (1, 1, (-7.25, -98.0 / 60, 0.5), (-7.25, 0.0, 0.5), (-7.25 * d, 0.0, 0.5 * d)),  # one step of gravity on a standing character
+    ]
+    for g, near, vin, vout, rem in table:
+        v = np.array(vin, np.float64)
+        r = np.zeros(3, np.float32)
+        assert lib.sgeo_probe_velocity_gate(v.ctypes.data, g, near, C.c_float(dt), r.ctypes.data) == 0
+        assert np.array_equal(v, np.array(vout)), (g, near, vin, v)
+        assert np.array_equal(r, np.array(rem, np.float64).astype(np.float32)), (g, near, vin, r)
+
+
+def test_ground_snap_known_answers():
+    """GroundSnap.apply (Systems.swift:945-963): down by max(toi - groundSnapSkin, 0), capped at groundSnapMaxStep only when the
+    probe said nearGround; the velocity loses its component INTO the hit normal; nothing without canSnap or without a hit."""
+    lib = ob.load_oracle()
+    skin, cap = np.float32(0.05), np.float32(0.1)
+    up = (0.0, 1.0, 0.0)
+    f = np.float32
+    table = [  # canSnap, hasHit, near, toi, normal, v in -> dy, v out
+        (0, 1, 1, 0.30, up, (1, -2, 0), 0.0, (1, -2, 0)),                               # the probe forbade it
+        (1, 0, 1, 0.30, up, (1, -2, 0), 0.0, (1, -2, 0)),                               # no centre hit
+        (1, 1, 1, 0.30, up, (1, -2, 0), -float(cap), (1, 0, 0)),                        # near: 0.25 wanted, 0.1 allowed per step
+        (1, 1, 0, 0.30, up, (1, -2, 0), -float(f(0.30) - skin), (1, 0, 0)),             # not near: the whole 0.25
+        (1, 1, 1, 0.12, up, (0, 3, 0), -float(f(0.12) - skin), (0, 3, 0)),              # under the cap; moving away: velocity kept
+        (1, 1, 1, 0.03, up, (0, -1, 0), 0.0, (0, 0, 0)),                                # inside the skin: stays, still stops sinking
+        (1, 1, 0, 0.55, (0.6, 0.8, 0.0), (0, -5, 0), -float(f(0.55) - skin), (2.4, -1.8, 0)),  # slope: v - n (v.n), v.n = -4
+    ]
+    for can, has, near, toi, n, vin, dy, vout in table:
+        pos = np.array([3.0, 7.0, -2.0], np.float32)
+        v = np.array(vin, np.float64)
+        nn = np.array(n, np.float32)
+        assert lib.sgeo_probe_ground_snap(pos.ctypes.data, v.ctypes.data, C.c_float(skin), C.c_float(cap), can, has, near, C.c_float(toi), nn.ctypes.data) == 0
+        assert pos[0] == 3.0 and pos[2] == -2.0
+        assert abs(float(pos[1]) - (7.0 + dy)) < 1e-6, (toi, near, pos)
+        assert np.allclose(v, vout, rtol=0, atol=1e-6), (toi, n, v)
+
+
+def test_slope_friction_hysteresis_known_answers():
+    """SlopeFriction.apply (Systems.swift:965-1021) on planes of 20, 35, 38 and 50 degrees under g = (0, -98, 0), muS 0.8, muK 0.6.
+    With n = (sin a, cos a, 0): |gTan| = 98 sin a, stick limit = muS * 98 cos a, so the slide starts above tan a = 1.05 muS = 0.84,
+    ends below tan a = 0.9 muS = 0.72 and keeps its state in between: 20 deg (0.36) and 35 deg (0.70) stick — 35 also ENDS a
+    slide —, 38 deg (0.78) keeps whatever state it had, 50 deg (1.19) slides. Sticking removes the downhill part of the
+    tangential velocity; sliding adds (98 sin a - muK 98 cos a) dt downhill."""
+    lib = ob.load_oracle()
+    g = np.array([0, -98.0, 0], np.float32)
+    dt = np.float32(1 / 60)
+    muS, muK = 0.8, 0.6
+
+    def run(deg, v, sliding, frames=0, grounded=1):
+        a = np.radians(deg)
+        n = np.array([np.sin(a), np.cos(a), 0], np.float32)
+        vel = np.array(v, np.float64)
+        s, f = C.c_int32(sliding), C.c_int32(frames)
+        assert lib.sgeo_probe_slope_friction(vel.ctypes.data, C.byref(s), C.byref(f), g.ctypes.data, C.c_float(dt), grounded, n.ctypes.data,
+                                             C.c_float(muS), C.c_float(muK)) == 0
+        return vel, s.value, f.value, a
+
+    def stuck(v, a):        # v minus the downhill part of its tangential component, if that part points downhill
+        n = np.array([np.sin(a), np.cos(a), 0]); down = np.array([np.cos(a), -np.sin(a), 0])
+        v = np.array(v, np.float64)
+        s = (v - n * v.dot(n)).dot(down)
+        return v - down * s if s > 0 else v
+
+    def slid(v, a):
+        down = np.array([np.cos(a), -np.sin(a), 0])
+        return np.array(v, np.float64) + down * max(98 * np.sin(a) - muK * 98 * np.cos(a), 0) * float(dt)
+
+    for deg, v, was, expect_state, rule in [
+        (20, (2, 0, 0.5), 0, 0, stuck), (20, (2, 0, 0.5), 1, 0, stuck),      # 20 deg: a slide ends, downhill creep removed
+        (20, (-2, 0, 0.5), 0, 0, stuck),                                      # walking uphill: nothing to remove
+        (35, (1, -0.5, 0), 0, 0, stuck), (35, (1, -0.5, 0), 1, 0, stuck),    # 35 deg: below the exit threshold
+        (38, (1, -0.5, 0), 0, 0, stuck), (38, (1, -0.5, 0), 1, 1, slid),     # 38 deg: inside the band, the state is kept
+        (50, (0, 0, 0), 0, 1, slid), (50, (3, -1, 2), 1, 1, slid),           # 50 deg: slides, from rest too
+    ]:
+        vel, s, f, a = run(deg, v, was)
+        assert s == expect_state, (deg, was, s)
+        assert np.allclose(vel, rule(v, a), rtol=0, atol=2e-5), (deg, was, vel, rule(v, a))
+    # flat ground (normal.y > 0.98): transition frames cleared, never sliding, velocity untouched
+    vel, s, f, _ = run(5, (4, -1, 0), 1, frames=2)
+    assert s == 0 and f == 0 and np.array_equal(vel, (4, -1, 0))
+    # the three frames after stepping onto a steeper triangle (:976-980): counted down, friction suspended
+    vel, s, f, _ = run(50, (4, -1, 0), 1, frames=3)
+    assert s == 0 and f == 2 and np.array_equal(vel, (4, -1, 0))
+    # airborne: the flag drops, nothing else
+    vel, s, f, _ = run(50, (4, -1, 0), 1, frames=3, grounded=0)
+    assert s == 0 and f == 3 and np.array_equal(vel, (4, -1, 0))
+    # a gentle slope whose tangential gravity is below slopeAccelEps 0.5 (98 sin a < 0.5, a < 0.29 deg) is flat anyway; and a slope
+    # just past 0.98 in normal.y (11.5 deg) sticks: |gTan| = 19.5 >> 0.5
+    vel, s, f, a = run(11.6, (1, 0, 0), 0)
+    assert s == 0 and np.allclose(vel, stuck((1, 0, 0), a), atol=2e-5) and vel[0] < 1.0
