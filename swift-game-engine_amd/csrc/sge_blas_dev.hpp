@@ -59,6 +59,29 @@ __device__ __forceinline__ void blasWalk(float* tab, int rows, const float* X, c
     __hip_atomic_fetch_max(t + 5 * rows, mxz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// The same walk over a tile kept in LDS as it lies in memory (xyz xyz ..., 12 bytes per vertex, the raw-granule refit kernel):
+// `tile` = LDS address of the tile's first vertex; the schedule's byte offsets (4 * local vertex id) times three.
+__device__ __forceinline__ void blasWalkAoS(float* tab, int rows, const char* tile, const BlasRound& R) {
+    const float inf = __builtin_inff();
+    float mnx = inf, mny = inf, mnz = inf, mxx = -inf, mxy = -inf, mxz = -inf;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i < R.len) { // wave-uniform
+            const uint32_t off = (i & 1) ? (R.w[i >> 1] >> 16) : (R.w[i >> 1] & 0xffffu);
+            const float* q = reinterpret_cast<const float*>(tile + off * 3u);
+            const float x = q[0], y = q[1], z = q[2];
+            SGE_BLAS_FOLD(x, y, z)
+        }
+    }
+    float* t = tab + R.cluster;
+    __hip_atomic_fetch_min(t, mnx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_min(t + rows, mny, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_min(t + 2 * rows, mnz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_max(t + 3 * rows, mxx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_max(t + 4 * rows, mxy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_max(t + 5 * rows, mxz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // End of a character, called by every thread of the workgroup: inner entries from their wide nodes, deepest level first, one
 // wavefront per wide node; the table goes out coalesced ([entries + 1][6]) and is re-initialised. Leaves a barrier pending:
 // the caller's next __syncthreads() orders the re-initialisation before the next character's folds.
