@@ -25,12 +25,23 @@
 #include <cstdlib>
 #include "sge_blas_dev.hpp"
 
+#ifndef SGE_BLAS_EXPERIMENT
+#define SGE_BLAS_EXPERIMENT 0
+#endif
+
 namespace sge {
+
+#if SGE_BLAS_EXPERIMENT == 4 // diagnostic build: shader-clock cycles of every phase of a step, summed per workgroup (wave 0's view)
+__device__ unsigned long long g_blasPhase[1024][8];
+#define SGE_PHASE(k) do { if (tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); phase[k] += now_ - stamp; stamp = now_; } } while (0)
+#else
+#define SGE_PHASE(k) do { } while (0)
+#endif
 
 constexpr int kWave = 64;
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// Persistent workgroups (two or three per CU, as the LDS allows), each taking characters blockIdx.x, blockIdx.x + gridDim.x, ... LDS: tab[c * rows + row]
+// Persistent workgroups (two or three per CU, as the LDS allows), each taking characters blockIdx.x, blockIdx.x + gridDim.x, ... LDS: tab[row * 6 + c]
 // (c = 0..2 minima, 3..5 maxima), one tile of positions as X[], Y[], Z[], and the tiles' round ranges. The work is one
 // flat sequence of (character, tile) steps. Per step: the workgroup's registers already hold the tile (its loads were
 // issued a step earlier and completed behind the previous step's work); they are written to LDS; every wavefront requests
@@ -53,7 +64,9 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, 
     // the next character of this workgroup, behind the round ranges (in the dynamic region: a static __shared__ variable would
     // move the region's base off its 16-byte alignment)
     int& sNextChar = trs[B.tileCount + 1];
+    int* topo = trs + B.tileCount + 2;
     blasTableInit(tab, rows, tid, kBlasRefitBlock);
+    blasTopoStage(B, topo, tid, kBlasRefitBlock);
     for (int i = tid; i <= B.tileCount; i += kBlasRefitBlock) trs[i] = B.tileRoundStart[i];
     __syncthreads();
     const int lane = tid & (kWave - 1), wave = tid / kWave;
@@ -82,20 +95,31 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, 
     // Characters after the first are handed out through a ticket counter (zeroed by the launcher), gridDim.x + ticket: with a
     // fixed stride the workgroups that get one character more than the rest (10,000 over 768: 14 against 13) are the tail of
     // the launch, and so is every workgroup that found its place on a CU late. The ticket is drawn at the start of a
-    // character and is needed in its last step, where the next character's first tile is requested.
+    // character and is needed in its last step, where the next character's first tile is requested: thread 0 keeps it in a
+    // register until then (written to LDS in the first step, the wait for the atomic's answer — behind the tile loads in flight,
+    // loads return in order — stood in front of every character's second barrier).
     int tile = c % n, done = 0, ticket = 0;
     fetchPos(c, tile);
+#if SGE_BLAS_EXPERIMENT == 4
+    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp = __builtin_readcyclecounter();
+#endif
     while (true) {
         const int nv = min(B.tileVerts, B.vertexCount - tile * B.tileVerts);
         if (done == 0 && tid == 0) ticket = atomicAdd(queue, 1);
         __syncthreads(); // the previous step's rounds have read X/Y/Z; a finished character's table has been re-initialised
+        SGE_PHASE(0); // barrier 1 (the other wavefronts' walks)
+#if SGE_BLAS_EXPERIMENT == 4
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SGE_PHASE(1); // the tile's loads
+#endif
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
             const int v = tid + k * kBlasRefitBlock;
             if (v < nv) { X[v] = px[k]; X[v + TILE] = py[k]; X[v + 2 * TILE] = pz[k]; }
         }
-        if (done == 0 && tid == 0) sNextChar = (int)gridDim.x + ticket; // read below in this character's last step, behind the barrier
+        if (done + 1 == n && tid == 0) sNextChar = (int)gridDim.x + ticket; // read below in this step, behind the barrier
         __syncthreads();
+        SGE_PHASE(2); // LDS write + barrier 2
         const int rEnd = trs[tile + 1];
         int r = trs[tile] + wave;
         BlasRound R;
@@ -104,14 +128,30 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, 
         const bool last = done + 1 == n;
         const int cNext = last ? __builtin_amdgcn_readfirstlane(sNextChar) : c;
         const int tileNext = last ? cNext % n : (tile + 1 == n ? 0 : tile + 1);
+#if SGE_BLAS_EXPERIMENT != 2 // (diagnostic builds, tools/build_variant.sh: 1 = no walk, 2 = no position loads after the first; results are wrong)
         fetchPos(min(cNext, chars - 1), tileNext); // unconditional (a branch here would make the waits below conservative); after the last step: unused
+#endif
+        SGE_PHASE(3); // issue: round words + next tile
+#if SGE_BLAS_EXPERIMENT == 4
+        if (r < rEnd) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kPerThread) : "memory"); }
+        SGE_PHASE(4); // the round words' latency
+#endif
+#if SGE_BLAS_EXPERIMENT != 1
         if (r < rEnd) blasWalk<TILE>(tab, rows, X, R); // wave-uniform
         for (r += kWaves; r < rEnd; r += kWaves) { // only when a tile has more rounds than the workgroup has wavefronts
             blasFetchRound(B, r, lastRound, lane, R);
             blasWalk<TILE>(tab, rows, X, R);
         }
+#else
+        if (r < rEnd && R.w[0] == 0xdeadbeefu) tab[0] = (float)R.cluster; // keeps the round's loads alive
+#endif
+        SGE_PHASE(5); // walk
         if (last) {
-            blasFinishCharacter(B, tab, rows, tid, kBlasRefitBlock, bounds + (size_t)c * rows * 6);
+            blasFinishCharacter(B, topo, tab, rows, tid, kBlasRefitBlock, bounds + (size_t)c * rows * 6);
+            SGE_PHASE(6); // end of character
+#if SGE_BLAS_EXPERIMENT == 4
+            if (cNext >= chars && tid == 0) { for (int k = 0; k < 8; ++k) g_blasPhase[blockIdx.x & 1023][k] += phase[k]; }
+#endif
             if (cNext >= chars) return;
             c = cNext;
             done = 0;
@@ -121,6 +161,16 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, 
         tile = tileNext;
     }
 }
+
+#if SGE_BLAS_EXPERIMENT == 4
+} // namespace sge
+extern "C" int sge_experiment_blas_phases(unsigned long long* out, int reset) { // [1024][8], diagnostic builds only
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sge::g_blasPhase), sizeof(sge::g_blasPhase)) != hipSuccess) return 1;
+    if (reset) { static unsigned long long zero[1024][8]; if (hipMemcpyToSymbol(HIP_SYMBOL(sge::g_blasPhase), zero, sizeof(zero)) != hipSuccess) return 1; }
+    return 0;
+}
+namespace sge {
+#endif
 
 // The packed layout again, loaded as it lies in memory: the tile is a run of 12 * nv contiguous bytes, fetched as 16-byte granules
 // (one global_load_dwordx4 per lane: a wavefront's instruction covers 1 KB of consecutive addresses, eight whole 128-byte lines;
@@ -139,9 +189,11 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_raw_kernel(DevBlas
     char* T = reinterpret_cast<char*>(lds) + (((size_t)rows * 24 + 15) & ~(size_t)15); // the granules of one tile, 16-byte aligned behind the table
     constexpr int kGranules = (TILE * 12 + 12 + 15) / 16;        // most granules a tile touches
     constexpr int kPerThread = (kGranules + kBlasRefitBlock - 1) / kBlasRefitBlock;
-    int* trs = reinterpret_cast<int*>(T + (size_t)kPerThread * kBlasRefitBlock * 16);
+    int* trs = reinterpret_cast<int*>(T + (size_t)kGranules * 16);
     int& sNextChar = trs[B.tileCount + 1];
+    int* topo = trs + B.tileCount + 2;
     blasTableInit(tab, rows, tid, kBlasRefitBlock);
+    blasTopoStage(B, topo, tid, kBlasRefitBlock);
     for (int i = tid; i <= B.tileCount; i += kBlasRefitBlock) trs[i] = B.tileRoundStart[i];
     __syncthreads();
     const int lane = tid & (kWave - 1), wave = tid / kWave;
@@ -167,14 +219,26 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_raw_kernel(DevBlas
     if (c >= chars) return;
     int tile = c % n, done = 0, ticket = 0;
     fetch(c, tile);
+#if SGE_BLAS_EXPERIMENT == 4
+    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp = __builtin_readcyclecounter();
+#endif
     while (true) {
         const int shift = (int)(tileByte(c, tile) & 15);
         if (done == 0 && tid == 0) ticket = atomicAdd(queue, 1);
         __syncthreads(); // the previous step's rounds have read the tile; a finished character's table has been re-initialised
+        SGE_PHASE(0);
+#if SGE_BLAS_EXPERIMENT == 4
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SGE_PHASE(1);
+#endif
 #pragma unroll
-        for (int k = 0; k < kPerThread; ++k) *reinterpret_cast<v4f*>(T + (size_t)(tid + k * kBlasRefitBlock) * 16) = g[k];
-        if (done == 0 && tid == 0) sNextChar = (int)gridDim.x + ticket;
+        for (int k = 0; k < kPerThread; ++k) {
+            const int q = tid + k * kBlasRefitBlock;
+            if (q < kGranules) *reinterpret_cast<v4f*>(T + (size_t)q * 16) = g[k]; // (granules past the tile's own hold the last one again: harmless)
+        }
+        if (done + 1 == n && tid == 0) sNextChar = (int)gridDim.x + ticket; // thread 0 has kept the ticket since the character's first step
         __syncthreads();
+        SGE_PHASE(2);
         const int rEnd = trs[tile + 1];
         int r = trs[tile] + wave;
         BlasRound R;
@@ -183,13 +247,23 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_raw_kernel(DevBlas
         const int cNext = last ? __builtin_amdgcn_readfirstlane(sNextChar) : c;
         const int tileNext = last ? cNext % n : (tile + 1 == n ? 0 : tile + 1);
         fetch(min(cNext, chars - 1), tileNext);
+        SGE_PHASE(3);
+#if SGE_BLAS_EXPERIMENT == 4
+        if (r < rEnd) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kPerThread) : "memory"); }
+        SGE_PHASE(4);
+#endif
         if (r < rEnd) blasWalkAoS(tab, rows, T + shift, R);
         for (r += kWaves; r < rEnd; r += kWaves) {
             blasFetchRound(B, r, lastRound, lane, R);
             blasWalkAoS(tab, rows, T + shift, R);
         }
+        SGE_PHASE(5);
         if (last) {
-            blasFinishCharacter(B, tab, rows, tid, kBlasRefitBlock, bounds + (size_t)c * rows * 6);
+            blasFinishCharacter(B, topo, tab, rows, tid, kBlasRefitBlock, bounds + (size_t)c * rows * 6);
+            SGE_PHASE(6);
+#if SGE_BLAS_EXPERIMENT == 4
+            if (cNext >= chars && tid == 0) { for (int k = 0; k < 8; ++k) g_blasPhase[blockIdx.x & 1023][k] += phase[k]; }
+#endif
             if (cNext >= chars) return;
             c = cNext;
             done = 0;
@@ -202,7 +276,7 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_raw_kernel(DevBlas
 // LDS of the raw-granule kernel: the box table padded to a multiple of 16 bytes, the granules of one tile, the round ranges
 template <int TILE>
 constexpr size_t blasRefitRawLdsBytes(int entryCount, int tileCount) {
-    return (((size_t)(entryCount + 1) * 24 + 15) & ~(size_t)15) + (size_t)(((TILE * 12 + 12 + 15) / 16 + kBlasRefitBlock - 1) / kBlasRefitBlock) * kBlasRefitBlock * 16 + (size_t)(tileCount + 2) * 4;
+    return (((size_t)(entryCount + 1) * 24 + 15) & ~(size_t)15) + (size_t)((TILE * 12 + 12 + 15) / 16) * 16 + (size_t)(tileCount + 2) * 4;
 }
 
 template <int TILE>
@@ -217,7 +291,7 @@ static int launchRefitTile(const DevBlas& B, const float* p, int layout, long lo
     static const int rawSetting = getenv("SGE_BLAS_RAW") ? atoi(getenv("SGE_BLAS_RAW")) : 1; // experiments: 0 = the per-component loads
     // the raw-granule form: packed positions, 16-byte aligned base, and no granule that reaches past the end of the buffer
     const long long endByte = (firstVertex + (long long)chars * B.vertexCount) * 12;
-    const size_t rawLds = blasRefitRawLdsBytes<TILE>(B.entryCount, B.tileCount) + 16;
+    const size_t rawLds = blasRefitRawLdsBytes<TILE>(B.entryCount, B.tileCount) + blasTopoBytes(B.wideCount, B.levels) + 16;
     if (rawSetting && layout == SGE_LAYOUT_PACKED && (reinterpret_cast<uintptr_t>(p) & 15) == 0 &&
         ((endByte & 15) == 0 || padBytes >= 16) && rawLds <= kBlasMaxLdsBytes + 4096) {
         static bool rawAttr[kMaxDevices] = {};
@@ -236,7 +310,7 @@ static int launchRefitTile(const DevBlas& B, const float* p, int layout, long lo
 int launch_blas_refit(const DevBlas& B, const void* positions, int layout, long long firstVertex, int chars, float* bounds, int* queue, hipStream_t s, int padBytes) {
     if (chars <= 0) return SGE_OK;
     SGE_HIP(hipMemsetAsync(queue, 0, sizeof(int), s));
-    const size_t lds = blasRefitLdsBytes(B.entryCount, B.tileCount, B.tileCap) + 16; // + the ticket slot
+    const size_t lds = blasRefitLdsBytes(B.entryCount, B.tileCount, B.tileCap) + blasTopoBytes(B.wideCount, B.levels) + 16; // + the ticket slot
     const int cus = currentDeviceCUs();
     // persistent: as many workgroups as stay resident together (LDS allows floor(160 KB / lds) per CU)
     const int perCU = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / (lds + 256)));

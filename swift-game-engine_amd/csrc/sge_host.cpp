@@ -411,10 +411,12 @@ bool HostBlas::build(const float* pos, int V, const uint32_t* idx, int indexCoun
         ++levels;
         level.swap(next);
     }
-    if (blasRefitLdsBytes(entryCount(), V / 512 + 2) > kBlasMaxLdsBytes) { err = "blas: mesh too large (more than ~250k triangles per character)"; return false; }
+    if (entryCount() >= (1 << 24)) { err = "blas: more than 2^24 entries"; return false; }
+    if (blasRefitLdsBytes(entryCount(), V / 512 + 2) + blasTopoBytes(wideCount(), levels) > kBlasMaxLdsBytes) { err = "blas: mesh too large (more than ~250k triangles per character)"; return false; }
     tileCap = kBlasTileVerts;
     for (int cap : kBlasTileSteps)
-        if (cap >= 2048 && 3 * (blasRefitLdsBytes(entryCount(), V / cap + 2, cap) + 256) <= (size_t)160 * 1024) { tileCap = cap; break; }
+        if (cap >= 2048 && 3 * (blasRefitLdsBytes(entryCount(), V / cap + 2, cap) + blasTopoBytes(wideCount(), levels) + 256) <= (size_t)160 * 1024) { tileCap = cap; break; }
+    if (const char* e = getenv("SGE_BLAS_TILE_CAP")) { const int v = atoi(e); if (v == 2048 || v == 3072 || v == 4096) tileCap = v; } // experiments
     tileCount = (V + tileCap - 1) / tileCap;
     tileVerts = ((V + tileCount - 1) / tileCount + 63) / 64 * 64;
     tileCount = (V + tileVerts - 1) / tileVerts;
@@ -478,7 +480,7 @@ bool HostBlas::build(const float* pos, int V, const uint32_t* idx, int indexCoun
             // 32 lanes of a half-wave read X[id] (bank = id mod 32, same for Y and Z) together; every lane takes, among the
             // vertices it has not read yet (all of them again once it ran out: padding), the one on the least loaded bank.
             std::vector<uint16_t> order[64];
-            for (int lane = 0; lane < 64; ++lane) roundCluster.push_back(chunks[r + lane < chunks.size() ? r + lane : r].cluster);
+            for (int lane = 0; lane < 64; ++lane) roundCluster.push_back(chunks[r + lane < chunks.size() ? r + lane : r].cluster | (len << 24));
             for (int half = 0; half < 2; ++half) {
                 std::vector<uint16_t> left[32];
                 for (int l = 0; l < 32; ++l) left[l] = chunks[r + half * 32 + l < chunks.size() ? r + half * 32 + l : r].ids;
@@ -534,7 +536,7 @@ bool HostBlas::build(const float* pos, int V, const uint32_t* idx, int indexCoun
             for (int lane = 0; lane < 64; ++lane)
                 for (int i = 0; i < 16; ++i) {
                     const uint32_t off = 4u * order[lane][i < len ? i : 0];
-                    roundIds[idBase + (size_t)(i >> 1) * 64 + lane] |= off << (16 * (i & 1));
+                    roundIds[idBase + (size_t)lane * 8 + (i >> 1)] |= off << (16 * (i & 1));
                 }
         }
         tileRoundStart.push_back((int)roundLen.size());

@@ -199,8 +199,9 @@ struct HostBlas {
     int tileVerts = 0, tileCount = 0, chunkCount = 0, tileCap = 4096;
     std::vector<int> tileRoundStart;     // [tileCount + 1]
     std::vector<int> roundLen;           // [roundCount] vertices per chunk in this round (1..16; shorter chunks repeat their first vertex)
-    std::vector<int> roundCluster;       // [roundCount][64] leaf entry of every lane's chunk (a short last round repeats its first chunk)
-    std::vector<uint32_t> roundIds;      // [roundCount][8][64]: word j of a lane = LDS byte offsets (4 * local vertex id) of its vertices 2j | 2j+1 << 16
+    std::vector<int> roundCluster;       // [roundCount][64] leaf entry of every lane's chunk (a short last round repeats its first chunk) | roundLen << 24
+    std::vector<uint32_t> roundIds;      // [roundCount][64][8]: word j of a lane = LDS byte offsets (4 * local vertex id) of its vertices 2j | 2j+1 << 16
+                                         // (a lane's eight words are contiguous: two 16-byte loads; entries past the round's length repeat the lane's first vertex)
     int entryCount() const { return (int)entryLink.size() / 2; }
     int wideCount() const { return (int)wideParentEntry.size(); }
     // false + message when the mesh cannot be handled
@@ -231,6 +232,10 @@ constexpr int kBlasTileVerts = 4096; // most vertices staged in LDS at a time (4
 constexpr int kBlasTileSteps[4] = {4096, 3072, 2048, 1024};
 // LDS of the refit kernel: the box table, six floats per row, (entryCount + 1) rows, + one tile of positions (SoA) + tileRoundStart
 inline size_t blasRefitLdsBytes(int entryCount, int tileCount, int tileCap = kBlasTileVerts) { return (size_t)(entryCount + 1) * 24 + (size_t)tileCap * 12 + (size_t)(tileCount + 1) * 4; }
+// + the shape of the wide tree, staged once per workgroup (wideLevelStart[levels + 1], wideFirst[wideCount + 1], wideParentEntry[wideCount]):
+// the end-of-character reduction reads it from LDS — a global load there queues behind the position loads already in flight for the
+// next tile (loads return in order) and took a third of the kernel
+inline size_t blasTopoBytes(int wideCount, int levels) { return (size_t)(levels + 2 * wideCount + 2) * 4 + 16; }
 constexpr size_t kBlasMaxLdsBytes = 144 * 1024; // of the CU's 160 KB
 
 // ---- kernel launchers ----------------------------------------------------- //

@@ -551,6 +551,8 @@ __global__ __launch_bounds__(kBlasRefitBlock) void skin_refit_kernel(SkinLaunch 
     // the ticket's slot lies behind the palette: a static __shared__ variable would shift the dynamic region to offset 4 and
     // with it every 16-byte palette read off its alignment (measured: the kernel takes twice as long)
     int& sNextChar = *reinterpret_cast<int*>(pal + L.paletteCount * 3);
+    int* topo = reinterpret_cast<int*>(pal + L.paletteCount * 3 + 1); // the wide tree's shape, behind the ticket's 16-byte slot
+    blasTopoStage(B, topo, tid, kBlasRefitBlock);                     // (made visible by the first tile's barrier)
 
     // Characters are handed out through a ticket counter (zeroed by the launcher): the first is blockIdx.x, every later one
     // gridDim.x + ticket. Beside the collision kernels of the next step (SGE_OPT_OVERLAP_SKIN) some workgroups find their
@@ -608,7 +610,7 @@ __global__ __launch_bounds__(kBlasRefitBlock) void skin_refit_kernel(SkinLaunch 
         }
         int ticket = 0;
         if (tid == 0) ticket = atomicAdd(queue, 1); // answered behind the reduction and the write-out below
-        blasFinishCharacter(B, tab, rows, tid, kBlasRefitBlock, bounds + (size_t)c * rows * 6);
+        blasFinishCharacter(B, topo, tab, rows, tid, kBlasRefitBlock, bounds + (size_t)c * rows * 6);
         // the next character's palette staging writes `pal` only after every wavefront has left the last walk (barriers inside
         // blasFinishCharacter), and the barrier below orders the table re-initialisation before any fold
         if (tid == 0) sNextChar = (int)gridDim.x + ticket;
@@ -652,7 +654,7 @@ static int launchSkinRefitTile(const SkinLaunch& L, const DevBlas& B, float* bou
 int launch_skin_refit(const SkinLaunch& L, const DevBlas& B, float* bounds, int* queue, hipStream_t s, int maxWorkgroupsPerCU) {
     if (L.chars <= 0 || L.vertexCount <= 0) return SGE_OK;
     SGE_HIP(hipMemsetAsync(queue, 0, sizeof(int), s));
-    const size_t lds = blasRefitLdsBytes(B.entryCount, B.tileCount, B.tileCap) + 16 + (size_t)L.paletteCount * 48 + 16; // + the ticket slot
+    const size_t lds = blasRefitLdsBytes(B.entryCount, B.tileCount, B.tileCap) + 16 + (size_t)L.paletteCount * 48 + 16 + blasTopoBytes(B.wideCount, B.levels); // + the ticket slot + the tree's shape
     int perCU = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / (lds + 256)));
     if (maxWorkgroupsPerCU > 0) perCU = std::min(perCU, maxWorkgroupsPerCU);
     switch (B.tileCap) {
