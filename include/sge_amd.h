@@ -611,7 +611,11 @@ enum {
     SGE_STAGE_AGENTS = 1u << 8,     /* capsule-capsule sweep vs the imported agent set, Systems.swift:1053-1091 */
     SGE_STAGE_BLAS_REFIT = 1u << 9, /* RTAccelerationBuilder dynamic-slice refit, RTAccelerationBuilder.swift:113-145 (not in SGE_STAGE_ALL) */
     SGE_STAGE_SEPARATION = 1u << 10, /* AgentSeparationSystem, Systems.swift:1906-2210: between the move stage and the locomotion stage,
-                                      * as in DemoScene.swift:66-68 (not in SGE_STAGE_ALL; whole crowd only: first = 0, count = all) */
+                                      * as in DemoScene.swift:66-68 (not in SGE_STAGE_ALL; whole crowd only: first = 0, count = all).
+                                      * With the crowd sharded over several contexts (configs[3] / [4]: sge_agents_import or
+                                      * sge_agents_allgather named agents of other contexts) the stage returns SGE_ERR_STATE: the
+                                      * pair loop is sequential over the whole crowd in index order, a shard cannot reproduce it and
+                                      * a halo exchange would define another result. Gather the crowd into one context for it. */
     SGE_STAGE_SIDE_CONTACT_CACHE = 1u << 11, /* modifier of SGE_STAGE_MOVE, not a stage: the system's contactCachePolicy
                                       * (KinematicMoveStopSystem.init(gravity:contactCachePolicy:), Systems.swift:1402-1415) is
                                       * SideContactOnlyCachePolicy (:1136-1157: the depenetration pass records only side contacts)

@@ -1609,6 +1609,13 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
     }
     if (st & SGE_STAGE_SEPARATION) { // AgentSeparationSystem: after the move stage, before the animation stages (DemoScene.swift:66-71)
         if (first != 0 || count != c->crowd.count) { set_error("SGE_STAGE_SEPARATION works on the whole crowd (first = 0, count = all)"); return SGE_ERR_INVALID; }
+        // The pair loop is sequential over the WHOLE crowd in index order (Systems.swift:1906-2210): a context that holds one shard of
+        // it (an imported snapshot that names agents of other contexts) cannot produce the reference's result, with or without a
+        // halo — refused, not approximated.
+        if (c->agents.all && (c->agents.selfOffset > 0 || c->agents.total > c->crowd.count)) {
+            set_error("SGE_STAGE_SEPARATION needs the whole crowd in one context: this one holds a shard (sge_agents_import / _allgather named agents of other contexts)");
+            return SGE_ERR_STATE;
+        }
         if (c->col.root < 0 && c->col.triCount != 0) { set_error("collision world not built"); return SGE_ERR_STATE; }
         int rc;
         const size_t sepAgents = (size_t)std::max(c->crowd.count, (int)SGE_MAX_SEPARATION_AGENTS);

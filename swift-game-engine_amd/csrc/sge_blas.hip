@@ -212,7 +212,11 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_raw_kernel(DevBlas
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
             const int q = min(tid + k * kBlasRefitBlock, granules - 1); // past the end: the last granule again (stored twice, same bytes), no branch
+#if defined(SGE_BLAS_PLAIN_LOADS) // diagnostic build: default cache policy
+            g[k] = *reinterpret_cast<const v4f*>(P0 + a0 + (long long)q * 16);
+#else
             g[k] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(P0 + a0 + (long long)q * 16)); // streamed once
+#endif
         }
     };
     int c = blockIdx.x;

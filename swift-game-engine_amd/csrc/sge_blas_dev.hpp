@@ -13,6 +13,27 @@ constexpr int kBlasWave = 64;
 __device__ __forceinline__ float blasWaveMin(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, kBlasWave)); return v; }
 __device__ __forceinline__ float blasWaveMax(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kBlasWave)); return v; }
 
+// Wave-wide min / max on the VALU's data-parallel path (DPP): two quad permutes, the two row mirrors, then lane 15 of every row of
+// 16 into the next row and lane 31 into the upper half — lane 63 ends up with the reduction of all 64. __shfl_xor goes through
+// ds_bpermute_b32, i.e. through the LDS unit, which the other workgroups' walks keep busy: six dependent rounds of it cost the
+// end-of-character reduction ~3,000 cycles per level (profiles/r4_refit_phases.txt).
+template <bool MIN>
+__device__ __forceinline__ float blasWaveReduce(float x) {
+#define SGE_DPP_STEP(ctrl, rows_)                                                                                              \
+    {                                                                                                                             \
+        const float y_ = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), ctrl, rows_, 0xf, false)); \
+        x = MIN ? fminf(x, y_) : fmaxf(x, y_);                                                                                    \
+    }
+    SGE_DPP_STEP(0xB1, 0xf)  // quad_perm [1,0,3,2]
+    SGE_DPP_STEP(0x4E, 0xf)  // quad_perm [2,3,0,1]
+    SGE_DPP_STEP(0x141, 0xf) // row_half_mirror
+    SGE_DPP_STEP(0x140, 0xf) // row_mirror: every lane of a row holds the row's result
+    SGE_DPP_STEP(0x142, 0xa) // row_bcast15 into rows 1 and 3
+    SGE_DPP_STEP(0x143, 0xc) // row_bcast31 into rows 2 and 3
+#undef SGE_DPP_STEP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
 // v_min_f32 / v_max_f32 as written (fminf() on a value loaded from LDS would first canonicalise it: one more instruction each)
 #define SGE_BLAS_FOLD(X_, Y_, Z_)                                              \
     asm("v_min_f32 %0, %0, %1" : "+v"(mnx) : "v"(X_)); asm("v_max_f32 %0, %0, %1" : "+v"(mxx) : "v"(X_)); \
@@ -119,14 +140,20 @@ __device__ __forceinline__ void blasWalkAoS(float* tab, int rows, const char* ti
 // Nothing here loads from global memory (`topo`: blasTopoStage): the position loads of the next tile are in flight at this point and
 // loads return in order, so every global load in this function used to wait for a whole tile from HBM. The six components of a wide
 // node are reduced side by side (six independent butterfly chains) rather than one after the other.
+#ifndef SGE_FINISH_STAMP
+#define SGE_FINISH_STAMP(k) do { } while (0)
+#define SGE_FINISH_STAMP_BEGIN() do { } while (0)
+#endif
 __device__ __forceinline__ void blasFinishCharacter(const DevBlas& B, const int* topo, float* tab, int rows, int tid, int threads, float* out) {
     const float inf = __builtin_inff();
+    SGE_FINISH_STAMP_BEGIN();
     const int lane = tid & (kBlasWave - 1), wave = tid / kBlasWave, waves = threads / kBlasWave;
     const int* levelStart = topo;
     const int* wideFirst = topo + B.levels + 1;
     const int* wideParent = wideFirst + B.wideCount + 1;
     for (int lvl = B.levels - 1; lvl >= 0; --lvl) {
         __syncthreads();
+        SGE_FINISH_STAMP(lvl == B.levels - 1 ? 0 : 2); // 0: the first barrier (the slowest wavefront's walk), 2: a later level's barrier
         for (int w = levelStart[lvl] + wave; w < levelStart[lvl + 1]; w += waves) {
             const int first = wideFirst[w], cnt = wideFirst[w + 1] - first;
             const int parent = wideParent[w];
@@ -134,25 +161,22 @@ __device__ __forceinline__ void blasFinishCharacter(const DevBlas& B, const int*
             float k[6];
 #pragma unroll
             for (int q = 0; q < 6; ++q) k[q] = lane < cnt ? tab[(first + lane) * 6 + q] : (q < 3 ? inf : -inf);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                float v[6];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) v[q] = __shfl_xor(k[q], o, kBlasWave);
-#pragma unroll
-                for (int q = 0; q < 6; ++q) k[q] = q < 3 ? fminf(k[q], v[q]) : fmaxf(k[q], v[q]);
-            }
+            k[0] = blasWaveReduce<true>(k[0]); k[1] = blasWaveReduce<true>(k[1]); k[2] = blasWaveReduce<true>(k[2]);
+            k[3] = blasWaveReduce<false>(k[3]); k[4] = blasWaveReduce<false>(k[4]); k[5] = blasWaveReduce<false>(k[5]);
             if (lane == 0) {
 #pragma unroll
                 for (int q = 0; q < 6; ++q) tab[dst * 6 + q] = k[q];
             }
         }
+        SGE_FINISH_STAMP(1); // a level's reductions
     }
     __syncthreads();
+    SGE_FINISH_STAMP(2);
     for (int i = tid; i < rows * 6; i += threads) { // every table element is read by exactly one thread, which re-initialises it
         out[i] = tab[i];
         tab[i] = (i % 6) < 3 ? inf : -inf;
     }
+    SGE_FINISH_STAMP(3); // write-out + re-initialisation
 }
 
 } // namespace sge

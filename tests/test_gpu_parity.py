@@ -1052,20 +1052,24 @@ def _strided_checksums(eng, n, V, stride=97):
     return sums
 
 
-def test_bench_default_full_size(sge):
-    """The combination bench.py times, as one test: SGE_OPT_OVERLAP_SKIN on, every stage including skin, 10,000 characters x 14,080
-    vertices on the 17-Cheese mesh (BASELINE.json configs[2]) — the two-stream, two-palette-buffer schedule at full size. Checked
-    against (1) an oracle run over a subset (random characters + the expensive ones at the rim): bodies / controllers bit-exact,
-    palettes and the skinned vertices of three subset characters <= 1e-5; (2) the same crowd stepped in serial order
-    (overlap off): every state array and the strided checksums of the three output streams identical."""
+@pytest.mark.parametrize("mesh", ["synthetic", "ybot"])
+def test_bench_default_full_size(sge, mesh):
+    """The combination bench.py times, as one test: SGE_OPT_OVERLAP_SKIN on, every stage including skin, 10,000 characters on the
+    17-Cheese mesh (BASELINE.json configs[2]) — the three-stream, two-palette-buffer schedule at full size — with the synthetic
+    14,080-vertex mesh of the headline and with the FBX-derived Y-Bot (35,440 welded vertices, the real weights and bone indices:
+    bench.py's `real_mesh` object; SURVEY 8d "value distributions"). Checked against (1) an oracle run over a subset (random
+    characters + the expensive ones at the rim): bodies / controllers bit-exact, palettes and the skinned vertices of three subset
+    characters <= 1e-5; (2) the same crowd stepped in serial order (overlap off): every state array and the strided checksums of
+    the three output streams identical."""
     abi = sge.abi
     ybot = sge.assets.YBotAssets()
     n, settle, steps = 10000, 40, 60
+    upload_mesh = sge.crowd.upload_ybot_mesh if mesh == "ybot" else sge.crowd.upload_character_assets
 
     def run(overlap):
         eng = sge.CharacterEngine(0)
         eng.set_option(abi.OPT_OVERLAP_SKIN, 1 if overlap else 0)
-        sge.crowd.upload_character_assets(eng, ybot)
+        upload_mesh(eng, ybot)
         scene = sge.crowd.upload_asset_scene(eng, ("cheese",))
         state0 = sge.crowd.spawn_crowd(eng, ybot, n, scene)
         for _ in range(settle + steps):
@@ -1075,7 +1079,7 @@ def test_bench_default_full_size(sge):
 
     gpu, state0 = run(True)
     V, B = gpu.vertex_count, gpu.bone_count
-    assert V == 14080
+    assert V == (35440 if mesh == "ybot" else 14080)
     out = gpu.download()
     assert gpu.move_stats().overflow == 0
     sums = _strided_checksums(gpu, n, V)
@@ -1097,7 +1101,7 @@ def test_bench_default_full_size(sge):
 
     # (1) oracle over the subset
     cpu = ob.oracle_engine()
-    sge.crowd.upload_character_assets(cpu, ybot)
+    upload_mesh(cpu, ybot)
     sge.crowd.upload_asset_scene(cpu, ("cheese",))
     cpu.resize(len(pick))
     cpu.upload(**{k: v[pick] for k, v in state0.items()})

@@ -128,6 +128,14 @@ def test_separation_stage_gpu_parity(sge):
     # capacity and range errors
     with pytest.raises(sge.SgeError):
         gpu.tick(stages=sge.abi.STAGE_SEPARATION, first=1, count=5)
+    # a context that holds one shard of the crowd (its snapshot names agents of other contexts) refuses the stage: the pair loop
+    # is sequential over the WHOLE crowd in index order, there is nothing a shard could compute that equals it
+    other = torch.zeros((2 * n, 8), dtype=torch.float32, device="cuda:0")
+    other[:, 3] = -1.0
+    torch.cuda.synchronize()
+    gpu.agents_import(other.data_ptr(), 2 * n, n)
+    with pytest.raises(sge.SgeError, match="whole crowd in one context"):
+        gpu.tick(stages=sge.abi.STAGE_SEPARATION)
     for e in (gpu, cpu, free):
         e.close()
 

@@ -20,7 +20,7 @@ st = abi.STAGE_LOCOMOTION | abi.STAGE_ACTION | abi.STAGE_POSE | abi.STAGE_WRITEB
 for _ in range(5):
     eng.tick(stages=st)
 eng.synchronize()
-out = np.zeros((1024, 8), np.uint64)
+out = np.zeros((1024, 12), np.uint64)
 fn = eng.t.lib.sge_experiment_blas_phases
 fn.argtypes = [C.c_void_p, C.c_int]
 assert fn(out.ctypes.data, 1) == 0
@@ -29,9 +29,11 @@ for _ in range(launches):
     eng.tick(stages=st)
 eng.synchronize()
 assert fn(out.ctypes.data, 0) == 0
-used = out[out.sum(1) > 0].astype(np.float64) / launches
+used = out[out[:, :8].sum(1) > 0].astype(np.float64) / launches
 names = ["barrier 1 (others' walks)", "wait for the tile's loads", "LDS write + barrier 2", "issue round words + next tile", "round words' latency", "walk", "end of character", "-"]
-tot = used.sum(1).mean()
+tot = used[:, :8].sum(1).mean()
 print("workgroups %d, cycles per workgroup per launch %.0f" % (len(used), tot))
 for k, nm in enumerate(names[:7]):
     print("  %-32s %9.0f cycles  %5.1f %%" % (nm, used[:, k].mean(), 100 * used[:, k].mean() / tot))
+for k, nm in enumerate(["first barrier (slowest walk)", "level reductions", "later barriers", "write-out + re-initialisation"]):
+    print("    end of character: %-28s %9.0f cycles  %5.1f %%" % (nm, used[:, 8 + k].mean(), 100 * used[:, 8 + k].mean() / tot))
