@@ -23,6 +23,15 @@
 // world boxes (blas_world_boxes_kernel) 64 per step and descend into the ones they may hit.
 #include <algorithm>
 #include <cstdlib>
+#ifndef SGE_BLAS_EXPERIMENT
+#define SGE_BLAS_EXPERIMENT 0
+#endif
+#if SGE_BLAS_EXPERIMENT == 4 // diagnostic build: stamps inside blasFinishCharacter as well (columns 8..11 of the phase table)
+#include <hip/hip_runtime.h>
+namespace sge { __device__ unsigned long long g_blasPhase[1024][12]; }
+#define SGE_FINISH_STAMP_BEGIN() unsigned long long fstamp_ = __builtin_readcyclecounter()
+#define SGE_FINISH_STAMP(k) do { if (tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); ::sge::g_blasPhase[blockIdx.x & 1023][8 + (k)] += now_ - fstamp_; fstamp_ = now_; } } while (0)
+#endif
 #include "sge_blas_dev.hpp"
 
 #ifndef SGE_BLAS_EXPERIMENT
@@ -32,7 +41,6 @@
 namespace sge {
 
 #if SGE_BLAS_EXPERIMENT == 4 // diagnostic build: shader-clock cycles of every phase of a step, summed per workgroup (wave 0's view)
-__device__ unsigned long long g_blasPhase[1024][8];
 #define SGE_PHASE(k) do { if (tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); phase[k] += now_ - stamp; stamp = now_; } } while (0)
 #else
 #define SGE_PHASE(k) do { } while (0)
@@ -164,9 +172,9 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_kernel(DevBlas B, 
 
 #if SGE_BLAS_EXPERIMENT == 4
 } // namespace sge
-extern "C" int sge_experiment_blas_phases(unsigned long long* out, int reset) { // [1024][8], diagnostic builds only
+extern "C" int sge_experiment_blas_phases(unsigned long long* out, int reset) { // [1024][12], diagnostic builds only
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sge::g_blasPhase), sizeof(sge::g_blasPhase)) != hipSuccess) return 1;
-    if (reset) { static unsigned long long zero[1024][8]; if (hipMemcpyToSymbol(HIP_SYMBOL(sge::g_blasPhase), zero, sizeof(zero)) != hipSuccess) return 1; }
+    if (reset) { static unsigned long long zero[1024][12]; if (hipMemcpyToSymbol(HIP_SYMBOL(sge::g_blasPhase), zero, sizeof(zero)) != hipSuccess) return 1; }
     return 0;
 }
 namespace sge {
@@ -250,6 +258,8 @@ __global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_raw_kernel(DevBlas
         const bool last = done + 1 == n;
         const int cNext = last ? __builtin_amdgcn_readfirstlane(sNextChar) : c;
         const int tileNext = last ? cNext % n : (tile + 1 == n ? 0 : tile + 1);
+        // (issued in front of the barrier above instead — the registers are free once this thread's granules are in LDS — the
+        // requests take just as long, the wavefront then stalls there, and the step gets 10 % longer: profiles/r4_refit_phases.txt)
         fetch(min(cNext, chars - 1), tileNext);
         SGE_PHASE(3);
 #if SGE_BLAS_EXPERIMENT == 4
