@@ -289,9 +289,7 @@ int rebuildPoseSlots(sge_context* c) {
 int allocCrowdOutputs(sge_context* c) {
     const size_t verts = (size_t)c->crowd.count * (size_t)c->mesh.vertexCount;
     const size_t stride = c->skinLayout == SGE_LAYOUT_PADDED16 ? 16 : 12;
-    // (+ kCrowdOutputPad: the raw-granule refit kernel reads whole 16-byte granules, the last one may reach past the last vertex)
-    const size_t pad = verts ? kCrowdOutputPad : 0;
-    const size_t need[3] = {verts * stride + pad, verts * stride + pad, verts * 16 + pad};
+    const size_t need[3] = {verts * stride, verts * stride, verts * 16};
     DevBuf* bufs[3] = {&c->dOutPos, &c->dOutNrm, &c->dOutTan};
     c->outLayoutAllocated = c->skinLayout;
     if (need[0] <= bufs[0]->bytes && need[1] <= bufs[1]->bytes && need[2] <= bufs[2]->bytes && bufs[0]->p) return SGE_OK;
@@ -1712,7 +1710,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
             }
             if (refit) { // RTAccelerationBuilder.build is enqueued right behind the skinning encoder (RayTracingScene.swift:35-43)
                 Bracket br(c, &c->evBlas, ss);
-                int rc = launch_blas_refit(c->blas, c->dOutPos.p, c->skinLayout, (long long)first * c->mesh.vertexCount, count, boxes, c->dBlasQueue.as<int>(), ss, kCrowdOutputPad);
+                int rc = launch_blas_refit(c->blas, c->dOutPos.p, c->skinLayout, (long long)first * c->mesh.vertexCount, count, boxes, c->dBlasQueue.as<int>(), ss);
                 if (rc != SGE_OK) return rc;
             }
         }
@@ -1791,7 +1789,7 @@ int sge_blas_refit(sge_context* c, int32_t first, int32_t count) {
     { int rcj = joinSkin(c); if (rcj != SGE_OK) return rcj; }
     Bracket br(c, &c->evBlas);
     int rc = launch_blas_refit(c->blas, c->dOutPos.p, c->outLayoutAllocated, (long long)first * c->mesh.vertexCount, count,
-                               c->dBlasBounds.as<float>() + (size_t)first * (c->blas.entryCount + 1) * 6, c->dBlasQueue.as<int>() + 16, c->stream, kCrowdOutputPad);
+                               c->dBlasBounds.as<float>() + (size_t)first * (c->blas.entryCount + 1) * 6, c->dBlasQueue.as<int>() + 16, c->stream);
     if (rc != SGE_OK) return rc;
     SGE_HIP(hipGetLastError());
     return SGE_OK;

@@ -180,121 +180,8 @@ extern "C" int sge_experiment_blas_phases(unsigned long long* out, int reset) { 
 namespace sge {
 #endif
 
-// The packed layout again, loaded as it lies in memory: the tile is a run of 12 * nv contiguous bytes, fetched as 16-byte granules
-// (one global_load_dwordx4 per lane: a wavefront's instruction covers 1 KB of consecutive addresses, eight whole 128-byte lines;
-// the per-component dword loads of the kernel above have a lane stride of 12 bytes, so each instruction touches six lines for 256
-// bytes and the same lines are asked for three times, by x, y and z) and copied to LDS granule for granule. LDS then holds the tile
-// in memory order, vertex v at byte `shift + 12 v` (shift = the tile's first byte minus its 16-byte aligned start: 0, 4, 8 or 12),
-// and the walk reads x, y, z from three consecutive words (blasWalkAoS). 4.5 loads and 4.5 LDS stores per thread and 3,072-vertex
-// tile instead of 18 and 18. Needs: `positions` 16-byte aligned and the last character's last granule inside the buffer (the
-// launcher checks both and otherwise takes the kernel above).
 template <int TILE>
-__global__ __launch_bounds__(kBlasRefitBlock) void blas_refit_raw_kernel(DevBlas B, const float* __restrict__ positions, long long firstVertex,
-                                                                         int chars, float* __restrict__ bounds, int* __restrict__ queue) {
-    extern __shared__ float lds[];
-    const int rows = B.entryCount + 1, tid = threadIdx.x;
-    float* tab = lds;
-    char* T = reinterpret_cast<char*>(lds) + (((size_t)rows * 24 + 15) & ~(size_t)15); // the granules of one tile, 16-byte aligned behind the table
-    constexpr int kGranules = (TILE * 12 + 12 + 15) / 16;        // most granules a tile touches
-    constexpr int kPerThread = (kGranules + kBlasRefitBlock - 1) / kBlasRefitBlock;
-    int* trs = reinterpret_cast<int*>(T + (size_t)kGranules * 16);
-    int& sNextChar = trs[B.tileCount + 1];
-    int* topo = trs + B.tileCount + 2;
-    blasTableInit(tab, rows, tid, kBlasRefitBlock);
-    blasTopoStage(B, topo, tid, kBlasRefitBlock);
-    for (int i = tid; i <= B.tileCount; i += kBlasRefitBlock) trs[i] = B.tileRoundStart[i];
-    __syncthreads();
-    const int lane = tid & (kWave - 1), wave = tid / kWave;
-    constexpr int kWaves = kBlasRefitBlock / kWave;
-    const int n = B.tileCount, lastRound = trs[n] - 1;
-    const char* P0 = reinterpret_cast<const char*>(positions);
-
-    v4f g[kPerThread];
-    // first byte of a tile, relative to `positions`
-    auto tileByte = [&](int c, int tile) { return (firstVertex + (long long)c * B.vertexCount + (long long)tile * B.tileVerts) * 12; };
-    auto fetch = [&](int c, int tile) {
-        const long long b0 = tileByte(c, tile);
-        const int nv = min(B.tileVerts, B.vertexCount - tile * B.tileVerts);
-        const long long a0 = b0 & ~15ll;
-        const int granules = (int)((b0 + (long long)nv * 12 - a0 + 15) >> 4);
-#pragma unroll
-        for (int k = 0; k < kPerThread; ++k) {
-            const int q = min(tid + k * kBlasRefitBlock, granules - 1); // past the end: the last granule again (stored twice, same bytes), no branch
-#if defined(SGE_BLAS_PLAIN_LOADS) // diagnostic build: default cache policy
-            g[k] = *reinterpret_cast<const v4f*>(P0 + a0 + (long long)q * 16);
-#else
-            g[k] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(P0 + a0 + (long long)q * 16)); // streamed once
-#endif
-        }
-    };
-    int c = blockIdx.x;
-    if (c >= chars) return;
-    int tile = c % n, done = 0, ticket = 0;
-    fetch(c, tile);
-#if SGE_BLAS_EXPERIMENT == 4
-    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp = __builtin_readcyclecounter();
-#endif
-    while (true) {
-        const int shift = (int)(tileByte(c, tile) & 15);
-        if (done == 0 && tid == 0) ticket = atomicAdd(queue, 1);
-        __syncthreads(); // the previous step's rounds have read the tile; a finished character's table has been re-initialised
-        SGE_PHASE(0);
-#if SGE_BLAS_EXPERIMENT == 4
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        SGE_PHASE(1);
-#endif
-#pragma unroll
-        for (int k = 0; k < kPerThread; ++k) {
-            const int q = tid + k * kBlasRefitBlock;
-            if (q < kGranules) *reinterpret_cast<v4f*>(T + (size_t)q * 16) = g[k]; // (granules past the tile's own hold the last one again: harmless)
-        }
-        if (done + 1 == n && tid == 0) sNextChar = (int)gridDim.x + ticket; // thread 0 has kept the ticket since the character's first step
-        __syncthreads();
-        SGE_PHASE(2);
-        const int rEnd = trs[tile + 1];
-        int r = trs[tile] + wave;
-        BlasRound R;
-        if (r < rEnd) blasFetchRound(B, r, lastRound, lane, R);
-        const bool last = done + 1 == n;
-        const int cNext = last ? __builtin_amdgcn_readfirstlane(sNextChar) : c;
-        const int tileNext = last ? cNext % n : (tile + 1 == n ? 0 : tile + 1);
-        // (issued in front of the barrier above instead — the registers are free once this thread's granules are in LDS — the
-        // requests take just as long, the wavefront then stalls there, and the step gets 10 % longer: profiles/r4_refit_phases.txt)
-        fetch(min(cNext, chars - 1), tileNext);
-        SGE_PHASE(3);
-#if SGE_BLAS_EXPERIMENT == 4
-        if (r < rEnd) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kPerThread) : "memory"); }
-        SGE_PHASE(4);
-#endif
-        if (r < rEnd) blasWalkAoS(tab, rows, T + shift, R);
-        for (r += kWaves; r < rEnd; r += kWaves) {
-            blasFetchRound(B, r, lastRound, lane, R);
-            blasWalkAoS(tab, rows, T + shift, R);
-        }
-        SGE_PHASE(5);
-        if (last) {
-            blasFinishCharacter(B, topo, tab, rows, tid, kBlasRefitBlock, bounds + (size_t)c * rows * 6);
-            SGE_PHASE(6);
-#if SGE_BLAS_EXPERIMENT == 4
-            if (cNext >= chars && tid == 0) { for (int k = 0; k < 8; ++k) g_blasPhase[blockIdx.x & 1023][k] += phase[k]; }
-#endif
-            if (cNext >= chars) return;
-            c = cNext;
-            done = 0;
-        } else {
-            ++done;
-        }
-        tile = tileNext;
-    }
-}
-// LDS of the raw-granule kernel: the box table padded to a multiple of 16 bytes, the granules of one tile, the round ranges
-template <int TILE>
-constexpr size_t blasRefitRawLdsBytes(int entryCount, int tileCount) {
-    return (((size_t)(entryCount + 1) * 24 + 15) & ~(size_t)15) + (size_t)((TILE * 12 + 12 + 15) / 16) * 16 + (size_t)(tileCount + 2) * 4;
-}
-
-template <int TILE>
-static int launchRefitTile(const DevBlas& B, const float* p, int layout, long long firstVertex, int chars, float* bounds, int* queue, int grid, size_t lds, hipStream_t s, int padBytes) {
+static int launchRefitTile(const DevBlas& B, const float* p, int layout, long long firstVertex, int chars, float* bounds, int* queue, int grid, size_t lds, hipStream_t s) {
     static bool attrSet[kMaxDevices] = {};
     const int devSlot = currentDeviceSlot();
     if (!attrSet[devSlot]) {
@@ -302,26 +189,12 @@ static int launchRefitTile(const DevBlas& B, const float* p, int layout, long lo
         SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blas_refit_kernel<4, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlasMaxLdsBytes + 64)); // + the ticket slot
         attrSet[devSlot] = true;
     }
-    static const int rawSetting = getenv("SGE_BLAS_RAW") ? atoi(getenv("SGE_BLAS_RAW")) : 1; // experiments: 0 = the per-component loads
-    // the raw-granule form: packed positions, 16-byte aligned base, and no granule that reaches past the end of the buffer
-    const long long endByte = (firstVertex + (long long)chars * B.vertexCount) * 12;
-    const size_t rawLds = blasRefitRawLdsBytes<TILE>(B.entryCount, B.tileCount) + blasTopoBytes(B.wideCount, B.levels) + 16;
-    if (rawSetting && layout == SGE_LAYOUT_PACKED && (reinterpret_cast<uintptr_t>(p) & 15) == 0 &&
-        ((endByte & 15) == 0 || padBytes >= 16) && rawLds <= kBlasMaxLdsBytes + 4096) {
-        static bool rawAttr[kMaxDevices] = {};
-        if (!rawAttr[devSlot]) {
-            SGE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(blas_refit_raw_kernel<TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlasMaxLdsBytes + 4096));
-            rawAttr[devSlot] = true;
-        }
-        hipLaunchKernelGGL((blas_refit_raw_kernel<TILE>), dim3(grid), dim3(kBlasRefitBlock), rawLds, s, B, p, firstVertex, chars, bounds, queue);
-        return SGE_OK;
-    }
     if (layout == SGE_LAYOUT_PADDED16) hipLaunchKernelGGL((blas_refit_kernel<4, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, B, p, firstVertex, chars, bounds, queue);
     else hipLaunchKernelGGL((blas_refit_kernel<3, TILE>), dim3(grid), dim3(kBlasRefitBlock), lds, s, B, p, firstVertex, chars, bounds, queue);
     return SGE_OK;
 }
 
-int launch_blas_refit(const DevBlas& B, const void* positions, int layout, long long firstVertex, int chars, float* bounds, int* queue, hipStream_t s, int padBytes) {
+int launch_blas_refit(const DevBlas& B, const void* positions, int layout, long long firstVertex, int chars, float* bounds, int* queue, hipStream_t s) {
     if (chars <= 0) return SGE_OK;
     SGE_HIP(hipMemsetAsync(queue, 0, sizeof(int), s));
     const size_t lds = blasRefitLdsBytes(B.entryCount, B.tileCount, B.tileCap) + blasTopoBytes(B.wideCount, B.levels) + 16; // + the ticket slot
@@ -331,9 +204,9 @@ int launch_blas_refit(const DevBlas& B, const void* positions, int layout, long 
     const int grid = std::min(chars, cus * perCU);
     const float* p = reinterpret_cast<const float*>(positions);
     switch (B.tileCap) {
-    case 3072: return launchRefitTile<3072>(B, p, layout, firstVertex, chars, bounds, queue, grid, lds, s, padBytes);
-    case 2048: return launchRefitTile<2048>(B, p, layout, firstVertex, chars, bounds, queue, grid, lds, s, padBytes);
-    default: return launchRefitTile<4096>(B, p, layout, firstVertex, chars, bounds, queue, grid, lds, s, padBytes);
+    case 3072: return launchRefitTile<3072>(B, p, layout, firstVertex, chars, bounds, queue, grid, lds, s);
+    case 2048: return launchRefitTile<2048>(B, p, layout, firstVertex, chars, bounds, queue, grid, lds, s);
+    default: return launchRefitTile<4096>(B, p, layout, firstVertex, chars, bounds, queue, grid, lds, s);
     }
 }
 

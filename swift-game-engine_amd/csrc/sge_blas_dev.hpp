@@ -109,31 +109,6 @@ __device__ __forceinline__ void blasWalk(float* tab, int rows, const float* X, c
     blasFold(tab, R.cluster, mnx, mny, mnz, mxx, mxy, mxz);
 }
 
-// The same walk over a tile kept in LDS as it lies in memory (xyz xyz ..., 12 bytes per vertex, the raw-granule refit kernel):
-// `tile` = LDS address of the tile's first vertex; the schedule's byte offsets (4 * local vertex id) times three.
-__device__ __forceinline__ void blasWalkAoS(float* tab, int rows, const char* tile, const BlasRound& R) {
-    const float inf = __builtin_inff();
-    float mnx = inf, mny = inf, mnz = inf, mxx = -inf, mxy = -inf, mxz = -inf;
-    const int len = __builtin_amdgcn_readfirstlane(R.len);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        if (g * 4 < len) { // scalar branch; four vertices' reads in flight together (see blasWalk)
-            float x[4], y[4], z[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = g * 4 + j;
-                const uint32_t off = (i & 1) ? (R.w[i >> 1] >> 16) : (R.w[i >> 1] & 0xffffu);
-                const float* q = reinterpret_cast<const float*>(tile + off * 3u);
-                x[j] = q[0]; y[j] = q[1]; z[j] = q[2];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { SGE_BLAS_FOLD(x[j], y[j], z[j]) }
-        }
-    }
-    blasFold(tab, R.cluster, mnx, mny, mnz, mxx, mxy, mxz);
-}
-
 // End of a character, called by every thread of the workgroup: inner entries from their wide nodes, deepest level first, one
 // wavefront per wide node; the table goes out coalesced ([entries + 1][6]) and is re-initialised. Leaves a barrier pending:
 // the caller's next __syncthreads() orders the re-initialisation before the next character's folds.

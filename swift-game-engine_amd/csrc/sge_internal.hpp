@@ -346,10 +346,7 @@ void launch_agents_pad(sge_agent_state* d_out, int n, hipStream_t s);
 
 // boxes of `chars` characters: character k reads vertices [firstVertex + k * vertexCount, +vertexCount) of `positions`
 // (layout SGE_LAYOUT_*) and writes bounds[k][entryCount + 1][6]
-// padBytes: bytes that may be read past the last vertex of the last character (the context's own position stream is allocated with
-// kCrowdOutputPad of them; a caller's buffer has none)
-constexpr int kCrowdOutputPad = 64;
-int launch_blas_refit(const DevBlas& B, const void* positions, int layout, long long firstVertex, int chars, float* bounds, int* queue, hipStream_t s, int padBytes = 0); // queue: one device int
+int launch_blas_refit(const DevBlas& B, const void* positions, int layout, long long firstVertex, int chars, float* bounds, int* queue, hipStream_t s); // queue: one device int
 // skin stage + refit stage as one launch (SGE_OPT_FUSE_BLAS_REFIT): bounds[chars][entryCount + 1][6]; queue = one device int
 // (the kernel's ticket counter, zeroed on `s` by the launcher)
 int launch_skin_refit(const SkinLaunch& L, const DevBlas& B, float* bounds, int* queue, hipStream_t s, int maxWorkgroupsPerCU);
