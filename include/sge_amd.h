@@ -809,8 +809,10 @@ typedef struct sge_blas_hit {
 
 /* `isect.intersect(ray, accel)` (RayTracing.metalinc:242): closest hit of every ray against its instance's refitted
  * structure, or against all of them. Host arrays; synchronous. Ties on distance go to the smaller instance, then the
- * smaller primitive id. The instance level is two scans of world boxes, 64 per step: groups of 64 consecutive characters,
- * then the characters of the groups the ray may hit (nothing else is built per frame). */
+ * smaller primitive id. The instance level (the TLAS of RTAccelerationBuilder.swift:168-185, rebuilt per call like the reference's
+ * per frame) is three scans of 64 boxes: the characters are sorted by the cell of an XZ grid over their world boxes' centres (the
+ * grid of the character-vs-character sweeps), 64 consecutive characters of that order form a group, 64 groups a super-group —
+ * 250,000 characters are 62 super-groups, one step. */
 int sge_blas_intersect_batch(sge_context* ctx, const sge_blas_ray* rays, int32_t count, sge_blas_hit* hits);
 /* The same with rays and hits in device memory (a renderer's ray buffers), enqueued on the context's stream: asynchronous.
  * `any_instance` != 0 when some ray may carry instance < 0 (the world boxes are then refreshed first). */

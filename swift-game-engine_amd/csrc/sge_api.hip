@@ -127,7 +127,7 @@ struct sge_context {
     int fuseBlas = 1;
     int blasBoundsChars = 0;
     DevBuf dBlasEntryLink, dBlasWideFirst, dBlasWideParent, dBlasWideLevel, dBlasSlotIdx, dBlasSlotTri,
-           dBlasIndices, dBlasBounds, dBlasInstances, dBlasRays, dBlasHits, dBlasTileStart, dBlasRoundLen, dBlasRoundCluster, dBlasRoundIds, dBlasWorldBoxes, dBlasUVs, dBlasQueue, dSkinQueue;
+           dBlasIndices, dBlasBounds, dBlasInstances, dBlasRays, dBlasHits, dBlasTileStart, dBlasRoundLen, dBlasRoundCluster, dBlasRoundIds, dBlasWorldBoxes, dBlasUVs, dBlasQueue, dSkinQueue, dBlasInstPoints, dBlasInstMinMax, dBlasInstGrid, dBlasInstOrder, dBlasGroupBoxes;
     bool blasHasUVs = false;
     // stats / profiling
     DevBuf dStats, dWaveProf, dOrderHist, dSepAgents, dSepCounts, dSepFlow;
@@ -473,33 +473,66 @@ __global__ void agentScatterKernel(const sge_agent_state* a, int n, const AgentG
     if (i < n && a[i].radius >= 0) items[atomicAdd(&cursor[agentCell(a[i], G)], 1)] = i;
 }
 
-// Bins the gathered agents into the XZ grid, entirely on the device and on the context's stream (sge_tick stays asynchronous):
-// bounds -> grid parameters -> count / scan / scatter. The cell arrays are sized once for the largest grid.
-int buildAgentGrid(sge_context* c) {
-    DevAgents& ag = c->agents;
-    if (!ag.all || ag.total <= 0) return SGE_OK;
+// Bins `total` capsule records into a uniform XZ grid, entirely on the device and on stream `s` (sge_tick stays asynchronous):
+// bounds -> grid parameters -> count / scan / scatter. The cell arrays (shared scratch of the context) are sized once for the
+// largest grid; `items` receives the record indices sorted by cell, `grid` the parameters, `minmax` is 32 bytes of scratch.
+int buildXZGrid(sge_context* c, hipStream_t s, const sge_agent_state* all, int total, DevBuf& minmax, DevBuf& gridBuf, DevBuf& items) {
     int rc;
-    if ((rc = c->dAgentMinMax.alloc(32)) != SGE_OK) return rc;
-    if ((rc = c->dAgentGrid.alloc(sizeof(AgentGrid))) != SGE_OK) return rc;
+    if ((rc = minmax.alloc(32)) != SGE_OK) return rc;
+    if ((rc = gridBuf.alloc(sizeof(AgentGrid))) != SGE_OK) return rc;
     // counts live in dCellCursor's tail: [cursor cells][counts cells]
     if ((rc = c->dCellCursor.alloc((size_t)kAgentMaxCells * 8)) != SGE_OK) return rc;
     if ((rc = c->dCellStart.alloc((size_t)(kAgentMaxCells + 1) * 4)) != SGE_OK) return rc;
-    if ((rc = c->dCellItems.alloc((size_t)ag.total * 4)) != SGE_OK) return rc;
+    if ((rc = items.alloc((size_t)total * 4)) != SGE_OK) return rc;
     static const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u};
-    SGE_HIP(hipMemcpyAsync(c->dAgentMinMax.p, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-    const int blocks = (ag.total + 255) / 256;
-    AgentGrid* grid = c->dAgentGrid.as<AgentGrid>();
+    SGE_HIP(hipMemcpyAsync(minmax.p, init, sizeof(init), hipMemcpyHostToDevice, s));
+    const int blocks = (total + 255) / 256;
+    AgentGrid* grid = gridBuf.as<AgentGrid>();
     int* cursor = c->dCellCursor.as<int>();
     int* cnt = cursor + kAgentMaxCells;
-    hipLaunchKernelGGL(agentBoundsKernel, dim3(blocks), dim3(256), 0, c->stream, ag.all, ag.total, c->dAgentMinMax.as<float>());
-    hipLaunchKernelGGL(agentGridKernel, dim3(1), dim3(1), 0, c->stream, c->dAgentMinMax.as<unsigned>(), grid);
-    hipLaunchKernelGGL(agentClearKernel, dim3(256), dim3(256), 0, c->stream, grid, cnt);
-    hipLaunchKernelGGL(agentCountKernel, dim3(blocks), dim3(256), 0, c->stream, ag.all, ag.total, grid, cnt);
-    hipLaunchKernelGGL(agentScanKernel, dim3(1), dim3(1024), 0, c->stream, cnt, grid, c->dCellStart.as<int>(), cursor);
-    hipLaunchKernelGGL(agentScatterKernel, dim3(blocks), dim3(256), 0, c->stream, ag.all, ag.total, grid, cursor, c->dCellItems.as<int>());
-    ag.grid = grid;
+    hipLaunchKernelGGL(agentBoundsKernel, dim3(blocks), dim3(256), 0, s, all, total, minmax.as<float>());
+    hipLaunchKernelGGL(agentGridKernel, dim3(1), dim3(1), 0, s, minmax.as<unsigned>(), grid);
+    hipLaunchKernelGGL(agentClearKernel, dim3(256), dim3(256), 0, s, grid, cnt);
+    hipLaunchKernelGGL(agentCountKernel, dim3(blocks), dim3(256), 0, s, all, total, grid, cnt);
+    hipLaunchKernelGGL(agentScanKernel, dim3(1), dim3(1024), 0, s, cnt, grid, c->dCellStart.as<int>(), cursor);
+    hipLaunchKernelGGL(agentScatterKernel, dim3(blocks), dim3(256), 0, s, all, total, grid, cursor, items.as<int>());
+    return SGE_OK;
+}
+
+// the gathered agents of the character-vs-character sweeps (SGE_STAGE_AGENTS)
+int buildAgentGrid(sge_context* c) {
+    DevAgents& ag = c->agents;
+    if (!ag.all || ag.total <= 0) return SGE_OK;
+    int rc = buildXZGrid(c, c->stream, ag.all, ag.total, c->dAgentMinMax, c->dAgentGrid, c->dCellItems);
+    if (rc != SGE_OK) return rc;
+    ag.grid = c->dAgentGrid.as<AgentGrid>();
     ag.cellStart = c->dCellStart.as<int>();
     ag.cellItems = c->dCellItems.as<int>();
+    return SGE_OK;
+}
+
+// The instance level of `isect.intersect(ray, accel)` for rays that name no character (RTAccelerationBuilder.swift:168-185 rebuilds
+// the TLAS over all items every frame): world boxes of every character, the characters sorted by the cell of the same XZ grid the
+// agent sweeps use (over the boxes' centres), one box per 64 consecutive characters of THAT order, one per 64 such groups. A ray
+// then tests 64 super-groups, 64 groups, 64 instances per step where the flat form scanned ceil(N / 64) index groups: 250,000
+// characters are 62 super-groups. Fills the trace's pointers; everything on the context's stream.
+int buildInstanceLevel(sge_context* c, BlasTrace& T) {
+    const int N = c->crowd.count, groups = (N + 63) / 64, supers = (groups + 63) / 64;
+    int rc;
+    if ((rc = c->dBlasWorldBoxes.alloc(((size_t)N + groups) * 24)) != SGE_OK) return rc;
+    if ((rc = c->dBlasInstPoints.alloc((size_t)N * sizeof(sge_agent_state))) != SGE_OK) return rc;
+    if ((rc = c->dBlasGroupBoxes.alloc(((size_t)groups + supers) * 24)) != SGE_OK) return rc;
+    T.worldBoxes = c->dBlasWorldBoxes.as<float>();
+    launch_blas_world_boxes(T, c->dBlasWorldBoxes.as<float>(), c->stream);
+    const bool flat = getenv("SGE_BLAS_FLAT_INSTANCES") != nullptr; // experiments / tests: the flat scan of 64 consecutive indices (read per call)
+    if (flat) { T.instOrder = nullptr; return SGE_OK; }
+    launch_blas_instance_points(c->dBlasWorldBoxes.as<float>(), N, c->dBlasInstPoints.as<sge_agent_state>(), c->stream);
+    if ((rc = buildXZGrid(c, c->stream, c->dBlasInstPoints.as<sge_agent_state>(), N, c->dBlasInstMinMax, c->dBlasInstGrid, c->dBlasInstOrder)) != SGE_OK) return rc;
+    float* gb = c->dBlasGroupBoxes.as<float>();
+    launch_blas_group_boxes(c->dBlasWorldBoxes.as<float>(), c->dBlasInstOrder.as<int>(), N, gb, gb + (size_t)groups * 6, c->stream);
+    T.instOrder = c->dBlasInstOrder.as<int>();
+    T.groupBoxes = gb;
+    T.superBoxes = gb + (size_t)groups * 6;
     return SGE_OK;
 }
 
@@ -602,7 +635,8 @@ void sge_context_destroy(sge_context* c) {
                       &c->dCellCursor, &c->dAgentMinMax, &c->dAgentGrid, &c->dAgentsAll, &c->dQueries, &c->dCastOut, &c->dOverlapOut, &c->dCounts, &c->dStats,
                       &c->dBlasEntryLink, &c->dBlasWideFirst, &c->dBlasWideParent, &c->dBlasWideLevel, &c->dBlasSlotIdx, &c->dBlasSlotTri,
                       &c->dBlasIndices, &c->dBlasBounds, &c->dBlasInstances, &c->dBlasRays, &c->dBlasHits, &c->dBlasTileStart,
-                      &c->dBlasRoundLen, &c->dBlasRoundCluster, &c->dBlasRoundIds, &c->dBlasWorldBoxes, &c->dBlasUVs, &c->dBlasQueue, &c->dSkinQueue};
+                      &c->dBlasRoundLen, &c->dBlasRoundCluster, &c->dBlasRoundIds, &c->dBlasWorldBoxes, &c->dBlasUVs, &c->dBlasQueue, &c->dSkinQueue,
+                      &c->dBlasInstPoints, &c->dBlasInstMinMax, &c->dBlasInstGrid, &c->dBlasInstOrder, &c->dBlasGroupBoxes};
     for (DevBuf* b : bufs) b->release();
     for (int k = 0; k < 2; ++k) {
         c->pull[k].stage.release();
@@ -1849,10 +1883,10 @@ int sge_blas_intersect_batch(sge_context* c, const sge_blas_ray* rays, int32_t c
     if ((rc = c->dBlasHits.alloc((size_t)count * sizeof(sge_blas_hit))) != SGE_OK) return rc;
     bool anyInstance = false;
     for (int i = 0; i < count && !anyInstance; ++i) anyInstance = rays[i].instance < 0;
-    if (anyInstance && (rc = c->dBlasWorldBoxes.alloc(((size_t)c->crowd.count + (c->crowd.count + 63) / 64) * 24)) != SGE_OK) return rc;
     BlasTrace T{c->blas, c->dOutPos.p, c->dOutNrm.p, c->dOutTan.as<float>(), c->dBlasIndices.as<uint32_t>(), c->outLayoutAllocated,
-                c->dBlasBounds.as<float>(), c->dBlasInstances.as<float>(), c->crowd.count, c->dBlasWorldBoxes.as<float>(),
+                c->dBlasBounds.as<float>(), c->dBlasInstances.as<float>(), c->crowd.count, nullptr,
                 c->blasHasUVs ? c->dBlasUVs.as<float>() : nullptr};
+    if (anyInstance && (rc = buildInstanceLevel(c, T)) != SGE_OK) return rc;
     launch_blas_intersect(T, c->dBlasRays.as<sge_blas_ray>(), count, c->dBlasHits.as<sge_blas_hit>(), anyInstance, c->stream);
     SGE_HIP(hipGetLastError());
     SGE_HIP(hipMemcpyAsync(hits, c->dBlasHits.p, (size_t)count * sizeof(sge_blas_hit), hipMemcpyDeviceToHost, c->stream));
@@ -1867,10 +1901,10 @@ int sge_blas_intersect_device(sge_context* c, const void* d_rays, int32_t count,
     (void)hipSetDevice(c->device);
     { int rcj = joinSkin(c); if (rcj != SGE_OK) return rcj; }
     int rc;
-    if (any_instance && (rc = c->dBlasWorldBoxes.alloc(((size_t)c->crowd.count + (c->crowd.count + 63) / 64) * 24)) != SGE_OK) return rc;
     BlasTrace T{c->blas, c->dOutPos.p, c->dOutNrm.p, c->dOutTan.as<float>(), c->dBlasIndices.as<uint32_t>(), c->outLayoutAllocated,
-                c->dBlasBounds.as<float>(), c->dBlasInstances.as<float>(), c->crowd.count, c->dBlasWorldBoxes.as<float>(),
+                c->dBlasBounds.as<float>(), c->dBlasInstances.as<float>(), c->crowd.count, nullptr,
                 c->blasHasUVs ? c->dBlasUVs.as<float>() : nullptr};
+    if (any_instance && (rc = buildInstanceLevel(c, T)) != SGE_OK) return rc;
     launch_blas_intersect(T, reinterpret_cast<const sge_blas_ray*>(d_rays), count, reinterpret_cast<sge_blas_hit*>(d_hits), any_instance != 0, c->stream);
     SGE_HIP(hipGetLastError());
     return SGE_OK;

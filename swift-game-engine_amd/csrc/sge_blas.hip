@@ -328,7 +328,9 @@ __global__ __launch_bounds__(kWave) void blas_intersect_kernel(BlasTrace T, cons
         const float* boxes = T.bounds + (size_t)inst * (B.entryCount + 1) * 6;
         // (distance bits, primitive id); distances are >= 0, so their bit patterns order like the values. A character found
         // earlier keeps a tie: the starting key carries primitive 0, which nothing is smaller than at equal distance.
-        unsigned long long best = ((unsigned long long)__float_as_uint(bestT) << 32) | (bestInst < 0 ? 0xffffffffull : 0ull);
+        // (with the instances visited in grid order rather than index order, a character with a smaller index than the holder of
+        // the best hit so far may still take it at equal distance: its starting key accepts any primitive there)
+        unsigned long long best = ((unsigned long long)__float_as_uint(bestT) << 32) | ((bestInst < 0 || inst < bestInst) ? 0xffffffffull : 0ull);
         float u0 = 0, v0 = 0;
         bool found = false;
         int sp = 1;
@@ -391,6 +393,34 @@ __global__ __launch_bounds__(kWave) void blas_intersect_kernel(BlasTrace T, cons
 
     if (R.instance >= 0) {
         traverse(R.instance);
+    } else if (T.worldBoxesValid && T.instOrder) {
+        // three scans of 64 boxes: super-groups (4,096 instances each: 62 of them hold 250,000 characters, one step), the groups of
+        // the ones the ray may hit, the instances of those groups — grouped by where they ARE (grid order), not by their index
+        const F3 inv = invDir(wd);
+        const int groups = (T.chars + kWave - 1) / kWave, supers = (groups + kWave - 1) / kWave;
+        for (int sbase = 0; sbase < supers; sbase += kWave) {
+            const int sg = sbase + lane;
+            unsigned long long sm = __ballot(sg < supers && slabPass(T.superBoxes + (size_t)sg * 6, wo, inv, tMin, bestT));
+            while (sm) {
+                const int ssrc = __ffsll((long long)sm) - 1;
+                sm &= sm - 1;
+                const int g = (sbase + ssrc) * kWave + lane;
+                unsigned long long gm = __ballot(g < groups && slabPass(T.groupBoxes + (size_t)g * 6, wo, inv, tMin, bestT));
+                while (gm) {
+                    const int gsrc = __ffsll((long long)gm) - 1;
+                    gm &= gm - 1;
+                    const int slot = ((sbase + ssrc) * kWave + gsrc) * kWave + lane;
+                    const int inst = slot < T.chars ? T.instOrder[slot] : -1;
+                    const bool pass = inst >= 0 && slabPass(T.worldBoxes + (size_t)inst * 6, wo, inv, tMin, bestT);
+                    unsigned long long m = __ballot(pass);
+                    while (m) {
+                        const int src = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        traverse(__shfl(inst, src, kWave));
+                    }
+                }
+            }
+        }
     } else if (T.worldBoxesValid) {
         const F3 inv = invDir(wd);
         const int groups = (T.chars + kWave - 1) / kWave;
@@ -452,10 +482,53 @@ __global__ __launch_bounds__(kWave) void blas_intersect_kernel(BlasTrace T, cons
     hits[blockIdx.x] = H;
 }
 
+__global__ void blas_instance_points_kernel(const float* __restrict__ worldBoxes, int chars, sge_agent_state* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= chars) return;
+    const float* b = worldBoxes + (size_t)i * 6;
+    sge_agent_state a{};
+    a.position[0] = 0.5f * (b[0] + b[3]); a.position[1] = 0.5f * (b[1] + b[4]); a.position[2] = 0.5f * (b[2] + b[5]);
+    const float hx = 0.5f * (b[3] - b[0]), hz = 0.5f * (b[5] - b[2]);
+    a.radius = fmaxf(sqrtf(hx * hx + hz * hz), 0.0f); // >= 0: every instance is binned (a character without triangles has an inverted box: NaN-free by the fmaxf)
+    if (!(a.radius >= 0.0f) || !(a.position[0] == a.position[0]) || !(a.position[2] == a.position[2])) { a.position[0] = a.position[1] = a.position[2] = 0.0f; a.radius = 0.0f; }
+    a.halfHeight = 0.5f * (b[4] - b[1]);
+    out[i] = a;
+}
+void launch_blas_instance_points(const float* worldBoxes, int chars, sge_agent_state* out, hipStream_t s) {
+    if (chars > 0) hipLaunchKernelGGL(blas_instance_points_kernel, dim3((chars + 255) / 256), dim3(256), 0, s, worldBoxes, chars, out);
+}
+// level 0: one wavefront per group of 64 entries of `order`; level 1 (second launch, order == nullptr): per 64 group boxes
+__global__ __launch_bounds__(kWave) void blas_group_boxes_kernel(const float* __restrict__ boxes, const int* __restrict__ order, int count, float* __restrict__ out) {
+    const int slot = blockIdx.x * kWave + threadIdx.x;
+    F3 mn{kFloatMax, kFloatMax, kFloatMax}, mx{-kFloatMax, -kFloatMax, -kFloatMax};
+    if (slot < count) {
+        const float* b = boxes + (size_t)(order ? order[slot] : slot) * 6;
+        mn = F3{b[0], b[1], b[2]}; mx = F3{b[3], b[4], b[5]};
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = vmin(mn, F3{__shfl_xor(mn.x, off, kWave), __shfl_xor(mn.y, off, kWave), __shfl_xor(mn.z, off, kWave)});
+        mx = vmax(mx, F3{__shfl_xor(mx.x, off, kWave), __shfl_xor(mx.y, off, kWave), __shfl_xor(mx.z, off, kWave)});
+    }
+    if (threadIdx.x == 0) {
+        float* o = out + (size_t)blockIdx.x * 6;
+        o[0] = mn.x; o[1] = mn.y; o[2] = mn.z; o[3] = mx.x; o[4] = mx.y; o[5] = mx.z;
+    }
+}
+void launch_blas_group_boxes(const float* worldBoxes, const int* order, int chars, float* groupBoxes, float* superBoxes, hipStream_t s) {
+    if (chars <= 0) return;
+    const int groups = (chars + kWave - 1) / kWave, supers = (groups + kWave - 1) / kWave;
+    hipLaunchKernelGGL(blas_group_boxes_kernel, dim3(groups), dim3(kWave), 0, s, worldBoxes, order, chars, groupBoxes);
+    hipLaunchKernelGGL(blas_group_boxes_kernel, dim3(supers), dim3(kWave), 0, s, groupBoxes, (const int*)nullptr, groups, superBoxes);
+}
+void launch_blas_world_boxes(const BlasTrace& T, float* worldBoxes, hipStream_t s) {
+    if (T.chars > 0) hipLaunchKernelGGL(blas_world_boxes_kernel, dim3((T.chars + kWave - 1) / kWave), dim3(kWave), 0, s, T, worldBoxes);
+}
+
 void launch_blas_intersect(BlasTrace T, const sge_blas_ray* d_rays, int n, sge_blas_hit* d_hits, bool anyInstance, hipStream_t s) {
     T.worldBoxesValid = anyInstance && T.worldBoxes != nullptr ? 1 : 0;
     if (n <= 0) return;
-    if (anyInstance && T.chars > 0) hipLaunchKernelGGL(blas_world_boxes_kernel, dim3((T.chars + kWave - 1) / kWave), dim3(kWave), 0, s, T, const_cast<float*>(T.worldBoxes));
+    // (the caller has refreshed the world boxes and, when it passes instOrder, the grid-ordered instance level: sge_api.hip)
+    if (anyInstance && T.chars > 0 && !T.instOrder && !T.worldBoxes) T.worldBoxesValid = 0; // nothing refreshed: rays without an instance miss
     if (T.layout == SGE_LAYOUT_PADDED16) hipLaunchKernelGGL((blas_intersect_kernel<4>), dim3(n), dim3(kWave), 0, s, T, d_rays, n, d_hits);
     else hipLaunchKernelGGL((blas_intersect_kernel<3>), dim3(n), dim3(kWave), 0, s, T, d_rays, n, d_hits);
 }

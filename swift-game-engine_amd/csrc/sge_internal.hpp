@@ -363,8 +363,21 @@ struct BlasTrace {
     const float* uvs;        // [V][2] of the shared mesh, or null
     int worldBoxesValid;     // 0: this launch did not refresh worldBoxes — a ray with instance < 0 reports a miss instead of walking
                              // boxes that are missing or belong to an earlier frame (the host cannot inspect device-resident rays)
+    // The instance level of a ray that names no character (RTAccelerationBuilder.swift:168-185: the TLAS over all items), rebuilt
+    // with the world boxes: the instances sorted by the cell of an XZ grid over their centres (the agent grid's kernels,
+    // sge_api.hip), `instOrder`; one box per 64 consecutive entries of that order (`groupBoxes`), one per 64 groups (`superBoxes`).
+    // Null: the flat form (groups of 64 consecutive character indices, boxes behind the instances' in worldBoxes).
+    const int* instOrder;    // [chars]
+    const float* groupBoxes; // [ceil(chars / 64)][6]
+    const float* superBoxes; // [ceil(chars / 4096)][6]
 };
 constexpr int kBlasTraversalStackCap = 256; // pending wide nodes of one closest-hit query (sge_blas.hip); sge_blas_build checks it
 void launch_blas_intersect(BlasTrace T, const sge_blas_ray* d_rays, int n, sge_blas_hit* d_hits, bool anyInstance, hipStream_t s);
+// the per-frame part of the instance level: every character's world box (+ the flat form's boxes of 64 consecutive indices)
+void launch_blas_world_boxes(const BlasTrace& T, float* worldBoxes, hipStream_t s);
+// centre + half diagonal of every world box as an agent record (what the XZ grid kernels bin)
+void launch_blas_instance_points(const float* worldBoxes, int chars, sge_agent_state* out, hipStream_t s);
+// boxes of the groups of 64 consecutive entries of `order`, and of 64 consecutive groups
+void launch_blas_group_boxes(const float* worldBoxes, const int* order, int chars, float* groupBoxes, float* superBoxes, hipStream_t s);
 
 } // namespace sge

@@ -379,3 +379,56 @@ def test_full_size_refit_properties(sge):
                 assert np.array_equal(b[:, rows, :3].min(1), b[:, dst, :3]) and np.array_equal(b[:, rows, 3:].max(1), b[:, dst, 3:])
     finally:
         gpu.close()
+
+
+def test_instance_level_of_31250_characters_matches_the_flat_scan(sge, monkeypatch):
+    """The instance level of a ray that names no character (the reference rebuilds its TLAS over all items per frame,
+    RTAccelerationBuilder.swift:168-185) at one GPU's share of configs[3]: 31,250 characters. The grid-ordered three-level form
+    (characters sorted by XZ cell, 64 per group, 64 groups per super-group) against the flat scan over groups of 64 consecutive
+    indices (SGE_BLAS_FLAT_INSTANCES, round 3's form): hit / instance / primitive / distance identical for 4,096 rays — rays into
+    the crowd, grazing rays along rows, rays that miss everything — including a tie: two characters far apart in index stand in
+    the same place in the same pose, the smaller index must win whichever the traversal meets first."""
+    gpu = sge.CharacterEngine(0)
+    try:
+        n = 31250
+        ybot, _, st = build_scene(sge, gpu, n, terrain_cells=None, mode="lbs", rings=3, segments=3, pose_debug=False)
+        # characters 77 and 20,000 become the same character (same body, same clocks): identical skinned vertices
+        twin = gpu.download(first=77, count=1)
+        gpu.upload(first=20000, **{k: twin[k] for k in ("bodies", "locomotion", "actions", "controllers")})
+        gpu.blas_build(gpu.mesh["indices"])
+        lbs = sge.abi.STAGE_LOCOMOTION | sge.abi.STAGE_ACTION | sge.abi.STAGE_POSE | sge.abi.STAGE_WRITEBACK | sge.abi.STAGE_SKIN | sge.abi.STAGE_BLAS_REFIT
+        for _ in range(3):
+            gpu.tick(stages=lbs)
+        V = gpu.vertex_count
+        b = gpu.download(what=("bodies",))["bodies"]["position"].astype(np.float32)
+        a77, a20k = gpu.skinned(77 * V, V)[0], gpu.skinned(20000 * V, V)[0]
+        assert np.array_equal(a77, a20k)
+        rng = np.random.default_rng(8)
+        k = 4096
+        lo, hi = b.min(0) - 3, b.max(0) + (3, 6, 3)
+        target = b[rng.integers(0, n, k)] + rng.normal(0, 0.8, (k, 3)).astype(np.float32) + (0, 2.5, 0)
+        origin = np.stack([rng.uniform(lo[0] - 40, hi[0] + 40, k), rng.uniform(5, 60, k), rng.uniform(lo[2] - 40, hi[2] + 40, k)], 1).astype(np.float32)
+        origin[:512, 1] = 2.5                                        # grazing: along the rows, at chest height
+        target[:64] = a77[rng.integers(0, V, 64)]                     # at the twins
+        origin[64:128] = origin[64:128] * (1, 0, 1) + (0, 500, 0)    # far above, straight down the middle of nothing
+        target[64:128] = origin[64:128] - (0, 1, 0) + (1e4, 0, 0)
+        d = target - origin
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        inst = np.full(k, -1, np.int32)
+        tree = gpu.blas_intersect(origin, d, inst)
+        monkeypatch.setenv("SGE_BLAS_FLAT_INSTANCES", "1")
+        flat = gpu.blas_intersect(origin, d, inst)
+        monkeypatch.delenv("SGE_BLAS_FLAT_INSTANCES")
+        for f in ("hit", "instance", "primitive"):
+            assert np.array_equal(tree[f], flat[f]), (f, np.argwhere(tree[f] != flat[f])[:5])
+        assert np.array_equal(tree["distance"].view(np.uint32), flat["distance"].view(np.uint32))
+        assert tree["hit"].mean() > 0.5 and (tree["hit"] == 0).sum() >= 32
+        assert len(np.unique(tree["instance"][tree["hit"] == 1])) > 1000
+        at_twins = tree["instance"][:64][tree["hit"][:64] == 1]
+        assert (at_twins == 77).sum() > 20 and not (at_twins == 20000).any(), "at equal distance the smaller character index wins"
+        # against a ray that names its character: the all-instances answer is never farther
+        named = gpu.blas_intersect(origin[:512], d[:512], np.where(tree["hit"][:512] == 1, tree["instance"][:512], 0).astype(np.int32))
+        sel = tree["hit"][:512] == 1
+        assert np.array_equal(named["primitive"][sel], tree["primitive"][:512][sel]) and np.array_equal(named["distance"][sel], tree["distance"][:512][sel])
+    finally:
+        gpu.close()
