@@ -405,11 +405,13 @@ def test_instance_level_of_31250_characters_matches_the_flat_scan(sge, monkeypat
         assert np.array_equal(a77, a20k)
         rng = np.random.default_rng(8)
         k = 4096
-        lo, hi = b.min(0) - 3, b.max(0) + (3, 6, 3)
-        target = b[rng.integers(0, n, k)] + rng.normal(0, 0.8, (k, 3)).astype(np.float32) + (0, 2.5, 0)
+        P = gpu.skinned(normals=False, tangents=False)[0]                # every skinned vertex of the crowd
+        target = P[rng.integers(0, len(P), k)] + rng.normal(0, 0.05, (k, 3)).astype(np.float32)
+        lo, hi = P.min(0) - 3, P.max(0) + 3
         origin = np.stack([rng.uniform(lo[0] - 40, hi[0] + 40, k), rng.uniform(5, 60, k), rng.uniform(lo[2] - 40, hi[2] + 40, k)], 1).astype(np.float32)
-        origin[:512, 1] = 2.5                                        # grazing: along the rows, at chest height
-        target[:64] = a77[rng.integers(0, V, 64)]                     # at the twins
+        origin[:512, 1] = target[:512, 1]                            # grazing: level rays along the rows
+        target[:64] = a77[rng.integers(0, V, 64)]                     # at the twins, from just above them (nobody else in the way)
+        origin[:64] = target[:64] + rng.uniform(-0.4, 0.4, (64, 3)).astype(np.float32) + (0, 6, 0)
         origin[64:128] = origin[64:128] * (1, 0, 1) + (0, 500, 0)    # far above, straight down the middle of nothing
         target[64:128] = origin[64:128] - (0, 1, 0) + (1e4, 0, 0)
         d = target - origin
@@ -422,10 +424,17 @@ def test_instance_level_of_31250_characters_matches_the_flat_scan(sge, monkeypat
         for f in ("hit", "instance", "primitive"):
             assert np.array_equal(tree[f], flat[f]), (f, np.argwhere(tree[f] != flat[f])[:5])
         assert np.array_equal(tree["distance"].view(np.uint32), flat["distance"].view(np.uint32))
-        assert tree["hit"].mean() > 0.5 and (tree["hit"] == 0).sum() >= 32
-        assert len(np.unique(tree["instance"][tree["hit"] == 1])) > 1000
-        at_twins = tree["instance"][:64][tree["hit"][:64] == 1]
-        assert (at_twins == 77).sum() > 20 and not (at_twins == 20000).any(), "at equal distance the smaller character index wins"
+        assert tree["hit"].mean() > 0.15 and (tree["hit"] == 0).sum() >= 32, tree["hit"].mean()
+        assert len(np.unique(tree["instance"][tree["hit"] == 1])) > 300
+        # the twins: a ray that names character 77 and one that names character 20,000 report the same hit bit for bit; the ray
+        # that names nobody reports character 77 wherever that hit is the closest, never character 20,000
+        n77 = gpu.blas_intersect(origin[:64], d[:64], np.full(64, 77, np.int32))
+        n20k = gpu.blas_intersect(origin[:64], d[:64], np.full(64, 20000, np.int32))
+        assert np.array_equal(n77["hit"], n20k["hit"]) and np.array_equal(n77["primitive"], n20k["primitive"])
+        assert np.array_equal(n77["distance"].view(np.uint32), n20k["distance"].view(np.uint32)) and n77["hit"].sum() >= 16
+        first = (n77["hit"] == 1) & (tree["distance"][:64] == n77["distance"])
+        assert first.sum() >= 4 and (tree["instance"][:64][first] == 77).all(), "at equal distance the smaller character index wins"
+        assert not (tree["instance"] == 20000).any()
         # against a ray that names its character: the all-instances answer is never farther
         named = gpu.blas_intersect(origin[:512], d[:512], np.where(tree["hit"][:512] == 1, tree["instance"][:512], 0).astype(np.int32))
         sel = tree["hit"][:512] == 1
