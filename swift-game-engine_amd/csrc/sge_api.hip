@@ -79,6 +79,10 @@ struct sge_context {
     int heavyThreshold = 4000; // distance evaluations in a character's last step above which it takes the multi-wave kernel; < 0: off
     int heavyCap = 2048;       // most characters the multi-wave launch takes per step (its grid is sized by demand, see sge_tick)
     int* hHeavyDemand = nullptr; // pinned host word the move stage copies its demand count to
+    // separation stage on crowds: {an agent was pushed further than a cell, a pass was redone serially} of the newest step whose copy
+    // has landed (pinned); after a "pushed" step the candidates of the following steps come from 7 x 7 cells instead of 5 x 5
+    int* hSepFlags = nullptr;
+    int sepWideSteps = 0;
     // the heavy / order lists of the next move stage, built behind the last one (launch_move): valid for exactly this range / threshold
     bool listsValid = false; int listsFirst = 0, listsCount = 0, listsThreshold = 0, listsCap = 0;
     hipEvent_t evListsReady = nullptr;
@@ -618,6 +622,8 @@ sge_context* sge_context_create(int device_index) {
     if (c->dSkinQueue.alloc(256) != SGE_OK || hipMemsetAsync(c->dSkinQueue.p, 0, 256, c->stream) != hipSuccess) { delete c; return nullptr; } // the resident LBS forms leave their ticket words at zero
     if (hipHostMalloc(reinterpret_cast<void**>(&c->hHeavyDemand), 2 * sizeof(int), hipHostMallocDefault) == hipSuccess) { c->hHeavyDemand[0] = -1; c->hHeavyDemand[1] = -1; }
     else { (void)hipGetLastError(); c->hHeavyDemand = nullptr; }
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->hSepFlags), 2 * sizeof(int), hipHostMallocDefault) == hipSuccess) { c->hSepFlags[0] = 0; c->hSepFlags[1] = 0; }
+    else { (void)hipGetLastError(); c->hSepFlags = nullptr; }
     if (c->dStats.alloc((size_t)kStatShards * 64) != SGE_OK || hipMemsetAsync(c->dStats.p, 0, (size_t)kStatShards * 64, c->stream) != hipSuccess) { delete c; return nullptr; }
     if (hipStreamSynchronize(c->stream) != hipSuccess) { set_error("context creation: device synchronisation failed"); delete c; return nullptr; } // the zeroed words are read from other streams
     return c;
@@ -650,6 +656,7 @@ void sge_context_destroy(sge_context* c) {
     for (hipEvent_t e : c->evPosePiped) if (e) (void)hipEventDestroy(e);
     if (c->poseStream) (void)hipStreamDestroy(c->poseStream);
     if (c->hHeavyDemand) (void)hipHostFree(c->hHeavyDemand);
+    if (c->hSepFlags) (void)hipHostFree(c->hSepFlags);
     if (c->evMainMark) (void)hipEventDestroy(c->evMainMark);
     if (c->evConsumed) (void)hipEventDestroy(c->evConsumed);
     if (c->evListsReady) (void)hipEventDestroy(c->evListsReady);
@@ -1654,8 +1661,14 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
         if ((rc = c->dSepAgents.alloc(sepAgents * kSeparationAgentBytes)) != SGE_OK) return rc;
         if ((rc = c->dSepCounts.alloc(2 * sizeof(int))) != SGE_OK) return rc;
         if ((rc = c->dSepFlow.alloc(separationFlowBytes(c->crowd.count))) != SGE_OK) return rc;
+        // A crowd whose agents get pushed further than a cell per pass (spawned on top of itself: 31,250 characters on the benchmark
+        // scene) takes its candidates from 7 x 7 cells for the next 64 steps; the step that shows it first is redone by one wavefront
+        // (results are the reference's either way)
+        if (c->hSepFlags && (*(volatile int*)c->hSepFlags & 2)) { c->sepWideSteps = 64; c->hSepFlags[0] = 0; }
+        const int reach = c->sepWideSteps > 0 ? 3 : 2;
+        if (c->sepWideSteps > 0) c->sepWideSteps -= 1;
         launch_separation(c->crowd, c->col, c->separationIterations, c->separationMargin, c->separationHeightMargin, c->dSepAgents.p,
-                          c->dSepCounts.as<int>(), c->dSepFlow.p, c->stream);
+                          c->dSepCounts.as<int>(), c->dSepFlow.p, c->stream, reach, c->hSepFlags);
     }
     if (st & (SGE_STAGE_LOCOMOTION | SGE_STAGE_ACTION | SGE_STAGE_POSE | SGE_STAGE_WRITEBACK)) {
         if ((st & SGE_STAGE_POSE) && (c->boneCount == 0 || c->prof.count == 0)) { set_error("pose stage needs a skeleton and motion profiles"); return SGE_ERR_STATE; }

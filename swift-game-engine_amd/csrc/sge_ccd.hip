@@ -2686,7 +2686,10 @@ __global__ __launch_bounds__(kWave, 3) void separation_post_kernel(SepLaunch K) 
 // Positions and velocities cross CUs (and XCDs) through agent-scope atomic loads / stores; a release is the data stores, a wait for
 // them, then the counter store (MI355X_MICROARCH.md, "Valid forms"). The result is the reference's, bit for bit, for any crowd;
 // what varies is the depth of the dependency graph (tools/separation_depth.py prints it).
-constexpr int kSepMaxCand = 256; // candidates a loop tracks (agents of higher index in its 5 x 5 cells); more: the pass runs serially
+constexpr int kSepMaxCand = 1024; // candidates a loop tracks (agents of higher index in its 5 x 5 cells); more: the pass runs serially.
+                                  // (256 until round 3: a crowd spawned at 1.6 units' spacing — 31,250 agents on the benchmark scene, one
+                                  // GPU's share of configs[3] — has 300-500 per agent and every pass fell back to one wavefront, 2.1 s per
+                                  // step; 1,024 are 16 KB of LDS per loop and 8 KB of list per agent)
 struct SepFlow {
     int* cell;          // [n][2] cell of every agent at the head of the pass (:1940-1944)
     int* bucketStart;   // [H + 1] hashed cells: agents sorted by (bucket, index)
@@ -2699,6 +2702,8 @@ struct SepFlow {
     int* control;       // [0] listed agents, [1] ticket, [2] redo flag of the pass, [3] cell size (float bits), [4] depth diagnostics
     float* backup;      // [n][6] position, velocity at the head of the pass
     int H;
+    int reach;          // candidates come from the (2 reach + 1)^2 cells around an agent's cell at the head of the pass: 2 = one cell of
+                        // movement + the 3 x 3 pair list (the rule); 3 after a step in which an agent was pushed further than a cell
 };
 __device__ __forceinline__ unsigned sepHash(int cx, int cz, int H) { return ((unsigned)cx * 73856093u ^ (unsigned)cz * 19349663u) & (unsigned)(H - 1); }
 __device__ __forceinline__ float sepLoad(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -2811,11 +2816,11 @@ __global__ void sep_sort_kernel(SepFlow F) {
         F.bucketItems[q + 1] = v;
     }
 }
-// agents in the 5 x 5 cells around (cx, cz) with index below `limit`
+// agents in the (2 reach + 1)^2 cells around (cx, cz) with index below `limit`
 __device__ __forceinline__ int sepCountBelow(const SepFlow& F, int cx, int cz, int limit) {
     int cnt = 0;
-    for (int dz = -2; dz <= 2; ++dz)
-        for (int dx = -2; dx <= 2; ++dx) {
+    for (int dz = -F.reach; dz <= F.reach; ++dz)
+        for (int dx = -F.reach; dx <= F.reach; ++dx) {
             const int tx = cx + dx, tz = cz + dz;
             const unsigned b = sepHash(tx, tz, F.H);
             for (int p = F.bucketStart[b]; p < F.bucketStart[b + 1]; ++p) {
@@ -2836,8 +2841,9 @@ __global__ __launch_bounds__(kWave) void sep_cand_kernel(SepFlow F) {
     __syncthreads();
     const int cx = F.cell[2 * k], cz = F.cell[2 * k + 1];
     int below = 0;
-    if (lane < 25) { // one cell of the 5 x 5 per lane
-        const int tx = cx + lane % 5 - 2, tz = cz + lane / 5 - 2;
+    const int side = 2 * F.reach + 1; // 5 or 7: at most 49 cells, one per lane
+    if (lane < side * side) {
+        const int tx = cx + lane % side - F.reach, tz = cz + lane / side - F.reach;
         const unsigned b = sepHash(tx, tz, F.H);
         for (int p = F.bucketStart[b]; p < F.bucketStart[b + 1]; ++p) {
             const int x = F.bucketItems[p];
@@ -2975,8 +2981,9 @@ __global__ __launch_bounds__(kWave, 2) void sep_flow_kernel(SepLaunch K, SepFlow
         const int cx = (int)floorf(aPos.x / cellSize), cz = (int)floorf(aPos.z / cellSize);
         {   // the pair list of :1955-1960 hangs on the LIVE cell: its 3 x 3 cells lie inside the 5 x 5 the candidates were taken from
             // as long as the agent has not been pushed further than one cell since the head of the pass
-            const int d0 = cx - F.cell[2 * i], d1 = cz - F.cell[2 * i + 1];
-            if ((d0 < -1 || d0 > 1 || d1 < -1 || d1 > 1) && lane == 0) atomicOr(&F.control[2], 2); // redo serially
+            const int d0 = cx - F.cell[2 * i], d1 = cz - F.cell[2 * i + 1], slack = F.reach - 1;
+            if ((d0 < -slack || d0 > slack || d1 < -slack || d1 > slack) && lane == 0) atomicOr(&F.control[2], 2); // redo serially
+            if ((d0 < -1 || d0 > 1 || d1 < -1 || d1 > 1) && lane == 0) atomicOr(&F.control[5], 2);               // (what the rule's reach would have said)
         }
         // 1. every candidate in its turn, a lane each: the ones outside the 3 x 3 cells around the live cell, and the pairs that fail
         //    the tests of :1972-1986 (they read agent j at their turn and change nothing: they commute with everything), are passed
@@ -3038,6 +3045,7 @@ __global__ __launch_bounds__(kWave) void sep_serial_kernel(SepLaunch K, SepFlow 
     WaveStats st{0, 0, 0, 0, 0, 0, 0};
     const int n = F.control[0];
     if (n <= 1 || F.control[2] == 0) return;
+    if (lane == 0) F.control[6] |= F.control[2];
     const float cellSize = __int_as_float(F.control[3]);
     for (int i = lane; i < n; i += kWave)
         for (int k = 0; k < 3; ++k) { sepStore(&K.agents[i].position[k], F.backup[i * 6 + k]); sepStore(&K.agents[i].velocity[k], F.backup[i * 6 + 3 + k]); }
@@ -3086,7 +3094,7 @@ size_t separationFlowBytes(int count) {
 int separationFlowBuckets(int count) { int H = 64; while (H < 2 * count) H <<= 1; return H; }
 
 void launch_separation(const DevCrowd& crowd, const DevCollision& col, int iterations, float separationMargin, float heightMargin,
-                       void* agentScratch, int* counts, void* flowScratch, hipStream_t s) {
+                       void* agentScratch, int* counts, void* flowScratch, hipStream_t s, int reach, int* flagsHost) {
     if (crowd.count <= 1) return;
     SepLaunch K{crowd, col, iterations < 1 ? 1 : iterations, separationMargin, heightMargin, reinterpret_cast<SepAgentDev*>(agentScratch), counts};
     const bool forceFlow = getenv("SGE_SEPARATION_FLOW") && atoi(getenv("SGE_SEPARATION_FLOW")) != 0; // tests: the crowd path on a small crowd
@@ -3110,7 +3118,9 @@ void launch_separation(const DevCrowd& crowd, const DevCollision& col, int itera
     F.control = reinterpret_cast<int*>(carve(64));
     F.backup = reinterpret_cast<float*>(carve(24 * (size_t)n));
     F.H = H;
+    F.reach = reach < 2 ? 2 : (reach > 3 ? 3 : reach);
     const int blocks = (n + 255) / 256;
+    (void)hipMemsetAsync(F.control + 5, 0, 8, s); // [5] "pushed further than a cell" over the whole step, [6] redo flags of any pass of the step
     hipLaunchKernelGGL(sep_list_kernel, dim3(1), dim3(1024), 0, s, K, F);
     for (int it = 0; it < K.iterations; ++it) {
         (void)hipMemsetAsync(F.bucketCursor, 0, 4 * (size_t)H, s);
@@ -3125,6 +3135,8 @@ void launch_separation(const DevCrowd& crowd, const DevCollision& col, int itera
         hipLaunchKernelGGL(sep_serial_kernel, dim3(1), dim3(kWave), 0, s, K, F);
     }
     hipLaunchKernelGGL(separation_post_kernel, dim3(n), dim3(kWave), 0, s, K);
+    // what the host sizes the NEXT step's reach from: [0] an agent was pushed further than a cell in some pass, [1] a pass was redone
+    if (flagsHost) (void)hipMemcpyAsync(flagsHost, F.control + 5, 8, hipMemcpyDeviceToHost, s);
 }
 
 // Picks this step's heavy characters by last step's sweep cost: flags[e] = 1 and an entry in the heavy list (at most

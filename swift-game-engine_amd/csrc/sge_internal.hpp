@@ -301,8 +301,9 @@ constexpr size_t kSeparationAgentBytes = 56; // SepAgentDev (sge_ccd.hip)
 // agentScratch: crowd.count x kSeparationAgentBytes; flowScratch: separationFlowBytes(crowd.count) (used above SGE_MAX_SEPARATION_AGENTS)
 size_t separationFlowBytes(int count);
 size_t separationFlowControlOffset(int count);
+// reach: 2 (the rule) or 3, see SepFlow::reach; flagsHost: pinned int[2] the stage copies {pushed further than a cell, pass redone} to, or null
 void launch_separation(const DevCrowd& crowd, const DevCollision& col, int iterations, float separationMargin, float heightMargin,
-                       void* agentScratch, int* counts, void* flowScratch, hipStream_t s);
+                       void* agentScratch, int* counts, void* flowScratch, hipStream_t s, int reach = 2, int* flagsHost = nullptr);
 void launch_cast_queries(const DevCollision& col, const sge_capsule_query* d_q, int n, sge_capsule_cast_hit* d_out,
                          unsigned long long* stats, hipStream_t s);
 void launch_overlap_queries(const DevCollision& col, const sge_capsule_query* d_q, int n, int maxHits,
