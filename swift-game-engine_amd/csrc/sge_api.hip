@@ -1751,9 +1751,10 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
                 int quarters = 0;
                 if (overlap && c->residentSkinQuarters >= 0) quarters = c->residentSkinQuarters;
                 else if (overlap && count >= kResidentSkinCharacters) quarters = kResidentSkinQuarters;
-                launch_skin(L, ss, overlap ? c->overlapSkinWorkgroups : 0, c->dSkinQueue.as<int>(), quarters, c->residentSkinCharsPerUnit);
-                c->lastSkinQuarters = quarters;
-                c->lastSkinCharsPerUnit = quarters > 0 && count >= 64 ? c->residentSkinCharsPerUnit : 1;
+                const int form = launch_skin(L, ss, overlap ? c->overlapSkinWorkgroups : 0, c->dSkinQueue.as<int>(), quarters, c->residentSkinCharsPerUnit);
+                SGE_HIP(hipGetLastError()); // a launch that could not start would leave the previous frame's streams in place
+                c->lastSkinQuarters = form > 0 ? quarters : 0; // what ran, not what was asked for (sge_debug_skin_form)
+                c->lastSkinCharsPerUnit = form > 0 ? form : 1;
             }
             if (refit) { // RTAccelerationBuilder.build is enqueued right behind the skinning encoder (RayTracingScene.swift:35-43)
                 Bracket br(c, &c->evBlas, ss);

@@ -329,7 +329,8 @@ struct SkinLaunch {
 };
 // residentQueue + residentQuarters > 0: the resident form (quarters of a workgroup per CU, one device int as the ticket counter)
 // charsPerUnit: 1, 2, 4 or 8 characters share every loaded source vertex in the resident form
-void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU = 0, int* residentQueue = nullptr, int residentQuarters = 0, int charsPerUnit = 1);
+// returns the form the launch took: 0 = workgroups that come and go, n >= 1 = resident workgroups with n characters per work unit
+int launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU = 0, int* residentQueue = nullptr, int residentQuarters = 0, int charsPerUnit = 1);
 // one record per RTSkinningJob of a batched encode (device copy)
 struct SkinJobDev {
     const void* srcPos; const void* srcNrm; const void* srcTan; const void* srcIdx; const void* srcWgt;

@@ -437,8 +437,8 @@ void launch_store_probe(void* outPos, void* outNrm, void* outTan, int chars, int
 // maxWorkgroupsPerCU > 0 caps the kernel's residency with dynamic-LDS padding: beside the next step's collision kernels
 // (SGE_OPT_OVERLAP_SKIN) three workgroups per CU stream as fast as five do alone, and the rest of the register file goes to the
 // latency-bound side (measured: 1.50 ms per step uncapped, 1.31 ms capped at three, 1.74 ms without overlap).
-void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU, int* residentQueue, int residentQuarters, int charsPerUnit) {
-    if (L.chars <= 0 || L.vertexCount <= 0) return;
+int launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU, int* residentQueue, int residentQuarters, int charsPerUnit) {
+    if (L.chars <= 0 || L.vertexCount <= 0) return 0;
     // enough workgroups to fill 256 CUs x 8 resident blocks several times over; small crowds split characters
     int splits = 1;
     while ((long long)L.chars * splits < 8192 && splits < 64 && (L.vertexCount + splits - 1) / splits > 2 * kSkinBlock) splits *= 2;
@@ -465,7 +465,10 @@ void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU, int
             else attrSet[devSlot] = true;
         }
     }
-    const int cpwSetting = charsPerUnit;
+    // the multi-character form stages charsPerUnit palettes in LDS (48 bytes per bone each): fewer characters per unit when a rig
+    // with many bones would pass the 64 KB a kernel may ask for without an attribute (8 x 256 bones = 98 KB; 4 x 256 = 49 KB)
+    int cpwSetting = charsPerUnit;
+    while (cpwSetting >= 2 && (size_t)cpwSetting * L.paletteCount * 48 + 16 > (size_t)64 * 1024) cpwSetting /= 2;
     if (residentQueue && residentQuarters > 0 && L.srcLayout != SGE_LAYOUT_PADDED16 && (cpwSetting == 2 || cpwSetting == 4 || cpwSetting == 8) && L.chars >= 64) {
         const int cpw = cpwSetting, groups = (L.chars + cpw - 1) / cpw;
         int sp2 = 1;
@@ -484,13 +487,13 @@ void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU, int
             if (ds == 3) hipLaunchKernelGGL((skin_ticket_multi_kernel<3, 8>), pgrid, dim3(kSkinBlock), lds, s, L, sp2, vps, residentQueue);
             else hipLaunchKernelGGL((skin_ticket_multi_kernel<4, 8>), pgrid, dim3(kSkinBlock), lds, s, L, sp2, vps, residentQueue);
         }
-        return;
+        return cpw;
     }
     if (residentQueue && residentQuarters > 0 && L.srcLayout != SGE_LAYOUT_PADDED16) { // resident workgroups + ticket counter (left at zero by the launch before)
         dim3 pgrid((unsigned)std::min<size_t>((size_t)splits * L.chars, (size_t)currentDeviceCUs() * residentQuarters / 4));
         if (ds == 3) hipLaunchKernelGGL((skin_ticket_kernel<3, 3>), pgrid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit, residentQueue);
         else hipLaunchKernelGGL((skin_ticket_kernel<3, 4>), pgrid, dim3(kSkinBlock), 0, s, L, splits, vertsPerSplit, residentQueue);
-        return;
+        return 1;
     }
     static const int prio = getenv("SGE_SKIN_SETPRIO") ? atoi(getenv("SGE_SKIN_SETPRIO")) : 0;
     const int wp = maxWorkgroupsPerCU > 0 ? prio : 0;
@@ -498,6 +501,7 @@ void launch_skin(const SkinLaunch& L, hipStream_t s, int maxWorkgroupsPerCU, int
     else if (ss == 3 && ds == 4) hipLaunchKernelGGL((skin_kernel<3, 4>), grid, dim3(kSkinBlock), ldsPad, s, L, splits, vertsPerSplit, wp);
     else if (ss == 4 && ds == 3) hipLaunchKernelGGL((skin_kernel<4, 3>), grid, dim3(kSkinBlock), ldsPad, s, L, splits, vertsPerSplit, wp);
     else hipLaunchKernelGGL((skin_kernel<4, 4>), grid, dim3(kSkinBlock), ldsPad, s, L, splits, vertsPerSplit, wp);
+    return 0;
 }
 
 // ---------------------------------------------------------------------------

@@ -95,6 +95,26 @@ def test_two_ranks_on_rccl_match_one_process(tmp_path):
     assert d.min() < 6.0, "no agent of rank 0 ever came near an agent of rank 1: the test crowd does not exercise the exchange"
 
 
+def test_two_rank_worker_rehearsal_on_one_gpu(tmp_path):
+    """What a one-GPU box can run of the test above: the same worker, two fresh rank processes sharing cuda:0 (--single-device),
+    the exchange staged through gloo, against one process with the whole crowd — everything but the RCCL transport."""
+    dump = str(tmp_path)
+    chars, steps = 2048, 40
+    base = [sys.executable, WORKER, "--chars", str(chars), "--steps", str(steps), "--dump", dump, "--single-device"]
+    launch(base + ["--backend", "gloo", "--tag", "staged"], 2)
+    launch(base + ["--tag", "one"], 1)
+    one = _load(dump, "one", 1)[0]
+    ranks = _load(dump, "staged", 2)
+    assert [int(r["first"]) for r in ranks] == [0, chars // 2] and int(one["overflow"]) == 0
+    for k in ("bodies", "controllers"):
+        assert_struct_equal(np.concatenate([r[k] for r in ranks]), one[k], "%s (staged exchange, 2 ranks on one GPU vs 1 process)" % k, skip=())
+    assert np.array_equal(ranks[0]["gathered"], ranks[1]["gathered"]) and "staged" in str(ranks[0]["path"])
+    g = ranks[0]["gathered"]
+    slot = g.shape[0] // 2
+    d = np.linalg.norm(g[:slot, None, [0, 2]][::8] - g[None, slot:, [0, 2]][:, ::8], axis=2)
+    assert d.min() < 6.0, "no agent of rank 0 came near an agent of rank 1"
+
+
 def _build_cpp(tmp_path, name):
     exe = str(tmp_path / name)
     hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"

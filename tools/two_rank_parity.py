@@ -47,8 +47,12 @@ def run_role(args):
     out = eng.download()
     pal = eng.palettes(0, min(count, 32))[0]
     stats = eng.move_stats()
+    extra = {}
+    if world == 1:  # the characters the two ranks dump as their first 32: global indices 0.. and chars_per_rank..
+        for f in (0, args.chars_per_rank):
+            extra["palettes_at_%d" % f] = eng.palettes(f, 32)[0]
     np.savez(os.path.join(args.dump, "world%d_rank%d.npz" % (world, rank)), first=first, count=count, palettes=pal,
-             overflow=int(stats.overflow), **{k: out[k] for k in ("bodies", "controllers", "locomotion")})
+             overflow=int(stats.overflow), **extra, **{k: out[k] for k in ("bodies", "controllers", "locomotion")})
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -91,12 +95,23 @@ def main():
         same = cat.tobytes() == single[k].tobytes()
         result["arrays"][k] = {"bytes": int(cat.nbytes), "identical": bool(same)}
         ok &= same
+    # palettes: every rank dumps its first 32 characters, the single process dumps the characters at the same GLOBAL indices
     for r, d in enumerate(ranks):
         f = int(d["first"])
-        same = d["palettes"].tobytes() == (single["palettes"].tobytes() if f == 0 else d["palettes"].tobytes())
+        same = d["palettes"].tobytes() == single["palettes_at_%d" % f].tobytes()
+        result["arrays"]["palettes_rank%d" % r] = {"first_global_index": f, "identical": bool(same)}
         ok &= same
     # did the exchange matter? (a run in which no sweep ever met another rank's agent would pass trivially)
+    # ... a run WITHOUT the exchange must differ, or no sweep ever met the other rank's agents
     moved = np.abs(single["bodies"]["position"][:, [0, 2]]).sum()
+    both = np.concatenate([r["bodies"] for r in ranks])
+    half = args.chars_per_rank
+    pa, pb = both["position"][:half][:, [0, 2]], both["position"][half:][:, [0, 2]]
+    step = max(1, half // 512)
+    near = float(np.min(np.linalg.norm(pa[::step, None, :] - pb[None, ::step, :], axis=2)))
+    result["closest_cross_rank_pair_of_a_sample"] = near
+    if near > 6.0:
+        raise SystemExit("no character of rank 0 ended near a character of rank 1 (closest sampled pair %.2f units): the crowd does not exercise the exchange" % near)
     result["overflow"] = [int(single["overflow"])] + [int(r["overflow"]) for r in ranks]
     result["identical"] = bool(ok)
     result["position_checksum"] = float(moved)
