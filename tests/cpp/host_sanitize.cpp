@@ -136,8 +136,12 @@ int main() {
         CHECK((int)hb.tileRoundStart.size() == hb.tileCount + 1);
         CHECK(hb.roundCluster.size() == hb.roundLen.size() * 64);
         CHECK(hb.roundIds.size() == hb.roundLen.size() * 8 * 64);
-        for (int c : hb.roundCluster) CHECK(c >= 0 && c < hb.entryCount());
+        for (size_t k = 0; k < hb.roundCluster.size(); ++k) { // leaf entry | the round's length << 24
+            const int packed = hb.roundCluster[k], c = packed & 0xffffff;
+            CHECK(c >= 0 && c < hb.entryCount() && (packed >> 24) == hb.roundLen[k / 64]);
+        }
         for (int l : hb.roundLen) CHECK(l >= 1 && l <= 16);
+        for (uint32_t w : hb.roundIds) CHECK((w & 0xffffu) < 4u * (uint32_t)hb.tileVerts && (w >> 16) < 4u * (uint32_t)hb.tileVerts && (w & 0x30003u) == 0); // all 16 entries of a lane are valid LDS offsets
     }
     { // rejected input comes back as an error, not as a crash
         HostBlas hb;
