@@ -2683,13 +2683,18 @@ __global__ __launch_bounds__(kWave, 3) void separation_post_kernel(SepLaunch K) 
 // in the pass; a quarter cell and half a cell were both exceeded in crowded scenes, 3 of 45 and 1 of 45 steps of the 192-agent
 // test, every step of an 8,192-agent crowd without character-vs-character sweeps, and each miss costs a serial pass.) Wavefronts draw loops from a ticket counter in index order, so the lowest
 // unfinished loop never waits for an unfinished one: no deadlock, whatever the number of resident wavefronts.
-// Positions and velocities cross CUs (and XCDs) through agent-scope atomic loads / stores; a release is the data stores, a wait for
-// them, then the counter store (MI355X_MICROARCH.md, "Valid forms"). The result is the reference's, bit for bit, for any crowd;
-// what varies is the depth of the dependency graph (tools/separation_depth.py prints it).
+// Positions and velocities cross CUs (and XCDs) through agent-scope atomic loads / stores. In the first form of the loops
+// (sep_flow_kernel, kept behind SGE_SEPARATION_BVH_CASTS=1 as the reference point of tests/test_separation.py) a release is the data
+// stores, a wait for them, then the counter store (MI355X_MICROARCH.md, "Valid forms"); the second form (sep_flow2_kernel, the
+// default) carries the version inside the data. The result is the reference's, bit for bit, for any crowd; what varies is the depth
+// of the dependency graph (tools/separation_depth.py prints it).
+constexpr int kSepTriCap = 128;       // triangles cached per agent; an agent with more in reach casts through the BVH
+constexpr float kSepTriReach = 1.0f;  // the cached box reaches this far beyond the capsule at the head of the pass
 constexpr int kSepMaxCand = 1024; // candidates a loop tracks (agents of higher index in its 5 x 5 cells); more: the pass runs serially.
                                   // (256 until round 3: a crowd spawned at 1.6 units' spacing — 31,250 agents on the benchmark scene, one
                                   // GPU's share of configs[3] — has 300-500 per agent and every pass fell back to one wavefront, 2.1 s per
                                   // step; 1,024 are 16 KB of LDS per loop and 8 KB of list per agent)
+struct SepStaticDev { float radius, halfHeight, invWeight, skinWidth, minGroundDot; uint32_t mask; float posY, velY; };
 struct SepFlow {
     int* cell;          // [n][2] cell of every agent at the head of the pass (:1940-1944)
     int* bucketStart;   // [H + 1] hashed cells: agents sorted by (bucket, index)
@@ -2701,7 +2706,12 @@ struct SepFlow {
     int2* cand;         // [n][kSepMaxCand] (agent of higher index in the 5 x 5 cells, this loop's rank among that agent's passers)
     int* control;       // [0] listed agents, [1] ticket, [2] redo flag of the pass, [3] cell size (float bits), [4] depth diagnostics
     float* backup;      // [n][6] position, velocity at the head of the pass
+    SepStaticDev* stat; // [n] what a pair reads of an agent that no pair changes (sep_cells_kernel)
+    unsigned long long* live; // [n][4] position x, z and velocity x, z, each an 8-byte granule (version << 32 | float bits): the data is the flag
+    float4* triCache;   // [n][kSepTriCap][3] the 48-B records of the triangles in reach of every agent during the pass (sep_tricache_kernel)
+    float* triBox;      // [n][8] the box those were gathered for (min xyz, max xyz) and their number (int bits; -1: more than kSepTriCap)
     int H;
+    int trace;          // (diagnostics build: this pass writes the timeline)
     int reach;          // candidates come from the (2 reach + 1)^2 cells around an agent's cell at the head of the pass: 2 = one cell of
                         // movement + the 3 x 3 pair list (the rule); 3 after a step in which an agent was pushed further than a cell
 };
@@ -2784,6 +2794,10 @@ __global__ void sep_cells_kernel(SepLaunch K, SepFlow F) {
     atomicAdd(&F.bucketCursor[sepHash(cx, cz, F.H)], 1);
     F.ver[i] = 0;
     for (int k = 0; k < 3; ++k) { F.backup[i * 6 + k] = a.position[k]; F.backup[i * 6 + 3 + k] = a.velocity[k]; }
+    const sge_controller_params& P = K.crowd.params[a.entity];
+    F.stat[i] = SepStaticDev{a.radius, a.halfHeight, a.invWeight, P.skinWidth, P.minGroundDot, P.collisionMask, a.position[1], a.velocity[1]};
+    const float lv[4] = {a.position[0], a.position[2], a.velocity[0], a.velocity[2]};
+    for (int k = 0; k < 4; ++k) F.live[(size_t)i * 4 + k] = (unsigned long long)__float_as_uint(lv[k]); // version 0
 }
 // exclusive scan of the bucket counts (one workgroup; every thread a contiguous run), counts -> zero (they become the scatter cursors)
 __global__ __launch_bounds__(1024) void sep_scan_kernel(SepFlow F) {
@@ -2867,7 +2881,117 @@ __global__ __launch_bounds__(kWave) void sep_cand_kernel(SepFlow F) {
     }
 }
 
+// Can the capsule touch the triangle anywhere along the cast? A lower bound of the distance between the triangle and the parallelogram
+// the capsule's axis sweeps (axis box [lo, hi]: for a cast, the box of its four corners; for "any cast of this agent in this pass", the
+// agent's whole cached region): the distance to the triangle's plane is linear in the position, so its minimum over a box is at a
+// corner, and the box distance to the triangle's box. Every evaluation of sweepCapsuleTriangle (:1303-1322) lies on that axis sweep; if
+// the bound exceeds radius + contactEps by 1e-3 (the rounding of either computation is below 1e-4 at these coordinates) no evaluation
+// can report contact and the march returns nil whatever steps it takes.
+__device__ __forceinline__ bool sepNeverTouches(F3 lo, F3 hi, float radius, F3 v0, F3 v1, F3 v2) {
+    const F3 n = normalize(cross(v1 - v0, v2 - v0));
+    float dmin = kFloatMax, dmax = -kFloatMax;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const F3 c{(k & 1) ? hi.x : lo.x, (k & 2) ? hi.y : lo.y, (k & 4) ? hi.z : lo.z};
+        const float d = dot(n, c - v0);
+        dmin = smin(dmin, d); dmax = smax(dmax, d);
+    }
+    float lb = dmin > 0 ? dmin : (dmax < 0 ? -dmax : 0.0f);
+    const F3 mn = vmin(v0, vmin(v1, v2)), mx = vmax(v0, vmax(v1, v2));
+    const float dx = smax(0.0f, smax(mn.x - hi.x, lo.x - mx.x));
+    const float dy = smax(0.0f, smax(mn.y - hi.y, lo.y - mx.y));
+    const float dz = smax(0.0f, smax(mn.z - hi.z, lo.z - mx.z));
+    const float lbBox = sqrtf(dx * dx + dy * dy + dz * dz);
+    if (lbBox > lb) lb = lbBox;
+    return lb - radius - 1e-5f - 1e-3f > 0;
+}
+// Per agent (one wavefront, all agents in parallel, off the pass's critical path): the triangles whose box overlaps the capsule's box at
+// the head of the pass grown by kSepTriReach AND that the capsule could touch from somewhere in there (sepNeverTouches over the whole
+// region the axis can be in) — what the casts of this agent's pairs can meet unless it is pushed further than that.
+// A cast takes exactly the triangles whose AABB overlaps ITS swept box and whose layer passes the mask (groupGather: the traversal
+// only prunes, the triangle test decides), so filtering this list by the cast's box gives the work items of a traversal minus
+// triangles whose marches return nil, whenever the cast's box lies inside the cached one. An agent whose list is empty (open
+// ground: the capsule rests a snap skin above it) casts into nothing at all.
+__global__ __launch_bounds__(kWave) void sep_tricache_kernel(SepLaunch K, SepFlow F) {
+    const int lane = laneId();
+    const int x = blockIdx.x;
+    if (x >= F.control[0]) return;
+    WaveStats st{0, 0, 0, 0, 0, 0, 0};
+    const DevCollision& col = K.col;
+    const SepAgentDev& a = K.agents[x];
+    const uint32_t mask = K.crowd.params[a.entity].collisionMask;
+    const float e = a.radius + kSepTriReach, ey = a.halfHeight + a.radius + 0.01f;
+    const F3 minP{a.position[0] - e, a.position[1] - ey, a.position[2] - e}, maxP{a.position[0] + e, a.position[1] + ey, a.position[2] + e};
+    // where the capsule's axis is during any cast that stays inside the cached box
+    const F3 axisLo{a.position[0] - kSepTriReach, a.position[1] - a.halfHeight - 0.01f, a.position[2] - kSepTriReach};
+    const F3 axisHi{a.position[0] + kSepTriReach, a.position[1] + a.halfHeight + 0.01f, a.position[2] + kSepTriReach};
+    int count = 0;
+    if (col.root >= 0) {
+        int stackSize = initTraversal(col), rangeCount = 0, candCount = 0;
+        __syncthreads();
+        while (stackSize > 0 || rangeCount > 0 || candCount > 0) {
+            while ((stackSize > 0 || rangeCount > 0) && candCount < kWave) expandNodes(col, minP, maxP, mask, stackSize, rangeCount, candCount, st);
+            const int m = candCount < kWave ? candCount : kWave;
+            candCount -= m;
+            bool touchable = false;
+            float4 t0{0, 0, 0, 0}, t1{0, 0, 0, 0}, t2{0, 0, 0, 0};
+            if (lane < m) {
+                const float4* tp = reinterpret_cast<const float4*>(col.tris + sh.cand[candCount + lane]);
+                t0 = tp[0]; t1 = tp[1]; t2 = tp[2];
+                touchable = !sepNeverTouches(axisLo, axisHi, a.radius, F3{t0.x, t0.y, t0.z}, F3{t0.w, t1.x, t1.y}, F3{t1.z, t1.w, t2.x});
+            }
+            const unsigned long long mt = __ballot(touchable);
+            if (count + __popcll(mt) > kSepTriCap) { count = -1; break; }
+            if (touchable) {
+                float4* dst = F.triCache + ((size_t)x * kSepTriCap + count + prefixCount(mt)) * 3;
+                dst[0] = t0; dst[1] = t1; dst[2] = t2;
+            }
+            count += __popcll(mt);
+            __syncthreads();
+        }
+    }
+    const int clear = count == 0 ? 1 : 0;
+    if (lane == 0) {
+        float* b = F.triBox + (size_t)x * 8;
+        b[0] = minP.x; b[1] = minP.y; b[2] = minP.z; b[3] = maxP.x; b[4] = maxP.y; b[5] = maxP.z;
+        b[6] = __int_as_float(count); b[7] = __int_as_float(clear);
+    }
+}
+
+#ifdef SGE_SEP_TIMING
+// diagnostics build (tools/separation_timeline.py): per loop of the last pass — ticket, own turn, candidates all passed, end (100-MHz
+// chip-wide clock), then the changing pairs, rounds, pairs sent through the BVH casts and sweep trips of the loop
+__device__ unsigned long long g_sepTs[8 * 32768];
+#define SEP_TS(i, k) do { if (laneId() == 0 && (i) < 32768 && F.trace) g_sepTs[(i) * 8 + (k)] = wall_clock64(); } while (0)
+#define SEP_TSV(i, k, v) do { if (laneId() == 0 && (i) < 32768 && F.trace) g_sepTs[(i) * 8 + (k)] = (unsigned long long)(v); } while (0)
+extern "C" int sge_experiment_sep_timeline(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sepTs), sizeof(unsigned long long) * 8 * (size_t)(n < 32768 ? n : 32768));
+}
+#else
+#define SEP_TS(i, k) do {} while (0)
+#define SEP_TSV(i, k, v) do {} while (0)
+#endif
 struct SepPairAgent { float radius, halfHeight, invWeight, skinWidth, minGroundDot; uint32_t mask; };
+// per-ray set-up of a blocking cast (groupSetupRays), for the short form of a pair's casts in sep_flow2_kernel
+struct SepRay { F3 from, delta, dir, mn, mx; float len; int maxIter; bool valid; };
+__device__ __forceinline__ SepRay sepRaySetup(const DevCollision& col, F3 from, F3 delta, float radius, float halfHeight) { // groupSetupRays, :1021-1035
+    SepRay r;
+    r.from = from; r.delta = delta;
+    r.len = length(delta);
+    r.valid = !(r.len < 1e-6f) && col.root >= 0;
+    r.dir = delta / r.len;
+    const F3 up{0, 1, 0};
+    const F3 a0 = from + up * halfHeight, b0 = from - up * halfHeight;
+    const F3 a1 = a0 + delta, b1 = b0 + delta;
+    const F3 mn = vmin(vmin(a0, b0), vmin(a1, b1));
+    const F3 mx = vmax(vmax(a0, b0), vmax(a1, b1));
+    const F3 ext{radius, radius, radius};
+    r.mn = mn - ext; r.mx = mx + ext;
+    const float minAdv = smax(radius * 0.02f, 1e-4f);
+    const int maxIter = (int)ceilf(r.len / minAdv) + 1; // :1296
+    r.maxIter = maxIter < 256 ? maxIter : 256;
+    return r;
+}
 // One pair of AgentSeparationResolver.resolve (:1961-2040): `aPos` / `aVel` are loop i's copy of agent i, posI / velI its live entry,
 // bPos / bVel agent j's (live). Returns true when agent j's entry changed.
 __device__ __forceinline__ bool sepPair(const DevCollision& col, const SepPairAgent& A, const SepPairAgent& B, F3 aPos, F3 aVel, F3& posI, F3& velI,
@@ -3037,6 +3161,537 @@ __global__ __launch_bounds__(kWave, 2) void sep_flow_kernel(SepLaunch K, SepFlow
     }
 }
 
+// ---- the pair loops, second form (round 4) ---------------------------------------------------------------------------------------
+// In-kernel stamps of the first form showed a changing pair costing ~25,000 cycles (~12 us), about half of them six dependent round
+// trips to the memory side (the agent's record behind its counter, its controller parameters behind its entity index, two BVH
+// traversals, the fence in front of the counter store) and the rest distance evaluations, mostly of triangles the capsule cannot
+// reach — and a per-loop timeline (tools/separation_timeline.py) that only ~3 loops are inside their pairs at any time: the stage's
+// time IS the pairs' latency. This form takes the round trips out of the chain and most of the evaluations out of the casts:
+//  - what a pair changes of an agent (position x, z and velocity x, z: the resolver's moves and impulses have no y) travels as four
+//    8-byte granules (version << 32 | float bits), stored by ONE 8-byte agent-scope atomic each: a reader that finds its rank in all
+//    four tags has the values — no counter behind a fence, no load behind a poll (cdna_hip_programming.md Guideline 16, R2);
+//  - what no pair changes (capsule, weight, controller parameters, y) is one 32-byte record per agent, and a candidate's lane loads
+//    it — and the box of the candidate's cached triangles — before the candidate's turn comes;
+//  - the pairs that change something are kept in LDS with everything a pair reads and with their push and impulse, which follow from
+//    loop i's copy of agent i and agent j alone (:1961-2003) and are worked out by the candidate's lane at its turn; only the origin
+//    of agent i's cast is its live position, i.e. the sum of the pushes before it — predicted as if no earlier pair were blocked;
+//  - per agent and pass, sep_tricache_kernel lists the triangles the capsule could touch from anywhere within kSepTriReach of where it
+//    stands (sepNeverTouches: a lower bound of the distance from the triangle's plane and box to the whole region the axis can be
+//    in, 1e-3 of margin against rounding). On open ground that list is empty — the capsule rests a snap skin above the ground —
+//    and a cast that stays in the region hits nothing: a loop whose agents are all like that is a few sums (step 2a, ~0.9 us
+//    against ~12 us per pair);
+//  - the other loops go through their casts in ROUNDS (2b): all rays of a round take their work items from the cached triangles
+//    (filtered once more against the cast's own sweep) and are swept together, one lane per item, idle lanes bisecting ahead for
+//    the items in refineTOI; the pairs are then resolved in the reference's order, and a pair that IS blocked ends the round behind
+//    it (its successors' origins were predicted wrong: they go into the next round).
+// A pair whose casts do not fit (more than kSepTriCap triangles in reach, cast outside the cached box, more items than lanes) goes
+// through sepPair's BVH casts as before. Same results, bit for bit (tests/test_separation.py: against the oracle and against the
+// first form). 8,192 agents on the cheese + mirror scene: 85 -> 58 ms per step on the same box (profiles/r4_separation_bench.txt);
+// what is left is real sweeps — a fifth of the loops stand on triangles they touch, ~6 trips of ~3 us each, one after the other.
+constexpr int kSepHeldCap = 64, kSepRound = 8;
+enum { SEP_LIVE = 1, SEP_CAST_A = 2, SEP_CAST_B = 4, SEP_VN_NEG = 8, SEP_B_CERTAIN = 16 };
+struct SepHeld {
+    unsigned long long key; int c, rank; float bx, bz, bvx, bvz; SepStaticDev S; float box[6]; int triCount, clear;
+    // the pair's push and impulse (:1961-2003) — functions of loop i's copy of agent i and of agent j alone, computed by the candidate's
+    // lane at its turn — and whether agent j's cast is known to hit nothing (SEP_B_CERTAIN)
+    float moveAx, moveAz, moveBx, moveBz, nx, nz, penetration, dvIx, dvIz, nbvx, nbvz; int flags;
+};
+struct SepRayRec { F3 from, delta, dir, mn, mx; float len, radius, halfHeight, ny; int maxIter, valid, src, skip, cnt, pad; unsigned long long key; };
+// the swept box of a cast (groupSetupRays, :1021-1035) and whether it lies inside an agent's cached box
+__device__ __forceinline__ bool sepCastInside(F3 from, F3 delta, float radius, float halfHeight, const float* box) {
+    const F3 up{0, 1, 0};
+    const F3 a0 = from + up * halfHeight, b0 = from - up * halfHeight;
+    const F3 a1 = a0 + delta, b1 = b0 + delta;
+    const F3 ext{radius, radius, radius};
+    const F3 mn = vmin(vmin(a0, b0), vmin(a1, b1)) - ext, mx = vmax(vmax(a0, b0), vmax(a1, b1)) + ext;
+    return mn.x >= box[0] && mn.y >= box[1] && mn.z >= box[2] && mx.x <= box[3] && mx.y <= box[4] && mx.z <= box[5];
+}
+__device__ __forceinline__ unsigned long long sepLoadG(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sepStoreG(unsigned long long* p, int tag, float v) {
+    __hip_atomic_store(p, ((unsigned long long)(unsigned)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// The workgroup is ONE wavefront: its LDS accesses execute in program order, so all a hand-over through LDS needs is that the
+// compiler keeps that order and that the writes have been issued — not __syncthreads(), whose s_waitcnt vmcnt(0) would also wait
+// for the acknowledgement of every granule store in flight (a round trip to the memory side per round).
+#define SEP_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+__global__ __launch_bounds__(kWave) void sep_flow2_kernel(SepLaunch K, SepFlow F) {
+    __shared__ int2 sCand[kSepMaxCand];
+    __shared__ SepHeld sHeld[kSepHeldCap];
+    __shared__ int sOrder[kSepHeldCap];
+    __shared__ SepRayRec sRay[2 * kSepRound];
+    __shared__ float4 sItemTri[kWave * 3];
+    __shared__ float4 sOwnTri[kSepTriCap * 3];
+    __shared__ int sItemRay[kWave];
+    __shared__ int sTicket, sHeldCount;
+    const int lane = laneId();
+    const DevCollision& col = K.col;
+    WaveStats st{0, 0, 0, 0, 0, 0, 0};
+    const int n = F.control[0];
+    if (n <= 1) return;
+    if (__hip_atomic_load(&F.control[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) return; // the candidate lists overflowed: serial pass
+    const float cellSize = __int_as_float(F.control[3]);
+    while (true) {
+        SEP_SYNC();
+        if (lane == 0) { sTicket = atomicAdd(&F.control[1], 1); sHeldCount = 0; }
+        SEP_SYNC();
+        const int i = sTicket;
+        if (i >= n) break;
+        SEP_TS(i, 0);
+        const int nc = F.candCount[i];
+        for (int l = lane; l < nc; l += kWave) sCand[l] = F.cand[(size_t)i * kSepMaxCand + l];
+        // agent i's own unchanging part and its cached triangles, before its turn comes
+        const SepStaticDev SA = F.stat[i];
+        const SepPairAgent A{SA.radius, SA.halfHeight, SA.invWeight, SA.skinWidth, SA.minGroundDot, SA.mask};
+        float boxI[6];
+        for (int k = 0; k < 6; ++k) boxI[k] = F.triBox[(size_t)i * 8 + k];
+        const int triCountI = __float_as_int(F.triBox[(size_t)i * 8 + 6]), clearI = __float_as_int(F.triBox[(size_t)i * 8 + 7]);
+        for (int k = lane; k < triCountI; k += kWave) {
+            const float4* tp = F.triCache + ((size_t)i * kSepTriCap + k) * 3;
+            sOwnTri[k * 3] = tp[0]; sOwnTri[k * 3 + 1] = tp[1]; sOwnTri[k * 3 + 2] = tp[2];
+        }
+        const int needI = F.need[i];
+        SEP_SYNC();
+        // every earlier loop that can pair with agent i has passed it: its four granules carry need[i]
+        unsigned long long g0, g1, g2, g3;
+        while (true) {
+            const unsigned long long* lp = F.live + (size_t)i * 4;
+            g0 = sepLoadG(lp); g1 = sepLoadG(lp + 1); g2 = sepLoadG(lp + 2); g3 = sepLoadG(lp + 3);
+            if ((int)(g0 >> 32) == needI && (int)(g1 >> 32) == needI && (int)(g2 >> 32) == needI && (int)(g3 >> 32) == needI) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        SEP_TS(i, 1);
+        const F3 aPos{__uint_as_float((unsigned)g0), SA.posY, __uint_as_float((unsigned)g1)};  // the copy `a` (:1954)
+        const F3 aVel{__uint_as_float((unsigned)g2), SA.velY, __uint_as_float((unsigned)g3)};
+        F3 posI = aPos, velI = aVel;
+        const int cx = (int)floorf(aPos.x / cellSize), cz = (int)floorf(aPos.z / cellSize);
+        {
+            const int d0 = cx - F.cell[2 * i], d1 = cz - F.cell[2 * i + 1], slack = F.reach - 1;
+            if ((d0 < -slack || d0 > slack || d1 < -slack || d1 > slack) && lane == 0) atomicOr(&F.control[2], 2); // redo serially
+            if ((d0 < -1 || d0 > 1 || d1 < -1 || d1 > 1) && lane == 0) atomicOr(&F.control[5], 2);               // (what the rule's reach would have said)
+        }
+        // 1. every candidate in its turn, a lane each (see sep_flow_kernel): passed at once unless the pair changes something; a pair
+        //    that does is kept in LDS with its push and impulse already worked out by that lane
+        for (int base = 0; base < nc; base += kWave) {
+            const int l = base + lane;
+            bool waiting = l < nc;
+            const int c = waiting ? sCand[l].x : 0, rank = waiting ? sCand[l].y : 0;
+            const int ddx = waiting ? F.cell[2 * c] - cx : 9, ddz = waiting ? F.cell[2 * c + 1] - cz : 9;
+            const bool inList = ddx >= -1 && ddx <= 1 && ddz >= -1 && ddz <= 1;
+            SepStaticDev S = SA;
+            float box[6] = {0, 0, 0, 0, 0, 0};
+            int triCount = -1, clear = 0;
+            if (waiting && inList) {
+                S = F.stat[c];
+                for (int k = 0; k < 6; ++k) box[k] = F.triBox[(size_t)c * 8 + k];
+                triCount = __float_as_int(F.triBox[(size_t)c * 8 + 6]);
+                clear = __float_as_int(F.triBox[(size_t)c * 8 + 7]);
+            }
+            unsigned long long* lp = F.live + (size_t)c * 4;
+            while (__any(waiting)) {
+                if (waiting) {
+                    const unsigned long long h0 = sepLoadG(lp), h1 = sepLoadG(lp + 1), h2 = sepLoadG(lp + 2), h3 = sepLoadG(lp + 3);
+                    if ((int)(h0 >> 32) == rank && (int)(h1 >> 32) == rank && (int)(h2 >> 32) == rank && (int)(h3 >> 32) == rank) {
+                        waiting = false;
+                        const float bx = __uint_as_float((unsigned)h0), bz = __uint_as_float((unsigned)h1);
+                        const float bvx = __uint_as_float((unsigned)h2), bvz = __uint_as_float((unsigned)h3);
+                        bool hold = false;
+                        if (inList) {
+                            const SepPairAgent B{S.radius, S.halfHeight, S.invWeight, S.skinWidth, S.minGroundDot, S.mask};
+                            hold = sepInteracts(A, B, aPos, F3{bx, S.posY, bz}, K.separationMargin, K.heightMargin);
+                        }
+                        int slot = -1;
+                        if (hold) slot = atomicAdd(&sHeldCount, 1);
+                        if (hold && slot < kSepHeldCap) {
+                            SepHeld& H = sHeld[slot];
+                            H.key = ((unsigned long long)((ddz + 1) * 3 + (ddx + 1)) << 32) | (unsigned)c;
+                            H.c = c; H.rank = rank; H.bx = bx; H.bz = bz; H.bvx = bvx; H.bvz = bvz; H.S = S;
+                            for (int k = 0; k < 6; ++k) H.box[k] = box[k];
+                            H.triCount = triCount; H.clear = clear;
+                            // the pair's push, impulse and cast flags (:1961-2003; sepPair's expressions)
+                            int flags = 0;
+                            float moveAx = 0, moveAz = 0, moveBx = 0, moveBz = 0, nx = 0, nz = 0, penetration = 0, dvIx = 0, dvIz = 0, nbvx = bvx, nbvz = bvz;
+                            const float pdx = aPos.x - bx, pdz = aPos.z - bz;
+                            const float distSq = pdx * pdx + pdz * pdz;
+                            const float skinAllowance = smin(A.skinWidth, S.skinWidth);
+                            const float margin = smin(K.separationMargin, skinAllowance);
+                            const float minDist = A.radius + S.radius + margin;
+                            const float wSum = A.invWeight + S.invWeight;
+                            if (!(distSq >= minDist * minDist) && !(wSum <= 0)) { // (the height test is part of `hold`)
+                                const float dist = sqrtf(smax(distSq, 1e-8f));
+                                nx = pdx / dist; nz = pdz / dist;
+                                penetration = minDist - dist;
+                                const float corr = penetration / wSum;
+                                flags = SEP_LIVE;
+                                moveAx = nx * corr * A.invWeight; moveAz = nz * corr * A.invWeight;
+                                moveBx = -nx * corr * S.invWeight; moveBz = -nz * corr * S.invWeight;
+                                const F3 relV = aVel - F3{bvx, S.velY, bvz};
+                                const float vn = relV.x * nx + relV.z * nz;
+                                if (vn < 0) {
+                                    const float impulse = -vn;
+                                    const float scaleA = A.invWeight / wSum, scaleB = S.invWeight / wSum;
+                                    dvIx = nx * impulse * scaleA; dvIz = nz * impulse * scaleA;
+                                    nbvx = bvx - nx * impulse * scaleB; nbvz = bvz - nz * impulse * scaleB;
+                                    flags |= SEP_VN_NEG;
+                                }
+                                const float eps = 1e-6f;
+                                if (length(F3{moveAx, 0, moveAz}) > eps) flags |= SEP_CAST_A;
+                                if (length(F3{moveBx, 0, moveBz}) > eps) flags |= SEP_CAST_B;
+                                // agent j's cast: nothing in reach of agent j, and the cast stays where that was established
+                                if (!(flags & SEP_CAST_B) || (clear && !(length(F3{moveBx, 0, moveBz}) < 1e-6f) &&
+                                                              sepCastInside(F3{bx, S.posY, bz}, F3{moveBx, 0, moveBz}, S.radius, S.halfHeight, box))) flags |= SEP_B_CERTAIN;
+                            }
+                            H.moveAx = moveAx; H.moveAz = moveAz; H.moveBx = moveBx; H.moveBz = moveBz; H.nx = nx; H.nz = nz; H.penetration = penetration;
+                            H.dvIx = dvIx; H.dvIz = dvIz; H.nbvx = nbvx; H.nbvz = nbvz; H.flags = flags;
+                        } else {
+                            if (hold) atomicOr(&F.control[2], 1); // more changing pairs than this form keeps: the pass runs serially
+                            sepStoreG(lp, rank + 1, bx); sepStoreG(lp + 1, rank + 1, bz); sepStoreG(lp + 2, rank + 1, bvx); sepStoreG(lp + 3, rank + 1, bvz);
+                        }
+                    }
+                }
+                if (__any(waiting)) __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        SEP_SYNC();
+        SEP_TS(i, 2);
+        const int nh = sHeldCount < kSepHeldCap ? sHeldCount : kSepHeldCap;
+        // the reference's order of the pairs that change something (cell dz, dx, then index)
+        if (lane < nh) {
+            const unsigned long long mine = sHeld[lane].key;
+            int before = 0;
+            for (int k = 0; k < nh; ++k) before += sHeld[k].key < mine ? 1 : 0;
+            sOrder[before] = lane;
+        }
+        SEP_SYNC();
+#ifdef SGE_SEP_TIMING
+        int dbgRounds = 0, dbgFall = 0, dbgTrips = 0, dbgMarch = 0, dbgCrawl = 0, dbgContact = 0;
+#endif
+        int h0 = 0;
+        // 2a. the common case, without a cast: lane g takes pair g. Agent i's live position at pair g is the sum of the pushes before it
+        //     (as long as none of them is blocked); if nothing is in reach of agent i there and of no agent j, no cast can hit, no pair
+        //     is blocked, and the loop is those sums.
+        if (nh > 0) {
+            int flags = 0, c = 0, rank = 0;
+            float mAx = 0, mAz = 0, dvx = 0, dvz = 0, nbx = 0, nbz = 0, nbvx = 0, nbvz = 0;
+            if (lane < nh) {
+                const SepHeld& H = sHeld[sOrder[lane]];
+                flags = H.flags; c = H.c; rank = H.rank; mAx = H.moveAx; mAz = H.moveAz; dvx = H.dvIx; dvz = H.dvIz; nbvx = H.nbvx; nbvz = H.nbvz;
+                nbx = H.bx; nbz = H.bz;
+                if (flags & SEP_LIVE) { const F3 nb = F3{H.bx, H.S.posY, H.bz} + F3{H.moveBx, 0, H.moveBz}; nbx = nb.x; nbz = nb.z; }
+            }
+            F3 pp = posI, vv = velI, myFrom = posI;
+            for (int k = 0; k < nh; ++k) {
+                const int fk = __shfl(flags, k, kWave);
+                const float ax = __shfl(mAx, k, kWave), az = __shfl(mAz, k, kWave), vx = __shfl(dvx, k, kWave), vz = __shfl(dvz, k, kWave);
+                if (lane == k) myFrom = pp;
+                if (fk & SEP_VN_NEG) { vv.x += vx; vv.z += vz; }
+                if (fk & SEP_LIVE) pp = pp + F3{ax, 0, az};
+            }
+            bool ok = true;
+            if (lane < nh && (flags & SEP_LIVE)) {
+                if (!(flags & SEP_B_CERTAIN)) ok = false;
+                if ((flags & SEP_CAST_A) && !(clearI && sepCastInside(myFrom, F3{mAx, 0, mAz}, A.radius, A.halfHeight, boxI))) ok = false;
+            }
+            if (__all(ok)) {
+                if (lane < nh) {
+                    unsigned long long* lp = F.live + (size_t)c * 4;
+                    sepStoreG(lp, rank + 1, nbx); sepStoreG(lp + 1, rank + 1, nbz); sepStoreG(lp + 2, rank + 1, nbvx); sepStoreG(lp + 3, rank + 1, nbvz);
+                }
+                posI = pp; velI = vv;
+                h0 = nh;
+            }
+        }
+        // 2b. otherwise the pairs go through their casts in rounds
+        while (h0 < nh) {
+#ifdef SGE_SEP_TIMING
+            dbgRounds += 1;
+#endif
+            int G = nh - h0 < kSepRound ? nh - h0 : kSepRound;
+            // (b) the rays: 2 g = agent i from its predicted live position along moveA, 2 g + 1 = agent j along moveB
+            bool rayOk = true;
+            if (lane < 2 * G) {
+                const int g = lane >> 1, which = lane & 1;
+                const SepHeld& H = sHeld[sOrder[h0 + g]];
+                F3 from, delta;
+                float radius, halfHeight;
+                bool cast;
+                const float* box;
+                int triCount, clear;
+                if (which == 0) {
+                    F3 pp = posI;
+                    for (int k = 0; k < g; ++k) { const SepHeld& Hk = sHeld[sOrder[h0 + k]]; if (Hk.flags & SEP_LIVE) pp = pp + F3{Hk.moveAx, 0, Hk.moveAz}; } // as if no earlier pair of the round were blocked
+                    from = pp; delta = F3{H.moveAx, 0, H.moveAz}; radius = A.radius; halfHeight = A.halfHeight; cast = (H.flags & SEP_CAST_A) != 0;
+                    box = boxI; triCount = triCountI; clear = clearI;
+                } else {
+                    from = F3{H.bx, H.S.posY, H.bz}; delta = F3{H.moveBx, 0, H.moveBz}; radius = H.S.radius; halfHeight = H.S.halfHeight; cast = (H.flags & SEP_CAST_B) != 0;
+                    box = H.box; triCount = H.triCount; clear = H.clear;
+                }
+                const SepRay r = sepRaySetup(col, from, cast ? delta : F3{0, 0, 0}, radius, halfHeight);
+                SepRayRec& R = sRay[lane];
+                R.from = r.from; R.delta = r.delta; R.dir = r.dir; R.mn = r.mn; R.mx = r.mx; R.len = r.len; R.radius = radius; R.halfHeight = halfHeight;
+                R.ny = 0; R.maxIter = r.maxIter; R.valid = r.valid ? 1 : 0; R.src = which ? H.c : -1; R.key = ~0ull;
+                R.skip = clear; // (inside the cached box, checked next:) nothing in reach of this agent — the cast hits nothing
+                R.cnt = triCount;
+                rayOk = !r.valid || (triCount >= 0 && r.mn.x >= box[0] && r.mn.y >= box[1] && r.mn.z >= box[2] &&
+                                     r.mx.x <= box[3] && r.mx.y <= box[4] && r.mx.z <= box[5]);
+            }
+            unsigned needRays = 0;
+            {
+                const unsigned long long bad = __ballot(!rayOk);
+                if (bad) { const int gBad = (__ffsll((long long)bad) - 1) >> 1; if (gBad < G) G = gBad; }
+                SEP_SYNC();
+                needRays = (unsigned)__ballot(lane < 2 * G && sRay[lane < 2 * kSepRound ? lane : 0].valid && !sRay[lane < 2 * kSepRound ? lane : 0].skip);
+            }
+            // (c) work items of the round's rays from the cached triangles: two rays of at most 32 cached triangles share the wavefront,
+            //     a longer list has it alone, 64 triangles at a time; a round ends in front of the pair whose items no longer fit one per lane
+            int total = 0;
+            {
+                int curPair = -1, pairStart = 0;
+                bool cut = false;
+                while (needRays && !cut) {
+                    const int rA = __ffs((int)needRays) - 1; needRays &= needRays - 1;
+                    int rB = needRays ? __ffs((int)needRays) - 1 : -1;
+                    const int cntA = sRay[rA].cnt;
+                    const bool wide = cntA > 32 || (rB >= 0 && sRay[rB].cnt > 32);
+                    if (wide) rB = -1;
+                    if (rB >= 0) needRays &= needRays - 1;
+                    for (int k0 = 0; k0 < (wide ? cntA : 1) && !cut; k0 += kWave) {
+                        const int half = wide ? 0 : lane >> 5, k = wide ? k0 + lane : lane & 31;
+                        const int r = half ? rB : rA;
+                        bool c = false;
+                        float4 t0{0, 0, 0, 0}, t1{0, 0, 0, 0}, t2{0, 0, 0, 0};
+                        if (r >= 0) {
+                            const SepRayRec& R = sRay[r];
+                            if (k < R.cnt) {
+                                if (R.src >= 0) { const float4* tp = F.triCache + ((size_t)R.src * kSepTriCap + k) * 3; t0 = tp[0]; t1 = tp[1]; t2 = tp[2]; }
+                                else { t0 = sOwnTri[k * 3]; t1 = sOwnTri[k * 3 + 1]; t2 = sOwnTri[k * 3 + 2]; }
+                                const F3 v0{t0.x, t0.y, t0.z}, v1{t0.w, t1.x, t1.y}, v2{t1.z, t1.w, t2.x};
+                                const F3 up{0, R.halfHeight, 0};
+                                const F3 axisLo = vmin(R.from, R.from + R.delta) - up, axisHi = vmax(R.from, R.from + R.delta) + up;
+                                c = !boxDisjoint(vmin(v0, vmin(v1, v2)), vmax(v0, vmax(v1, v2)), R.mn, R.mx) && !sepNeverTouches(axisLo, axisHi, R.radius, v0, v1, v2);
+                            }
+                        }
+                        const unsigned long long m = __ballot(c);
+                        const unsigned long long maskA = wide ? ~0ull : 0xffffffffull;
+                        const int nA = __popcll(m & maskA), nB = __popcll(m & ~maskA);
+                        // ray A, then ray B, in ray order: the items of one pair are contiguous
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const int rr = hh ? rB : rA, cnt = hh ? nB : nA;
+                            if (rr < 0) break;
+                            const int g = rr >> 1;
+                            if (g != curPair) { curPair = g; pairStart = total; }
+                            if (total + cnt > kWave) { G = g; total = pairStart; cut = true; break; }
+                            if (c && half == hh) {
+                                const int at = total + prefixCount(hh ? m & ~maskA : m & maskA);
+                                sItemTri[at * 3] = t0; sItemTri[at * 3 + 1] = t1; sItemTri[at * 3 + 2] = t2; sItemRay[at] = rr;
+                            }
+                            total += cnt;
+                        }
+                    }
+                }
+            }
+            SEP_SYNC();
+            if (G == 0) {
+                // the pair at the head does not fit the short form: its casts go through the BVH (sepPair), alone
+#ifdef SGE_SEP_TIMING
+                dbgFall += 1;
+#endif
+                const SepHeld& H = sHeld[sOrder[h0]];
+                const SepPairAgent B{H.S.radius, H.S.halfHeight, H.S.invWeight, H.S.skinWidth, H.S.minGroundDot, H.S.mask};
+                F3 bPos{H.bx, H.S.posY, H.bz}, bVel{H.bvx, H.S.velY, H.bvz};
+                const int j = H.c, rank = H.rank;
+                sepPair(col, A, B, aPos, aVel, posI, velI, bPos, bVel, K.separationMargin, K.heightMargin, st);
+                SEP_SYNC();
+                if (lane == 0) {
+                    unsigned long long* lp = F.live + (size_t)j * 4;
+                    sepStoreG(lp, rank + 1, bPos.x); sepStoreG(lp + 1, rank + 1, bPos.z); sepStoreG(lp + 2, rank + 1, bVel.x); sepStoreG(lp + 3, rank + 1, bVel.z);
+                }
+                h0 += 1;
+                continue;
+            }
+            // (d) the sweep: one lane per item through sweepCapsuleTriangle's states (the expressions of groupSweep)
+            if (total > 0) {
+                const bool mine = lane < total;
+                const int r = mine ? sItemRay[lane] : 0;
+                const SepRayRec& R = sRay[r];
+                const float radius = R.radius, halfHeight = R.halfHeight, len = R.len;
+                const float minAdvance = smax(radius * 0.02f, 1e-4f); // :1295
+                const float contactEps = 1e-5f;
+                const int maxIter = R.maxIter;
+                const F3 from = R.from, dir = R.dir, delta = R.delta;
+                F3 v0{0, 0, 0}, v1{0, 0, 0}, v2{0, 0, 0};
+                int triRank = 0x7fffffff;
+                if (mine) {
+                    const float4 t0 = sItemTri[lane * 3], t1 = sItemTri[lane * 3 + 1], t2 = sItemTri[lane * 3 + 2];
+                    v0 = F3{t0.x, t0.y, t0.z}; v1 = F3{t0.w, t1.x, t1.y}; v2 = F3{t1.z, t1.w, t2.x};
+                    triRank = __float_as_int(t2.w);
+                }
+                const F3 triNormal = normalize(cross(v1 - v0, v2 - v0));
+                int phase = mine ? PH_MARCH : PH_DONE, iter = 0, refineK = 0;
+                float t = 0, lastSafeT = 0, lo = 0, hi = 0, tEval = 0;
+                unsigned long long myKey = ~0ull;
+                float hitNy = 0;
+                while (__any(phase != PH_DONE)) {
+#ifdef SGE_SEP_TIMING
+                    dbgTrips += 1;
+#endif
+                    if (phase == PH_MARCH) {
+                        if (iter >= maxIter || t > len) phase = PH_DONE; // loop head of :1303-1307
+                        else { iter += 1; tEval = t; }
+                    } else if (phase == PH_REFINE) {
+                        tEval = 0.5f * (lo + hi);
+                    }
+                    // speculative bisection (see groupSweep): refineTOI (:1361-1377) is ten dependent evaluations whose points are
+                    // functions of the interval alone; idle lanes evaluate the 2 (6, 14) descendants of a refining item's midpoint in the
+                    // trip in which its lane evaluates the midpoint itself, and that lane then takes 2 (3, 4) steps at once. Node
+                    // numbering: 1 = the owner's midpoint; 2 n = the midpoint after "contact at n" (hi = mid), 2 n + 1 after "clear".
+                    const unsigned long long refMask = __ballot(phase == PH_REFINE), idleMask = __ballot(phase == PH_DONE);
+                    const int nOwn = __popcll(refMask), nHelp = __popcll(idleMask);
+                    int per = 0, levels = 1;
+                    if (nOwn > 0 && nHelp >= 2) {
+                        per = nOwn * 14 <= nHelp ? 14 : (nOwn * 6 <= nHelp ? 6 : 2);
+                        levels = per == 14 ? 4 : (per == 6 ? 3 : 2);
+                    }
+                    const int nServe = per ? (nOwn < nHelp / per ? nOwn : nHelp / per) : 0;
+                    const int oRank = prefixCount(refMask), hIdx = prefixCount(idleMask);
+                    const bool served = per && phase == PH_REFINE && oRank < nServe;
+                    const bool helper = per && phase == PH_DONE && hIdx < nServe * per;
+                    bool cEval = phase != PH_DONE;
+                    float cT = tEval, cHalf = halfHeight, cRadius = radius;
+                    F3 cFrom = from, cDir = dir, c0 = v0, c1 = v1, c2 = v2;
+                    int node = 0, ownerRank = 0;
+                    if (per) {
+                        if (served) { sSpecOwner[oRank] = (unsigned char)lane; sSpecBits[oRank] = 0; }
+                        SEP_SYNC();
+                        ownerRank = helper ? hIdx / per : 0;
+                        node = helper ? hIdx - ownerRank * per + 2 : 0;
+                        const int src = helper ? (int)sSpecOwner[ownerRank] : lane;
+                        float oLo = __shfl(lo, src, kWave), oHi = __shfl(hi, src, kWave);
+                        if (helper) {
+                            const int depth = 31 - __clz(node); // 1 .. 3: walk from the root along the bits of `node` below its leading one
+#pragma unroll
+                            for (int b = 2; b >= 0; --b) {
+                                if (b < depth) {
+                                    const float mid = 0.5f * (oLo + oHi);
+                                    if ((node >> b) & 1) oLo = mid; else oHi = mid;
+                                }
+                            }
+                            cT = 0.5f * (oLo + oHi);
+                            const float4 t0 = sItemTri[src * 3], t1 = sItemTri[src * 3 + 1], t2 = sItemTri[src * 3 + 2];
+                            c0 = F3{t0.x, t0.y, t0.z}; c1 = F3{t0.w, t1.x, t1.y}; c2 = F3{t1.z, t1.w, t2.x};
+                            const SepRayRec& OR = sRay[sItemRay[src]];
+                            cFrom = OR.from; cDir = OR.dir; cHalf = OR.halfHeight; cRadius = OR.radius;
+                            cEval = true;
+                        }
+                    }
+                    bool ownContact = false;
+                    F3 segP{0, 0, 0}, triP{0, 0, 0};
+                    float dist = 0;
+                    if (cEval) dist = segmentTriangleDistance(cFrom + cDir * cT, cHalf, c0, c1, c2, segP, triP);
+                    if (phase != PH_DONE) {
+                        if (phase == PH_MARCH) {
+                            if (dist <= radius + contactEps) { // refineTOI(t0: lastSafeT, t1: t) :1361-1377
+                                const float k0 = smax(0.0f, smin(lastSafeT, len));
+                                const float k1 = smax(0.0f, smin(t, len));
+                                lo = smin(k0, k1);
+                                hi = smax(k0, k1);
+                                if (hi - lo < 1e-5f) { phase = PH_FINAL; tEval = hi; }
+                                else { phase = PH_REFINE; refineK = 0; }
+#ifdef SGE_SEP_TIMING
+                                dbgContact += 1;
+#endif
+                            } else {
+                                lastSafeT = t;
+                                const float advance = smax(dist - radius, minAdvance);
+#ifdef SGE_SEP_TIMING
+                                dbgMarch += 1; if (advance == minAdvance) dbgCrawl += 1;
+#endif
+                                if (advance <= 0) t += minAdvance; else t += advance;
+                            }
+                        } else if (phase == PH_REFINE) {
+                            ownContact = dist <= radius;
+                            if (ownContact) hi = tEval; else lo = tEval;
+                            refineK += 1;
+                            if (refineK == 10) { phase = PH_FINAL; tEval = hi; }
+                        } else { // PH_FINAL :1325-1346, then the acceptance filters of capsuleCastBVH :1084-1097 (blocking casts)
+                            const float tHit = tEval;
+                            F3 nrm;
+                            if (dist < 1e-6f) nrm = dot(triNormal, dir) > 0 ? -triNormal : triNormal;
+                            else nrm = normalize(segP - triP);
+                            F3 triN = triNormal;
+                            if (dot(triN, nrm) < 0) triN = -triN;
+                            phase = PH_DONE;
+                            bool ok = tHit < len;
+                            if (ok) ok = !(dot(delta, nrm) >= 0) && !(dot(delta, triN) >= 0);
+                            if (ok) { myKey = ((unsigned long long)__float_as_uint(tHit) << 32) | (unsigned)triRank; hitNy = nrm.y; atomicMin(&sRay[r].key, myKey); }
+                        }
+                    }
+                    if (per) {
+                        if (helper && dist <= cRadius) atomicOr(&sSpecBits[ownerRank], 1u << node);
+                        SEP_SYNC();
+                        if (served && phase == PH_REFINE) { // (its own step did not finish the bisection)
+                            const unsigned bits = sSpecBits[oRank];
+                            int nn = ownContact ? 2 : 3;
+                            for (int k = 1; k < levels; ++k) {
+                                const float mid = 0.5f * (lo + hi);
+                                const bool c = (bits >> nn) & 1;
+                                if (c) hi = mid; else lo = mid;
+                                refineK += 1;
+                                nn = 2 * nn + (c ? 0 : 1);
+                                if (refineK == 10) { phase = PH_FINAL; tEval = hi; break; }
+                            }
+                        }
+                    }
+                }
+                SEP_SYNC();
+                if (myKey != ~0ull && sRay[r].key == myKey) sRay[r].ny = hitNy; // the hit capsuleCastBlocking returns: minimum (toi, visit rank)
+                SEP_SYNC();
+            }
+            // (e) the pairs of the round in the reference's order; a blocked pair ends the round behind it
+            int done = 0;
+            for (int g = 0; g < G; ++g) {
+                const SepHeld& H = sHeld[sOrder[h0 + g]];
+                const int flags = H.flags;
+                float nbx = H.bx, nbz = H.bz;
+                bool deviates = false;
+                if (flags & SEP_LIVE) {
+                    if (flags & SEP_VN_NEG) { velI.x += H.dvIx; velI.z += H.dvIz; }
+                    const SepRayRec& RA = sRay[2 * g];
+                    const SepRayRec& RB = sRay[2 * g + 1];
+                    const bool blockedA = (flags & SEP_CAST_A) && RA.key != ~0ull && __uint_as_float((unsigned)(RA.key >> 32)) <= A.skinWidth && RA.ny < A.minGroundDot;
+                    const bool blockedB = (flags & SEP_CAST_B) && RB.key != ~0ull && __uint_as_float((unsigned)(RB.key >> 32)) <= H.S.skinWidth && RB.ny < H.S.minGroundDot;
+                    F3 moveA{H.moveAx, 0, H.moveAz}, moveB{H.moveBx, 0, H.moveBz};
+                    bool apply = true;
+                    if (blockedA && !blockedB) { moveA = F3{0, 0, 0}; moveB = F3{-H.nx * H.penetration, 0, -H.nz * H.penetration}; deviates = true; }
+                    else if (blockedB && !blockedA) { moveB = F3{0, 0, 0}; moveA = F3{H.nx * H.penetration, 0, H.nz * H.penetration}; deviates = true; }
+                    else if (blockedA && blockedB) { apply = false; deviates = true; }
+                    if (apply) {
+                        posI = posI + moveA;
+                        const F3 nb = F3{H.bx, H.S.posY, H.bz} + moveB;
+                        nbx = nb.x; nbz = nb.z;
+                    }
+                }
+                if (lane == 0) {
+                    unsigned long long* lp = F.live + (size_t)H.c * 4;
+                    sepStoreG(lp, H.rank + 1, nbx); sepStoreG(lp + 1, H.rank + 1, nbz); sepStoreG(lp + 2, H.rank + 1, H.nbvx); sepStoreG(lp + 3, H.rank + 1, H.nbvz);
+                }
+                done = g + 1;
+                if (deviates) break;
+            }
+            h0 += done;
+            SEP_SYNC();
+        }
+        SEP_TS(i, 3);
+#ifdef SGE_SEP_TIMING
+        {   // (per-lane counters of the sweep: summed over the wavefront)
+            for (int o = 32; o > 0; o >>= 1) { dbgMarch += __shfl_xor(dbgMarch, o, kWave); dbgCrawl += __shfl_xor(dbgCrawl, o, kWave); dbgContact += __shfl_xor(dbgContact, o, kWave); }
+        }
+        SEP_TSV(i, 4, nh); SEP_TSV(i, 5, dbgRounds | (dbgContact << 8) | (dbgCrawl << 16)); SEP_TSV(i, 6, dbgFall | (dbgMarch << 8)); SEP_TSV(i, 7, dbgTrips);
+#endif
+        SepAgentDev* Ai = K.agents + i;
+        if (lane == 0) { sepStore3(Ai->position, posI); sepStore3(Ai->velocity, velI); } // nobody reads it before the pass ends
+    }
+}
+
 // the same pass by ONE wavefront in the reference's own order, from the state at the head of the pass: runs only when the dataflow
 // pass gave up (more than kSepMaxCand candidates for some agent, or an agent pushed further than a cell)
 __global__ __launch_bounds__(kWave) void sep_serial_kernel(SepLaunch K, SepFlow F) {
@@ -3089,7 +3744,7 @@ size_t separationFlowControlOffset(int count) {
 }
 size_t separationFlowBytes(int count) {
     const size_t n = (size_t)count, H = (size_t)separationFlowBuckets(count);
-    return 8 * n + 4 * (H + 1) + 4 * H + 4 * n * 4 + sizeof(int2) * kSepMaxCand * n + 64 + 24 * n + 256;
+    return 8 * n + 4 * (H + 1) + 4 * H + 4 * n * 4 + sizeof(int2) * kSepMaxCand * n + 64 + 24 * n + 48 * (size_t)kSepTriCap * n + 32 * n + 64 * n + 256;
 }
 int separationFlowBuckets(int count) { int H = 64; while (H < 2 * count) H <<= 1; return H; }
 
@@ -3117,21 +3772,31 @@ void launch_separation(const DevCrowd& crowd, const DevCollision& col, int itera
     F.cand = reinterpret_cast<int2*>(carve(sizeof(int2) * kSepMaxCand * (size_t)n));
     F.control = reinterpret_cast<int*>(carve(64));
     F.backup = reinterpret_cast<float*>(carve(24 * (size_t)n));
+    F.stat = reinterpret_cast<SepStaticDev*>(carve(sizeof(SepStaticDev) * (size_t)n));
+    F.live = reinterpret_cast<unsigned long long*>(carve(32 * (size_t)n));
+    F.triCache = reinterpret_cast<float4*>(carve(48 * (size_t)kSepTriCap * n));
+    F.triBox = reinterpret_cast<float*>(carve(32 * (size_t)n));
+    if (getenv("SGE_SEPARATION_BVH_CASTS") && atoi(getenv("SGE_SEPARATION_BVH_CASTS")) != 0) F.triCache = nullptr; // tests: every pair casts through the BVH
     F.H = H;
     F.reach = reach < 2 ? 2 : (reach > 3 ? 3 : reach);
     const int blocks = (n + 255) / 256;
     (void)hipMemsetAsync(F.control + 5, 0, 8, s); // [5] "pushed further than a cell" over the whole step, [6] redo flags of any pass of the step
     hipLaunchKernelGGL(sep_list_kernel, dim3(1), dim3(1024), 0, s, K, F);
+    const int tracePass = getenv("SGE_SEPARATION_TRACE_PASS") ? atoi(getenv("SGE_SEPARATION_TRACE_PASS")) : K.iterations - 1;
     for (int it = 0; it < K.iterations; ++it) {
+        F.trace = it == tracePass ? 1 : 0;
         (void)hipMemsetAsync(F.bucketCursor, 0, 4 * (size_t)H, s);
         hipLaunchKernelGGL(sep_cells_kernel, dim3(blocks), dim3(256), 0, s, K, F);
         hipLaunchKernelGGL(sep_scan_kernel, dim3(1), dim3(1024), 0, s, F);
         hipLaunchKernelGGL(sep_scatter_kernel, dim3(blocks), dim3(256), 0, s, F);
         hipLaunchKernelGGL(sep_sort_kernel, dim3((H + 255) / 256), dim3(256), 0, s, F);
         hipLaunchKernelGGL(sep_cand_kernel, dim3(n), dim3(kWave), 0, s, F);
+        if (F.triCache) hipLaunchKernelGGL(sep_tricache_kernel, dim3(n), dim3(kWave), 0, s, K, F);
         // as many wavefronts as stay resident together do useful work; more would only queue behind them
-        const int waves = std::min(n, currentDeviceCUs() * 8);
-        hipLaunchKernelGGL(sep_flow_kernel, dim3(waves), dim3(kWave), 0, s, K, F);
+        int waves = std::min(n, currentDeviceCUs() * (F.triCache ? 4 : 8)); // (37 KB of LDS per loop in the second form)
+        if (getenv("SGE_SEPARATION_WAVES") && atoi(getenv("SGE_SEPARATION_WAVES")) > 0) waves = std::min(n, atoi(getenv("SGE_SEPARATION_WAVES")));
+        if (F.triCache) hipLaunchKernelGGL(sep_flow2_kernel, dim3(waves), dim3(kWave), 0, s, K, F);
+        else hipLaunchKernelGGL(sep_flow_kernel, dim3(waves), dim3(kWave), 0, s, K, F);
         hipLaunchKernelGGL(sep_serial_kernel, dim3(1), dim3(kWave), 0, s, K, F);
     }
     hipLaunchKernelGGL(separation_post_kernel, dim3(n), dim3(kWave), 0, s, K);
