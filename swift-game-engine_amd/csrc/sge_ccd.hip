@@ -3534,11 +3534,15 @@ __global__ __launch_bounds__(kWave) void sep_flow2_kernel(SepLaunch K, SepFlow F
 #ifdef SGE_SEP_TIMING
                     dbgTrips += 1;
 #endif
+                    // (an item that cannot be touched before its ray's best accepted hit so far is dropped, as in groupSweep: a later or
+                    // equal hit of higher visit rank never wins)
+                    const float bestToi = __uint_as_float((unsigned)(sRay[r].key >> 32));
                     if (phase == PH_MARCH) {
-                        if (iter >= maxIter || t > len) phase = PH_DONE; // loop head of :1303-1307
+                        if (iter >= maxIter || t > len || lastSafeT > bestToi) phase = PH_DONE; // loop head of :1303-1307
                         else { iter += 1; tEval = t; }
                     } else if (phase == PH_REFINE) {
-                        tEval = 0.5f * (lo + hi);
+                        if (lo > bestToi) phase = PH_DONE;
+                        else tEval = 0.5f * (lo + hi);
                     }
                     // speculative bisection (see groupSweep): refineTOI (:1361-1377) is ten dependent evaluations whose points are
                     // functions of the interval alone; idle lanes evaluate the 2 (6, 14) descendants of a refining item's midpoint in the
@@ -3548,11 +3552,19 @@ __global__ __launch_bounds__(kWave) void sep_flow2_kernel(SepLaunch K, SepFlow F
                     const int nOwn = __popcll(refMask), nHelp = __popcll(idleMask);
                     int per = 0, levels = 1;
                     if (nOwn > 0 && nHelp >= 2) {
-                        per = nOwn * 14 <= nHelp ? 14 : (nOwn * 6 <= nHelp ? 6 : 2);
+                        per = nHelp >= 14 ? 14 : (nHelp >= 6 ? 6 : 2); // the earliest brackets get the helpers: their hits prune the others
                         levels = per == 14 ? 4 : (per == 6 ? 3 : 2);
                     }
                     const int nServe = per ? (nOwn < nHelp / per ? nOwn : nHelp / per) : 0;
-                    const int oRank = prefixCount(refMask), hIdx = prefixCount(idleMask);
+                    int oRank = 0; // place of this refining item by (lo, lane)
+                    if (per && nOwn > nServe) {
+                        for (unsigned long long mm = refMask; mm; mm &= mm - 1) {
+                            const int o = __ffsll((long long)mm) - 1;
+                            const float loO = __shfl(lo, o, kWave);
+                            oRank += (loO < lo || (loO == lo && o < lane)) ? 1 : 0;
+                        }
+                    } else oRank = prefixCount(refMask);
+                    const int hIdx = prefixCount(idleMask);
                     const bool served = per && phase == PH_REFINE && oRank < nServe;
                     const bool helper = per && phase == PH_DONE && hIdx < nServe * per;
                     bool cEval = phase != PH_DONE;
