@@ -2905,6 +2905,24 @@ __device__ __forceinline__ bool sepNeverTouches(F3 lo, F3 hi, float radius, F3 v
     if (lbBox > lb) lb = lbBox;
     return lb - radius - 1e-5f - 1e-3f > 0;
 }
+// The same bound for ONE cast: its axis sweeps the parallelogram from +- halfHeight * up, + delta, whose corners — not those of its
+// bounding box — carry the plane distance's minimum.
+__device__ __forceinline__ bool sepCastNeverTouches(F3 from, F3 delta, float halfHeight, float radius, F3 v0, F3 v1, F3 v2) {
+    const F3 n = normalize(cross(v1 - v0, v2 - v0));
+    const F3 up{0, halfHeight, 0};
+    const F3 c0 = from + up, c1 = from - up, c2 = c0 + delta, c3 = c1 + delta;
+    const float d0 = dot(n, c0 - v0), d1 = dot(n, c1 - v0), d2 = dot(n, c2 - v0), d3 = dot(n, c3 - v0);
+    const float dmin = smin(smin(d0, d1), smin(d2, d3)), dmax = smax(smax(d0, d1), smax(d2, d3));
+    float lb = dmin > 0 ? dmin : (dmax < 0 ? -dmax : 0.0f);
+    const F3 lo = vmin(c1, c3), hi = vmax(c0, c2); // (up.y >= 0)
+    const F3 mn = vmin(v0, vmin(v1, v2)), mx = vmax(v0, vmax(v1, v2));
+    const float dx = smax(0.0f, smax(mn.x - hi.x, lo.x - mx.x));
+    const float dy = smax(0.0f, smax(mn.y - hi.y, lo.y - mx.y));
+    const float dz = smax(0.0f, smax(mn.z - hi.z, lo.z - mx.z));
+    const float lbBox = sqrtf(dx * dx + dy * dy + dz * dz);
+    if (lbBox > lb) lb = lbBox;
+    return lb - radius - 1e-5f - 1e-3f > 0;
+}
 // Per agent (one wavefront, all agents in parallel, off the pass's critical path): the triangles whose box overlaps the capsule's box at
 // the head of the pass grown by kSepTriReach AND that the capsule could touch from somewhere in there (sepNeverTouches over the whole
 // region the axis can be in) — what the casts of this agent's pairs can meet unless it is pushed further than that.
@@ -3465,9 +3483,8 @@ __global__ __launch_bounds__(kWave) void sep_flow2_kernel(SepLaunch K, SepFlow F
                                 if (R.src >= 0) { const float4* tp = F.triCache + ((size_t)R.src * kSepTriCap + k) * 3; t0 = tp[0]; t1 = tp[1]; t2 = tp[2]; }
                                 else { t0 = sOwnTri[k * 3]; t1 = sOwnTri[k * 3 + 1]; t2 = sOwnTri[k * 3 + 2]; }
                                 const F3 v0{t0.x, t0.y, t0.z}, v1{t0.w, t1.x, t1.y}, v2{t1.z, t1.w, t2.x};
-                                const F3 up{0, R.halfHeight, 0};
-                                const F3 axisLo = vmin(R.from, R.from + R.delta) - up, axisHi = vmax(R.from, R.from + R.delta) + up;
-                                c = !boxDisjoint(vmin(v0, vmin(v1, v2)), vmax(v0, vmax(v1, v2)), R.mn, R.mx) && !sepNeverTouches(axisLo, axisHi, R.radius, v0, v1, v2);
+                                c = !boxDisjoint(vmin(v0, vmin(v1, v2)), vmax(v0, vmax(v1, v2)), R.mn, R.mx) &&
+                                    !sepCastNeverTouches(R.from, R.delta, R.halfHeight, R.radius, v0, v1, v2);
                             }
                         }
                         const unsigned long long m = __ballot(c);
