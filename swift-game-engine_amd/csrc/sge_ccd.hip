@@ -3205,8 +3205,9 @@ __global__ __launch_bounds__(kWave, 2) void sep_flow_kernel(SepLaunch K, SepFlow
 //    it (its successors' origins were predicted wrong: they go into the next round).
 // A pair whose casts do not fit (more than kSepTriCap triangles in reach, cast outside the cached box, more items than lanes) goes
 // through sepPair's BVH casts as before. Same results, bit for bit (tests/test_separation.py: against the oracle and against the
-// first form). 8,192 agents on the cheese + mirror scene: 85 -> 58 ms per step on the same box (profiles/r4_separation_bench.txt);
-// what is left is real sweeps — a fifth of the loops stand on triangles they touch, ~6 trips of ~3 us each, one after the other.
+// first form). 8,192 agents on the cheese + mirror scene: 79 -> 34 ms per step on the same box, 31,250: 446 -> 194
+// (profiles/r4_separation_bench.txt); what is left is real sweeps — a fifth of the loops stand on triangles they touch, ~5 trips
+// of ~3 us each — and the order itself: ~3 loops are inside their pairs at any time.
 constexpr int kSepHeldCap = 64, kSepRound = 8;
 enum { SEP_LIVE = 1, SEP_CAST_A = 2, SEP_CAST_B = 4, SEP_VN_NEG = 8, SEP_B_CERTAIN = 16 };
 struct SepHeld {
@@ -3295,7 +3296,7 @@ __global__ __launch_bounds__(kWave) void sep_flow2_kernel(SepLaunch K, SepFlow F
         //    alone, and the loop does not wait for it: whoever of the ring is not yet due when the inner ones of its chunk have all
         //    arrived goes back into the list's head (the chunk's own entries are in registers by then) and is passed between the rounds
         //    and behind the pairs — nothing the loop does depends on it, and the ring's own loops see the pass whenever it comes.
-        //    Same process, alternating steps, 8,192 agents: 47.6 -> 36.3 ms per step.
+        //    Two engines in lockstep in one process (tools/separation_ab.py), 8,192 agents: 48.1 -> 34.8 ms per step.
         const bool mayDefer = !sepNoDefer;
         int deferred = 0; // entries sCand[0 .. deferred) wait to be passed (x < 0: done)
         auto passDeferred = [&]() {

@@ -203,14 +203,19 @@ def test_separation_crowd_of_8192(sge):
 
 @pytest.mark.gpu
 def test_separation_crowd_forms_agree_over_a_settling_crowd(sge, monkeypatch):
-    """The crowd path has two forms of a loop's pairs (sge_ccd.hip): the first casts every pair through the BVH one after the other
-    (SGE_SEPARATION_BVH_CASTS=1), the second keeps the changing pairs in LDS and takes their casts from per-agent cached triangles in
-    rounds, skipping casts that provably hit nothing. Same crowd, 8,192 agents on the cheese + mirror scene while it settles from its
-    spawn overlaps (24 steps: long pushes, blocked pairs, agents beside the ornate mirror): bodies and controllers byte-identical after
-    every step, and in the later steps no pass is redone by the serial kernel, so what is compared is the two dataflows."""
+    """The crowd path in three settings (sge_ccd.hip): the first form of the loops casts every pair through the BVH one after the other and
+    keeps the order of the loops that touch an agent as a counter behind a fence (SGE_SEPARATION_BVH_CASTS=1); the second keeps the
+    changing pairs in LDS, takes their casts from per-agent cached triangles in rounds, skips casts that provably hit nothing and
+    carries the counter inside the data — once with every loop waiting for the outer ring of its candidates
+    (SGE_SEPARATION_NO_DEFER=1) and once, the default, passing the ring whenever it comes due.
+    Same crowd, 8,192 agents on the cheese + mirror scene while it settles from its spawn overlaps (24 steps: long pushes, blocked
+    pairs, agents beside the ornate mirror): bodies and controllers byte-identical after every step, and in the later steps no pass
+    is redone by the serial kernel, so what is compared is the three dataflows."""
     n = 8192
+    forms = ({"SGE_SEPARATION_BVH_CASTS": "1", "SGE_SEPARATION_NO_DEFER": "0"}, {"SGE_SEPARATION_BVH_CASTS": "0", "SGE_SEPARATION_NO_DEFER": "1"},
+             {"SGE_SEPARATION_BVH_CASTS": "0", "SGE_SEPARATION_NO_DEFER": "0"})
     engines = []
-    for _ in range(2):
+    for _ in forms:
         e = sge.CharacterEngine(0)
         build_scene(sge, e, n, seed=43, mixed=True, agents=True, rings=3, segments=3, asset_scene=("cheese", "mirror"))
         engines.append(e)
@@ -218,15 +223,17 @@ def test_separation_crowd_forms_agree_over_a_settling_crowd(sge, monkeypatch):
     info = np.zeros(4, np.int32)
     redone_late = 0
     for s in range(24):
-        for k, e in enumerate(engines):
-            monkeypatch.setenv("SGE_SEPARATION_BVH_CASTS", "1" if k == 0 else "0")
+        for form, e in zip(forms, engines):
+            for k, v in form.items():
+                monkeypatch.setenv(k, v)
             e.tick(stages=st)
             assert e.t.lib.sge_debug_separation(e.h, sge.abi.ptr(info)) == 0
             if s >= 12:
                 redone_late += int(info[2] != 0)
-        a, b = (e.download(what=("bodies", "controllers")) for e in engines)
-        for name in ("bodies", "controllers"):
-            assert a[name].tobytes() == b[name].tobytes(), "step %d: %s differ between the two forms" % (s, name)
+        states = [e.download(what=("bodies", "controllers")) for e in engines]
+        for other in states[1:]:
+            for name in ("bodies", "controllers"):
+                assert states[0][name].tobytes() == other[name].tobytes(), "step %d: %s differ between the forms" % (s, name)
     assert redone_late == 0
     for e in engines:
         e.close()

@@ -56,6 +56,7 @@ for n in sizes:
         tick = lambda stages: eng.tick(stages=stages)
     for _ in range(60 if sweeps else 30):
         tick(base | abi.STAGE_SEPARATION)
+        eng.synchronize()  # as a host that keeps its World in step does: the stage's reach for the next step follows from this step's flag
     eng.synchronize()
     pos = eng.download(what=("bodies",))["bodies"]["position"].astype(np.float32)
     depth, hist = dag_depth(pos)
