@@ -2689,7 +2689,7 @@ __global__ __launch_bounds__(kWave, 3) void separation_post_kernel(SepLaunch K) 
 // default) carries the version inside the data. The result is the reference's, bit for bit, for any crowd; what varies is the depth
 // of the dependency graph (tools/separation_depth.py prints it).
 constexpr int kSepTriCap = 128;       // triangles cached per agent; an agent with more in reach casts through the BVH
-constexpr float kSepTriReach = 1.0f;  // the cached box reaches this far beyond the capsule at the head of the pass
+constexpr float kSepTriReach = 1.5f;  // the cached box reaches this far beyond the capsule at the head of the pass (0.5 / 1 / 1.5 / 2.5: 38.9 / 34.4 / 33.7 / 35.0 ms per step)
 constexpr int kSepMaxCand = 1024; // candidates a loop tracks (agents of higher index in its 5 x 5 cells); more: the pass runs serially.
                                   // (256 until round 3: a crowd spawned at 1.6 units' spacing — 31,250 agents on the benchmark scene, one
                                   // GPU's share of configs[3] — has 300-500 per agent and every pass fell back to one wavefront, 2.1 s per
@@ -2713,6 +2713,7 @@ struct SepFlow {
     int H;
     int trace;          // (diagnostics build: this pass writes the timeline)
     int noDefer;        // (experiments: SGE_SEPARATION_NO_DEFER=1, every loop waits for its outer ring as well)
+    float triReach;     // the cached box reaches this far beyond the capsule at the head of the pass (kSepTriReach; SGE_SEPARATION_REACH)
     int reach;          // candidates come from the (2 reach + 1)^2 cells around an agent's cell at the head of the pass: 2 = one cell of
                         // movement + the 3 x 3 pair list (the rule); 3 after a step in which an agent was pushed further than a cell
 };
@@ -2939,11 +2940,12 @@ __global__ __launch_bounds__(kWave) void sep_tricache_kernel(SepLaunch K, SepFlo
     const DevCollision& col = K.col;
     const SepAgentDev& a = K.agents[x];
     const uint32_t mask = K.crowd.params[a.entity].collisionMask;
-    const float e = a.radius + kSepTriReach, ey = a.halfHeight + a.radius + 0.01f;
+    const float triReach = F.triReach;
+    const float e = a.radius + triReach, ey = a.halfHeight + a.radius + 0.01f;
     const F3 minP{a.position[0] - e, a.position[1] - ey, a.position[2] - e}, maxP{a.position[0] + e, a.position[1] + ey, a.position[2] + e};
     // where the capsule's axis is during any cast that stays inside the cached box
-    const F3 axisLo{a.position[0] - kSepTriReach, a.position[1] - a.halfHeight - 0.01f, a.position[2] - kSepTriReach};
-    const F3 axisHi{a.position[0] + kSepTriReach, a.position[1] + a.halfHeight + 0.01f, a.position[2] + kSepTriReach};
+    const F3 axisLo{a.position[0] - triReach, a.position[1] - a.halfHeight - 0.01f, a.position[2] - triReach};
+    const F3 axisHi{a.position[0] + triReach, a.position[1] + a.halfHeight + 0.01f, a.position[2] + triReach};
     int count = 0;
     if (col.root >= 0) {
         int stackSize = initTraversal(col), rangeCount = 0, candCount = 0;
@@ -3847,6 +3849,7 @@ void launch_separation(const DevCrowd& crowd, const DevCollision& col, int itera
     const int blocks = (n + 255) / 256;
     (void)hipMemsetAsync(F.control + 5, 0, 8, s); // [5] "pushed further than a cell" over the whole step, [6] redo flags of any pass of the step
     hipLaunchKernelGGL(sep_list_kernel, dim3(1), dim3(1024), 0, s, K, F);
+    F.triReach = getenv("SGE_SEPARATION_REACH") ? (float)atof(getenv("SGE_SEPARATION_REACH")) : kSepTriReach;
     F.noDefer = getenv("SGE_SEPARATION_NO_DEFER") && atoi(getenv("SGE_SEPARATION_NO_DEFER")) != 0 ? 1 : 0;
     const int tracePass = getenv("SGE_SEPARATION_TRACE_PASS") ? atoi(getenv("SGE_SEPARATION_TRACE_PASS")) : K.iterations - 1;
     for (int it = 0; it < K.iterations; ++it) {
