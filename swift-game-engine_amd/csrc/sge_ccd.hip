@@ -3211,6 +3211,7 @@ __global__ __launch_bounds__(kWave, 2) void sep_flow_kernel(SepLaunch K, SepFlow
 // (profiles/r4_separation_bench.txt); what is left is real sweeps — a fifth of the loops stand on triangles they touch, ~5 trips
 // of ~3 us each — and the order itself: ~3 loops are inside their pairs at any time.
 constexpr int kSepHeldCap = 64, kSepRound = 8;
+constexpr int kSepPollSleep = 8; // x 64 cycles between two polls of a waiting loop (none / 2 / 8 / 32 / 127: 34.0 / 33.4 / 32.8 / 33.3 / 39.3 ms per step)
 enum { SEP_LIVE = 1, SEP_CAST_A = 2, SEP_CAST_B = 4, SEP_VN_NEG = 8, SEP_B_CERTAIN = 16 };
 struct SepHeld {
     unsigned long long key; int c, rank; float bx, bz, bvx, bvz; SepStaticDev S; float box[6]; int triCount, clear;
@@ -3280,7 +3281,7 @@ __global__ __launch_bounds__(kWave) void sep_flow2_kernel(SepLaunch K, SepFlow F
             const unsigned long long* lp = F.live + (size_t)i * 4;
             g0 = sepLoadG(lp); g1 = sepLoadG(lp + 1); g2 = sepLoadG(lp + 2); g3 = sepLoadG(lp + 3);
             if ((int)(g0 >> 32) == needI && (int)(g1 >> 32) == needI && (int)(g2 >> 32) == needI && (int)(g3 >> 32) == needI) break;
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(kSepPollSleep);
         }
         SEP_TS(i, 1);
         const F3 aPos{__uint_as_float((unsigned)g0), SA.posY, __uint_as_float((unsigned)g1)};  // the copy `a` (:1954)
@@ -3395,7 +3396,7 @@ __global__ __launch_bounds__(kWave) void sep_flow2_kernel(SepLaunch K, SepFlow F
                         }
                     }
                 }
-                if (__any(waiting && (inList || !mayDefer))) __builtin_amdgcn_s_sleep(2);
+                if (__any(waiting && (inList || !mayDefer))) __builtin_amdgcn_s_sleep(kSepPollSleep);
             }
             if (mayDefer) { // (the chunk's entries are in registers: the list's head is free up to base + kWave)
                 const unsigned long long late = __ballot(waiting);
@@ -3746,7 +3747,7 @@ __global__ __launch_bounds__(kWave) void sep_flow2_kernel(SepLaunch K, SepFlow F
             SEP_SYNC();
         }
         SEP_SYNC();
-        while (deferred && passDeferred()) __builtin_amdgcn_s_sleep(2);
+        while (deferred && passDeferred()) __builtin_amdgcn_s_sleep(kSepPollSleep);
         SEP_TS(i, 3);
 #ifdef SGE_SEP_TIMING
         {   // (per-lane counters of the sweep: summed over the wavefront)
