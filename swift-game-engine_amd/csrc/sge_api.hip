@@ -1750,7 +1750,7 @@ int sge_tick(sge_context* c, const sge_tick_desc* d) {
                 // resident workgroups or workgroups that hand their places over (see kResidentSkinCharacters)
                 int quarters = 0;
                 if (overlap && c->residentSkinQuarters >= 0) quarters = c->residentSkinQuarters;
-                else if (overlap && count >= kResidentSkinCharacters) quarters = kResidentSkinQuarters;
+                else if (overlap && count >= kResidentSkinCharacters) quarters = (st & SGE_STAGE_AGENTS) ? kResidentSkinQuartersWithAgents : kResidentSkinQuarters;
                 const int form = launch_skin(L, ss, overlap ? c->overlapSkinWorkgroups : 0, c->dSkinQueue.as<int>(), quarters, c->residentSkinCharsPerUnit);
                 SGE_HIP(hipGetLastError()); // a launch that could not start would leave the previous frame's streams in place
                 c->lastSkinQuarters = form > 0 ? quarters : 0; // what ran, not what was asked for (sge_debug_skin_form)

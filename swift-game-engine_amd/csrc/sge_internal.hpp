@@ -294,6 +294,9 @@ constexpr int kStatShards = 256; // device counters: kStatShards lines of 8 x u6
 // dates from the schedule with pose in front of the next move stage and is gone).
 constexpr int kResidentSkinCharacters = 6000;
 constexpr int kResidentSkinQuarters = 6;
+// with character-vs-character sweeps the cast launches are the longer side of the step and one resident LBS workgroup per CU leaves them
+// more room: 10k characters, quarters 3 / 4 / 5 / 6 / 8: 1.13 / 1.06 / 1.10 / 1.14 / 1.18 ms per step (profiles/r4_agents_kernels.txt)
+constexpr int kResidentSkinQuartersWithAgents = 4;
 constexpr int kResidentSkinCharsPerUnit = 4;
 // returns true when the lists of the NEXT step (same range, threshold, cap = nextHeavyCap) have been enqueued behind this stage
 bool launch_move(const MoveLaunch& L, hipStream_t s);
