@@ -237,3 +237,55 @@ def test_separation_crowd_forms_agree_over_a_settling_crowd(sge, monkeypatch):
     assert redone_late == 0
     for e in engines:
         e.close()
+
+
+@pytest.mark.gpu
+def test_separation_crowd_of_31250_forms_agree(sge, monkeypatch):
+    """One GPU's share of configs[3] / configs[4]: 31,250 agents spawned at 1.6 units' spacing with capsules 3 wide — every agent
+    overlaps eight others, a loop has 300-500 candidates (several 64-lane chunks, the ring re-queued from every one of them), and
+    after the first step the stage takes its candidates from 7 x 7 cells. The two forms of the pair loops on the same crowd, eight
+    steps: bodies and controllers byte-identical after every step (the first steps are redone by the serial kernel in both — an
+    agent is pushed further than a cell — so they compare that kernel with itself; the later ones compare the two dataflows), every
+    solid agent listed, and the stage leaves the crowd less entangled than it found it."""
+    n = 31250
+    forms = ({"SGE_SEPARATION_BVH_CASTS": "1"}, {"SGE_SEPARATION_BVH_CASTS": "0"})
+    engines = []
+    for _ in forms:
+        e = sge.CharacterEngine(0)
+        build_scene(sge, e, n, seed=43, mixed=True, agents=True, rings=3, segments=3, asset_scene=("cheese", "mirror"))
+        engines.append(e)
+    st = (sge.abi.STAGE_ALL & ~sge.abi.STAGE_SKIN) | sge.abi.STAGE_SEPARATION
+    info = np.zeros(4, np.int32)
+
+    def overlapping_pairs(pos, radius=1.5):
+        # agents closer than two radii in XZ, counted over a uniform grid (numpy; a measure of entanglement, not of the reference's rule)
+        cell = 2 * radius
+        key = np.floor(pos[:, [0, 2]] / cell).astype(np.int64)
+        order = np.lexsort((key[:, 1], key[:, 0]))
+        p = pos[order][:, [0, 2]]
+        total = 0
+        for shift in range(1, 40):
+            d = p[shift:] - p[:-shift]
+            total += int(((d * d).sum(1) < (2 * radius) ** 2).sum())
+        return total
+
+    before = overlapping_pairs(engines[0].download(what=("bodies",))["bodies"]["position"].astype(np.float64))
+    redone = []
+    for s in range(8):
+        flags = []
+        for form, e in zip(forms, engines):
+            for k, v in form.items():
+                monkeypatch.setenv(k, v)
+            e.tick(stages=st)
+            assert e.t.lib.sge_debug_separation(e.h, sge.abi.ptr(info)) == 0
+            assert info[0] == n
+            flags.append(int(info[2]))
+        redone.append(flags)
+        a, b = (e.download(what=("bodies", "controllers")) for e in engines)
+        for name in ("bodies", "controllers"):
+            assert a[name].tobytes() == b[name].tobytes(), "step %d: %s differ between the two forms" % (s, name)
+    assert redone[-1] == [0, 0] and redone[-2] == [0, 0], "the dataflow passes of the last steps were redone serially: %r" % (redone,)
+    after = overlapping_pairs(engines[0].download(what=("bodies",))["bodies"]["position"].astype(np.float64))
+    assert after < before, (before, after)
+    for e in engines:
+        e.close()
