@@ -89,10 +89,16 @@ def test_order_is_the_character_index(sge):
 
 
 @pytest.mark.gpu
-def test_separation_stage_gpu_parity(sge):
+@pytest.mark.parametrize("form", ["default", "one_wavefront"])
+def test_separation_stage_gpu_parity(sge, monkeypatch, form):
     """f3 on the GPU: 192 solid agents crowded onto the real cheese + mirror scene, move-and-slide + character-vs-character sweeps +
-    AgentSeparationSystem every step: positions, velocities and controller state bit-exact with the oracle."""
+    AgentSeparationSystem every step: positions, velocities and controller state bit-exact with the oracle. `default` is the dataflow
+    over agents (any crowd of more than a few dozen), `one_wavefront` the loop walked by one wavefront with everything in LDS
+    (SGE_SEPARATION_FLOW=0: what smaller crowds get)."""
     import torch
+
+    if form == "one_wavefront":
+        monkeypatch.setenv("SGE_SEPARATION_FLOW", "0")
 
     gpu = sge.CharacterEngine(0)
     cpu = ob.oracle_engine()
