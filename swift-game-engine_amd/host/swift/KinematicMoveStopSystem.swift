@@ -118,7 +118,7 @@ public final class ActionAnimationSystem: FixedStepSystem {
     public func fixedUpdate(world: World, dt: Float) { sgeTick(crowd, dt: dt, stages: UInt32(SGE_STAGE_ACTION)) }
 }
 
-/// Systems.swift:1906-2210 — resolved in entity-id order (the order of GPUCrowd.entities); at most SGE_MAX_SEPARATION_AGENTS agents
+/// Systems.swift:1906-2210 — resolved in entity-id order (the order of GPUCrowd.entities); any crowd size (sge_amd.h, SGE_STAGE_SEPARATION)
 public final class AgentSeparationSystem: FixedStepSystem {
     private let crowd: GPUCrowd
     public var iterations: Int { didSet { push() } }
