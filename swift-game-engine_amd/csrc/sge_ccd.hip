@@ -3211,6 +3211,7 @@ __global__ __launch_bounds__(kWave, 2) void sep_flow_kernel(SepLaunch K, SepFlow
 // (profiles/r4_separation_bench.txt); what is left is real sweeps — a fifth of the loops stand on triangles they touch, ~5 trips
 // of ~3 us each — and the order itself: ~3 loops are inside their pairs at any time.
 constexpr int kSepHeldCap = 64, kSepRound = 8;
+constexpr unsigned kSepSpinLimit = 1u << 22; // polls of one loop before it gives the pass up (a poll is ~0.5 us)
 constexpr int kSepPollSleep = 8; // x 64 cycles between two polls of a waiting loop (none / 2 / 8 / 32 / 127: 34.0 / 33.4 / 32.8 / 33.3 / 39.3 ms per step)
 enum { SEP_LIVE = 1, SEP_CAST_A = 2, SEP_CAST_B = 4, SEP_VN_NEG = 8, SEP_B_CERTAIN = 16 };
 struct SepHeld {
@@ -3254,6 +3255,18 @@ __global__ __launch_bounds__(kWave) void sep_flow2_kernel(SepLaunch K, SepFlow F
     if (__hip_atomic_load(&F.control[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) return; // the candidate lists overflowed: serial pass
     const float cellSize = __int_as_float(F.control[3]);
     const bool sepNoDefer = F.noDefer != 0;
+    // Every wait in here is for a lower loop, and the lowest unfinished loop waits for nobody: the waits end. They are bounded all the
+    // same (a wavefront that spun forever would take the card with it): after kSepSpinLimit polls — seconds, where the longest
+    // legitimate wait is a pass, i.e. tens of milliseconds — a loop raises bit 2 of the pass's redo flags, every other loop sees it
+    // within 1,024 polls, the kernel drains, and the pass is redone by the serial kernel from the saved state.
+    unsigned spins = 0;
+    auto giveUp = [&]() {
+        spins += 1;
+        if ((spins & 1023u) != 0) return false;
+        const bool over = spins > kSepSpinLimit || (__hip_atomic_load(&F.control[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4);
+        if (over && lane == 0) atomicOr(&F.control[2], 4);
+        return over;
+    };
     while (true) {
         SEP_SYNC();
         if (lane == 0) { sTicket = atomicAdd(&F.control[1], 1); sHeldCount = 0; }
@@ -3281,6 +3294,7 @@ __global__ __launch_bounds__(kWave) void sep_flow2_kernel(SepLaunch K, SepFlow F
             const unsigned long long* lp = F.live + (size_t)i * 4;
             g0 = sepLoadG(lp); g1 = sepLoadG(lp + 1); g2 = sepLoadG(lp + 2); g3 = sepLoadG(lp + 3);
             if ((int)(g0 >> 32) == needI && (int)(g1 >> 32) == needI && (int)(g2 >> 32) == needI && (int)(g3 >> 32) == needI) break;
+            if (giveUp()) return;
             __builtin_amdgcn_s_sleep(kSepPollSleep);
         }
         SEP_TS(i, 1);
@@ -3396,7 +3410,7 @@ __global__ __launch_bounds__(kWave) void sep_flow2_kernel(SepLaunch K, SepFlow F
                         }
                     }
                 }
-                if (__any(waiting && (inList || !mayDefer))) __builtin_amdgcn_s_sleep(kSepPollSleep);
+                if (__any(waiting && (inList || !mayDefer))) { if (giveUp()) return; __builtin_amdgcn_s_sleep(kSepPollSleep); }
             }
             if (mayDefer) { // (the chunk's entries are in registers: the list's head is free up to base + kWave)
                 const unsigned long long late = __ballot(waiting);
@@ -3747,7 +3761,7 @@ __global__ __launch_bounds__(kWave) void sep_flow2_kernel(SepLaunch K, SepFlow F
             SEP_SYNC();
         }
         SEP_SYNC();
-        while (deferred && passDeferred()) __builtin_amdgcn_s_sleep(kSepPollSleep);
+        while (deferred && passDeferred()) { if (giveUp()) return; __builtin_amdgcn_s_sleep(kSepPollSleep); }
         SEP_TS(i, 3);
 #ifdef SGE_SEP_TIMING
         {   // (per-lane counters of the sweep: summed over the wavefront)
