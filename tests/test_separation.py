@@ -295,3 +295,30 @@ def test_separation_crowd_of_31250_forms_agree(sge, monkeypatch):
     assert after < before, (before, after)
     for e in engines:
         e.close()
+
+
+@pytest.mark.gpu
+def test_separation_crowd_of_2048_soak(sge):
+    """The default form of the crowd path against the oracle's sequential loop over time: 2,048 agents packed onto a quarter of the
+    cheese + mirror scene (capsules 3 wide at ~2.2 units' spacing: every agent overlaps its neighbours, pairs are blocked at the
+    mirror, agents stand on the bumps of the cheese), 40 steps, bodies and controllers bit-exact after every fifth."""
+    gpu = sge.CharacterEngine(0)
+    cpu = ob.oracle_engine()
+    n = 2048
+    for e in (gpu, cpu):
+        build_scene(sge, e, n, seed=47, mixed=True, agents=True, rings=3, segments=3, asset_scene=("cheese", "mirror"), footprint=100.0)
+    st = (sge.abi.STAGE_ALL & ~sge.abi.STAGE_SKIN) | sge.abi.STAGE_SEPARATION
+    info = np.zeros(4, np.int32)
+    redone = 0
+    for s in range(40):
+        gpu.tick(stages=st)
+        ob.tick_mt(cpu, 8, stages=st)
+        assert gpu.t.lib.sge_debug_separation(gpu.h, sge.abi.ptr(info)) == 0
+        redone += int(info[2] != 0)
+        if s % 5 == 4:
+            compare_states(sge, gpu, cpu, n)
+    assert info[0] == n
+    print("steps redone serially: %d of 40" % redone)
+    assert redone <= 10, "%d of 40 steps fell back to the serial kernel: the dataflow was hardly compared" % redone
+    gpu.close()
+    cpu.close()
