@@ -196,12 +196,15 @@ def test_separation_crowd_of_8192(sge):
         build_scene(sge, e, n, seed=43, mixed=True, agents=True, rings=3, segments=3, asset_scene=("cheese", "mirror"))
     st = (sge.abi.STAGE_ALL & ~sge.abi.STAGE_SKIN) | sge.abi.STAGE_SEPARATION
     info = np.zeros(4, np.int32)
-    for s in range(3):
+    dataflow_steps = 0
+    for s in range(8):
         gpu.tick(stages=st)
         ob.tick_mt(cpu, 8, stages=st)
         compare_states(sge, gpu, cpu, n)
         assert gpu.t.lib.sge_debug_separation(gpu.h, sge.abi.ptr(info)) == 0
         assert info[0] == n
+        dataflow_steps += int(info[2] == 0)
+    assert dataflow_steps >= 3, "only %d of 8 steps were not redone by the serial kernel" % dataflow_steps
     assert gpu.move_stats().overflow == 0
     gpu.close()
     cpu.close()
