@@ -691,7 +691,9 @@ typedef struct sge_move_stats {
 int sge_separation_params(sge_context* ctx, int32_t iterations, float separation_margin, float height_margin);
 /* Diagnostics of the crowd path, last pass of the last step: out[4] = listed agents, loops drawn, redo flags (bit 0: an agent had
    more than 1,024 neighbours to track, bit 1: an agent was pushed further than a grid cell, bit 2: a loop's bounded wait ran out —
-   not expected; in every case the pass was redone by the one-wavefront form, same result), cell size (float bits). */
+   not expected —, bit 3: a loop had more than 64 pairs that change something; in every case the pass was redone by the one-wavefront
+   form, same result; a pass that only raised bit 1 is first tried again on the device with candidates from 7 x 7 cells and counts
+   as redone only if that fails too), cell size (float bits). */
 int sge_debug_separation(sge_context* ctx, int32_t* out);
 /* Which form the newest skin stage of sge_tick took (the rule is in DESIGN.md 3.5): quarters of a RESIDENT workgroup per CU (0: one
    workgroup per character, coming and going) and characters per work unit. bench.py names the kernel it prices from this. */

@@ -2713,6 +2713,7 @@ struct SepFlow {
     int H;
     int trace;          // (diagnostics build: this pass writes the timeline)
     int noDefer;        // (experiments: SGE_SEPARATION_NO_DEFER=1, every loop waits for its outer ring as well)
+    int retry;          // this launch belongs to the second attempt of a pass (candidates from 7 x 7 cells): it runs only if control[8] says so
     float triReach;     // the cached box reaches this far beyond the capsule at the head of the pass (kSepTriReach; SGE_SEPARATION_REACH)
     int reach;          // candidates come from the (2 reach + 1)^2 cells around an agent's cell at the head of the pass: 2 = one cell of
                         // movement + the 3 x 3 pair list (the rule); 3 after a step in which an agent was pushed further than a cell
@@ -2853,6 +2854,7 @@ __global__ __launch_bounds__(kWave) void sep_cand_kernel(SepFlow F) {
     __shared__ int sList[kSepMaxCand];
     const int n = F.control[0], k = blockIdx.x, lane = laneId();
     if (k >= n) return;
+    if (F.retry && F.control[8] == 0) return;
     if (lane == 0) sCount = 0;
     __syncthreads();
     const int cx = F.cell[2 * k], cz = F.cell[2 * k + 1];
@@ -3253,6 +3255,7 @@ __global__ __launch_bounds__(kWave) void sep_flow2_kernel(SepLaunch K, SepFlow F
     const int n = F.control[0];
     if (n <= 1) return;
     if (__hip_atomic_load(&F.control[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) return; // the candidate lists overflowed: serial pass
+    if (F.retry && F.control[8] == 0) return; // the pass's first attempt stood
     const float cellSize = __int_as_float(F.control[3]);
     const bool sepNoDefer = F.noDefer != 0;
     // Every wait in here is for a lower loop, and the lowest unfinished loop waits for nobody: the waits end. They are bounded all the
@@ -3405,7 +3408,7 @@ __global__ __launch_bounds__(kWave) void sep_flow2_kernel(SepLaunch K, SepFlow F
                             H.moveAx = moveAx; H.moveAz = moveAz; H.moveBx = moveBx; H.moveBz = moveBz; H.nx = nx; H.nz = nz; H.penetration = penetration;
                             H.dvIx = dvIx; H.dvIz = dvIz; H.nbvx = nbvx; H.nbvz = nbvz; H.flags = flags;
                         } else {
-                            if (hold) atomicOr(&F.control[2], 1); // more changing pairs than this form keeps: the pass runs serially
+                            if (hold) atomicOr(&F.control[2], 8); // more changing pairs than this form keeps: the pass runs serially
                             sepStoreG(lp, rank + 1, bx); sepStoreG(lp + 1, rank + 1, bz); sepStoreG(lp + 2, rank + 1, bvx); sepStoreG(lp + 3, rank + 1, bvz);
                         }
                     }
@@ -3774,6 +3777,25 @@ __global__ __launch_bounds__(kWave) void sep_flow2_kernel(SepLaunch K, SepFlow F
     }
 }
 
+// A pass in which an agent was pushed further than its candidates' cells allow (control[2] == 2: nothing else went wrong) is run again
+// from the saved state with candidates from 7 x 7 cells, on the device's own decision: the serial kernel takes 0.35 s for 8,192
+// agents and 2.4 s for 31,250, the second attempt what a pass takes. (The host widens the following steps' reach from the same
+// flag; this is for the step that shows it first — a crowd spawned on top of itself, a teleport.)
+__global__ void sep_retry_decide_kernel(SepFlow F) {
+    const int again = F.control[2] == 2 ? 1 : 0;
+    F.control[8] = again;
+    if (again) { F.control[1] = 0; F.control[2] = 0; F.control[9] += 1; }
+}
+__global__ void sep_retry_restore_kernel(SepLaunch K, SepFlow F) {
+    const int n = F.control[0], i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || F.control[8] == 0) return;
+    SepAgentDev& a = K.agents[i];
+    for (int k = 0; k < 3; ++k) { a.position[k] = F.backup[i * 6 + k]; a.velocity[k] = F.backup[i * 6 + 3 + k]; }
+    F.ver[i] = 0;
+    const float lv[4] = {a.position[0], a.position[2], a.velocity[0], a.velocity[2]};
+    for (int k = 0; k < 4; ++k) F.live[(size_t)i * 4 + k] = (unsigned long long)__float_as_uint(lv[k]); // version 0
+}
+
 // the same pass by ONE wavefront in the reference's own order, from the state at the head of the pass: runs only when the dataflow
 // pass gave up (more than kSepMaxCand candidates for some agent, or an agent pushed further than a cell)
 __global__ __launch_bounds__(kWave) void sep_serial_kernel(SepLaunch K, SepFlow F) {
@@ -3869,6 +3891,8 @@ void launch_separation(const DevCrowd& crowd, const DevCollision& col, int itera
     (void)hipMemsetAsync(F.control + 5, 0, 8, s); // [5] "pushed further than a cell" over the whole step, [6] redo flags of any pass of the step
     hipLaunchKernelGGL(sep_list_kernel, dim3(1), dim3(1024), 0, s, K, F);
     F.triReach = getenv("SGE_SEPARATION_REACH") ? (float)atof(getenv("SGE_SEPARATION_REACH")) : kSepTriReach;
+    F.retry = 0;
+    const bool noRetry = getenv("SGE_SEPARATION_NO_RETRY") && atoi(getenv("SGE_SEPARATION_NO_RETRY")) != 0; // experiments / tests
     F.noDefer = getenv("SGE_SEPARATION_NO_DEFER") && atoi(getenv("SGE_SEPARATION_NO_DEFER")) != 0 ? 1 : 0;
     const int tracePass = getenv("SGE_SEPARATION_TRACE_PASS") ? atoi(getenv("SGE_SEPARATION_TRACE_PASS")) : K.iterations - 1;
     for (int it = 0; it < K.iterations; ++it) {
@@ -3885,6 +3909,14 @@ void launch_separation(const DevCrowd& crowd, const DevCollision& col, int itera
         if (getenv("SGE_SEPARATION_WAVES") && atoi(getenv("SGE_SEPARATION_WAVES")) > 0) waves = std::min(n, atoi(getenv("SGE_SEPARATION_WAVES")));
         if (F.triCache) hipLaunchKernelGGL(sep_flow2_kernel, dim3(waves), dim3(kWave), 0, s, K, F);
         else hipLaunchKernelGGL(sep_flow_kernel, dim3(waves), dim3(kWave), 0, s, K, F);
+        if (F.reach < 3 && F.triCache && !noRetry) { // second attempt with wider candidate cells, if the device finds the first one short
+            SepFlow R = F;
+            R.reach = 3; R.retry = 1;
+            hipLaunchKernelGGL(sep_retry_decide_kernel, dim3(1), dim3(1), 0, s, F);
+            hipLaunchKernelGGL(sep_retry_restore_kernel, dim3(blocks), dim3(256), 0, s, K, F);
+            hipLaunchKernelGGL(sep_cand_kernel, dim3(n), dim3(kWave), 0, s, R);
+            hipLaunchKernelGGL(sep_flow2_kernel, dim3(waves), dim3(kWave), 0, s, K, R);
+        }
         hipLaunchKernelGGL(sep_serial_kernel, dim3(1), dim3(kWave), 0, s, K, F);
     }
     hipLaunchKernelGGL(separation_post_kernel, dim3(n), dim3(kWave), 0, s, K);
